@@ -1,0 +1,93 @@
+// elem.h — shared device helpers for the row-streaming (HBM-bound) kernels.
+#pragma once
+#include "platform.h"
+
+#define MDS_DISPATCH_DTYPE(dtype, T, ...)                                         \
+  do {                                                                            \
+    if ((dtype) == MDS_F32) { typedef float T; __VA_ARGS__; }                     \
+    else if ((dtype) == MDS_BF16) { typedef bf16_t T; __VA_ARGS__; }              \
+    else { mds_set_error("unsupported dtype %d", (int)(dtype)); return MDS_ERR_UNSUPPORTED; } \
+  } while (0)
+
+// A 256-thread block walks a [rows][C] tensor 8 channels (16 B bf16 / 32 B fp32) per thread:
+// cpr = C/8 threads cover one row, rpb = 256/cpr rows per pass; a thread keeps its channel
+// chunk for the whole kernel so per-channel parameters live in registers.
+struct RowMap {
+  int cpr, rpb, chunk, rsub;
+  bool valid;
+};
+MDS_DEV RowMap rowmap(int C) {
+  RowMap m;
+  m.cpr = C >> 3;
+  m.rpb = 256 / m.cpr;
+  if (m.rpb < 1) m.rpb = 1;
+  m.chunk = threadIdx.x % m.cpr;
+  m.rsub = threadIdx.x / m.cpr;
+  m.valid = m.rsub < m.rpb;
+  return m;
+}
+// host: rows per block pass
+static inline int rows_per_pass(int C) { int cpr = C / 8; int r = 256 / cpr; return r < 1 ? 1 : r; }
+// host: number of blocks for a row-streaming kernel over M rows (cap ~2048 blocks, grid-stride)
+static inline int stream_blocks(long M, int C) {
+  long b = (M + rows_per_pass(C) - 1) / rows_per_pass(C);
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+MDS_DEV void load8f(const float* p, float (&v)[8]) { load8(p, v); }
+
+// Reduce NV 8-vectors across the rsub dimension of the block; threads with rsub == 0 end up
+// holding the block totals for their chunk.  `red` is LDS of >= 256*8*NV floats.
+template <int NV>
+MDS_DEV void block_reduce_rows(float (&acc)[NV][8], const RowMap& m, float* red) {
+  __syncthreads();
+  if (m.valid) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[((m.rsub * NV + v) * m.cpr + m.chunk) * 8 + j] = acc[v][j];
+  }
+  __syncthreads();
+  if (m.valid && m.rsub == 0) {
+    for (int r = 1; r < m.rpb; ++r)
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[v][j] += red[((r * NV + v) * m.cpr + m.chunk) * 8 + j];
+  }
+}
+
+// gradient-source evaluation (see mds_gsrc_t): g = f(u, z, gate, dpooled, mask)
+template <typename T>
+MDS_DEV void eval_g(const mds_gsrc_t& gs, long row, int c0, int C, const float (&z)[8], float (&g)[8]) {
+  float u[8];
+  load8((const T*)gs.u + row * (long)C + c0, u);
+  if (gs.mode == MDS_G_PLAIN) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = u[j];
+  } else if (gs.mode == MDS_G_SILU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = u[j] * silu_gradf_(z[j]);
+  } else if (gs.mode == MDS_G_SE_SILU) {
+    long grp = row / gs.rows_per_group;
+    float ga[8], dp[8];
+    load8f(gs.gate + grp * C + c0, ga);
+    load8f(gs.dpooled + grp * C + c0, dp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = (u[j] * ga[j] + dp[j]) * silu_gradf_(z[j]);
+  } else {  // MDS_G_MASK
+    float mk = gs.mask ? gs.mask[row / gs.rows_per_group] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = u[j] * mk;
+  }
+}
+
+// prologue evaluation on 8 channels of one row (scale/shift already in registers)
+MDS_DEV void apply_pro8(int mode, float (&v)[8], const float (&sc)[8], const float (&sh)[8]) {
+  if (mode == MDS_PRO_NONE) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float z = v[j] * sc[j] + sh[j];
+    v[j] = (mode == MDS_PRO_AFFINE) ? z : siluf_(z);
+  }
+}

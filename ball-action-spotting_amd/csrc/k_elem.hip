@@ -1,0 +1,303 @@
+// k_elem.hip — HBM-bound row-streaming kernels: 16-byte vector loads, per-channel parameters
+// in registers, LDS + wave reductions for the per-channel / per-group sums.
+#include "elem.h"
+
+// ------------------------------------------------------------------ bn_res
+template <typename T>
+__global__ void bn_res_kernel(mds_bn_res_args a) {
+  const RowMap m = rowmap(a.C);
+  if (!m.valid) return;
+  const int c0 = m.chunk * 8;
+  float sc[8], sh[8];
+  load8f(a.scale + c0, sc);
+  load8f(a.shift + c0, sh);
+  const T* y = (const T*)a.y;
+  const T* s = (const T*)a.shortcut;
+  T* o = (T*)a.out;
+  for (long row = (long)blockIdx.x * m.rpb + m.rsub; row < a.M; row += (long)gridDim.x * m.rpb) {
+    float v[8];
+    load8(y + row * a.C + c0, v);
+    float mk = a.mask ? a.mask[row / a.rows_per_group] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float z = v[j] * sc[j] + sh[j];
+      if (a.act) z = siluf_(z);
+      v[j] = z * mk;
+    }
+    if (s) {
+      float r[8];
+      load8(s + row * a.C + c0, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    store8(o + row * a.C + c0, v);
+  }
+}
+extern "C" int mds_bn_res(const mds_bn_res_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->M > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 2048, "bn_res: bad dims M=%ld C=%d", a ? a->M : 0, a ? a->C : 0);
+  MDS_REQUIRE(a->y && a->out && a->scale && a->shift, "bn_res: null pointer");
+  MDS_REQUIRE(!a->mask || a->rows_per_group > 0, "bn_res: mask needs rows_per_group");
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_res_kernel<T>, dim3(stream_blocks(a->M, a->C)), dim3(256), 0, stream, *a));
+  return mds_check_launch("bn_res");
+}
+
+// ------------------------------------------------------------------ grouped reductions
+// grid = (blocks_per_group, groups); block walks rows of its group.
+template <typename T>
+__global__ void se_pool_kernel(mds_se_pool_args a) {
+  __shared__ float red[256 * 8];
+  const RowMap m = rowmap(a.C);
+  const int c0 = m.chunk * 8;
+  float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
+  if (m.valid) {
+    float sc[8], sh[8];
+    load8f(a.scale + c0, sc);
+    load8f(a.shift + c0, sh);
+    const T* y = (const T*)a.y + (long)blockIdx.y * a.rows_per_group * a.C;
+    for (long r = (long)blockIdx.x * m.rpb + m.rsub; r < a.rows_per_group; r += (long)gridDim.x * m.rpb) {
+      float v[8];
+      load8(y + r * a.C + c0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[0][j] += siluf_(v[j] * sc[j] + sh[j]);
+    }
+  }
+  block_reduce_rows<1>(acc, m, red);
+  if (m.valid && m.rsub == 0) {
+    const float inv = 1.0f / (float)a.rows_per_group;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(a.pooled + (long)blockIdx.y * a.C + c0 + j, acc[0][j] * inv);
+  }
+}
+static inline int group_blocks(long rows, int C) {
+  long b = (rows + (long)rows_per_pass(C) * 8 - 1) / ((long)rows_per_pass(C) * 8);
+  return (int)(b > 64 ? 64 : (b < 1 ? 1 : b));
+}
+extern "C" int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "se_pool: bad dims");
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(se_pool_kernel<T>, dim3(group_blocks(a->rows_per_group, a->C), a->groups), dim3(256), 0, stream, *a));
+  return mds_check_launch("se_pool");
+}
+
+template <typename T>
+__global__ void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
+  __shared__ float red[256 * 8];
+  const RowMap m = rowmap(a.C);
+  const int c0 = m.chunk * 8;
+  float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
+  if (m.valid) {
+    float sc[8], sh[8];
+    load8f(a.scale + c0, sc);
+    load8f(a.shift + c0, sh);
+    const long base = (long)blockIdx.y * a.rows_per_group * a.C;
+    const T* y = (const T*)a.y + base;
+    const T* u = (const T*)a.u + base;
+    for (long r = (long)blockIdx.x * m.rpb + m.rsub; r < a.rows_per_group; r += (long)gridDim.x * m.rpb) {
+      float v[8], uu[8];
+      load8(y + r * a.C + c0, v);
+      load8(u + r * a.C + c0, uu);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[0][j] += uu[j] * siluf_(v[j] * sc[j] + sh[j]);
+    }
+  }
+  block_reduce_rows<1>(acc, m, red);
+  if (m.valid && m.rsub == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(a.dgate + (long)blockIdx.y * a.C + c0 + j, acc[0][j]);
+  }
+}
+extern "C" int mds_se_bwd_reduce(const mds_se_bwd_reduce_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "se_bwd_reduce: bad dims");
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(se_bwd_reduce_kernel<T>, dim3(group_blocks(a->rows_per_group, a->C), a->groups), dim3(256), 0, stream, *a));
+  return mds_check_launch("se_bwd_reduce");
+}
+
+// ------------------------------------------------------------------ BN backward reduce / apply
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_args a) {
+  __shared__ float red[256 * 8 * 2];
+  const RowMap m = rowmap(a.C);
+  const int c0 = m.chunk * 8;
+  float acc[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+  if (m.valid) {
+    float sc[8], sh[8], mu[8], rs[8];
+    load8f(a.bn + 0 * a.C + c0, sc);
+    load8f(a.bn + 1 * a.C + c0, sh);
+    load8f(a.bn + 2 * a.C + c0, mu);
+    load8f(a.bn + 3 * a.C + c0, rs);
+    const T* y = (const T*)a.y;
+    for (long row = (long)blockIdx.x * m.rpb + m.rsub; row < a.M; row += (long)gridDim.x * m.rpb) {
+      float v[8], z[8], g[8];
+      load8(y + row * a.C + c0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = v[j] * sc[j] + sh[j];
+      eval_g<T>(a.g, row, c0, a.C, z, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc[0][j] += g[j];
+        acc[1][j] += g[j] * ((v[j] - mu[j]) * rs[j]);
+      }
+    }
+  }
+  block_reduce_rows<2>(acc, m, red);
+  if (m.valid && m.rsub == 0) {
+    float* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * a.C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(st + c0 + j, acc[0][j]);
+      atomicAdd(st + a.C + c0 + j, acc[1][j]);
+    }
+  }
+}
+extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->M > 0 && a->C % 8 == 0 && a->C <= 2048, "bn_bwd_reduce: bad dims");
+  MDS_REQUIRE(a->g.u && a->y && a->bn && a->stats, "bn_bwd_reduce: null pointer");
+  MDS_REQUIRE(a->g.mode == MDS_G_PLAIN || a->g.mode == MDS_G_SILU || a->g.rows_per_group > 0, "bn_bwd_reduce: rows_per_group");
+  int nb = stream_blocks(a->M, a->C);
+  if (nb > 512) nb = 512;
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_reduce_kernel<T>, dim3(nb), dim3(256), 0, stream, *a));
+  return mds_check_launch("bn_bwd_reduce");
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(mds_bn_bwd_apply_args a) {
+  const RowMap m = rowmap(a.C);
+  if (!m.valid) return;
+  const int c0 = m.chunk * 8;
+  float sc[8], sh[8], mu[8], rs[8], k0[8], k1[8], k2[8];
+  load8f(a.bn + 0 * a.C + c0, sc);
+  load8f(a.bn + 1 * a.C + c0, sh);
+  load8f(a.bn + 2 * a.C + c0, mu);
+  load8f(a.bn + 3 * a.C + c0, rs);
+  load8f(a.coef + 0 * a.C + c0, k0);
+  load8f(a.coef + 1 * a.C + c0, k1);
+  load8f(a.coef + 2 * a.C + c0, k2);
+  const T* y = (const T*)a.y;
+  T* dy = (T*)a.dy;
+  for (long row = (long)blockIdx.x * m.rpb + m.rsub; row < a.M; row += (long)gridDim.x * m.rpb) {
+    float v[8], z[8], g[8];
+    load8(y + row * a.C + c0, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = v[j] * sc[j] + sh[j];
+    eval_g<T>(a.g, row, c0, a.C, z, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = k0[j] * (g[j] - k1[j] - (v[j] - mu[j]) * rs[j] * k2[j]);
+    store8(dy + row * a.C + c0, g);
+  }
+}
+extern "C" int mds_bn_bwd_apply(const mds_bn_bwd_apply_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->M > 0 && a->C % 8 == 0 && a->C <= 2048, "bn_bwd_apply: bad dims");
+  MDS_REQUIRE(a->g.u && a->y && a->bn && a->coef && a->dy, "bn_bwd_apply: null pointer");
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_apply_kernel<T>, dim3(stream_blocks(a->M, a->C)), dim3(256), 0, stream, *a));
+  return mds_check_launch("bn_bwd_apply");
+}
+
+// ------------------------------------------------------------------ GeM (fp32 math)
+// one block per (b,t) group.
+template <typename T>
+__global__ void gem_fwd_kernel(mds_gem_fwd_args a) {
+  __shared__ float red[256 * 8];
+  const RowMap m = rowmap(a.C);
+  const int c0 = m.chunk * 8;
+  const float p = a.p[0];
+  float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
+  if (m.valid) {
+    float sc[8], sh[8];
+    if (a.pro.mode != MDS_PRO_NONE) { load8f(a.pro.scale + c0, sc); load8f(a.pro.shift + c0, sh); }
+    const T* y = (const T*)a.y + (long)blockIdx.x * a.rows_per_group * a.C;
+    for (long r = m.rsub; r < a.rows_per_group; r += m.rpb) {
+      float v[8];
+      load8(y + r * a.C + c0, v);
+      apply_pro8(a.pro.mode, v, sc, sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[0][j] += expf(p * logf(fmaxf(v[j], a.eps)));
+    }
+  }
+  block_reduce_rows<1>(acc, m, red);
+  if (m.valid && m.rsub == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float mean = acc[0][j] / (float)a.rows_per_group;
+      a.pooled[(long)blockIdx.x * a.C + c0 + j] = expf(logf(mean) / p);
+    }
+  }
+}
+extern "C" int mds_gem_fwd(const mds_gem_fwd_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "gem_fwd: bad dims");
+  MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_BN_SILU || a->pro.mode == MDS_PRO_AFFINE, "gem_fwd: prologue");
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(gem_fwd_kernel<T>, dim3(a->groups), dim3(256), 0, stream, *a));
+  return mds_check_launch("gem_fwd");
+}
+
+template <typename T>
+__global__ void gem_bwd_kernel(mds_gem_bwd_args a) {
+  __shared__ float red[256 * 8];
+  const RowMap m = rowmap(a.C);
+  const int c0 = m.chunk * 8;
+  const float p = a.p[0];
+  const float R = (float)a.rows_per_group;
+  float sc[8], sh[8];
+  const long gbase = (long)blockIdx.x * a.rows_per_group * a.C;
+  const T* y = (const T*)a.y + gbase;
+  T* u = (T*)a.u + gbase;
+  // pass 1: S = sum_rows c^p * log c
+  float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
+  if (m.valid) {
+    if (a.pro.mode != MDS_PRO_NONE) { load8f(a.pro.scale + c0, sc); load8f(a.pro.shift + c0, sh); }
+    for (long r = m.rsub; r < a.rows_per_group; r += m.rpb) {
+      float v[8];
+      load8(y + r * a.C + c0, v);
+      apply_pro8(a.pro.mode, v, sc, sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float lc = logf(fmaxf(v[j], a.eps));
+        acc[0][j] += expf(p * lc) * lc;
+      }
+    }
+  }
+  block_reduce_rows<1>(acc, m, red);
+  float dp_part = 0.f;
+  float coef[8];  // dpooled * out / (mean * R)
+  if (m.valid) {
+    if (m.rsub == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[c0 + j] = acc[0][j];
+    }
+  }
+  __syncthreads();
+  if (m.valid) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float out = a.pooled[(long)blockIdx.x * a.C + c0 + j];
+      float dpo = a.dpooled[(long)blockIdx.x * a.C + c0 + j];
+      float mean = expf(p * logf(out));  // out^p
+      coef[j] = dpo * out / (mean * R);
+      if (m.rsub == 0) {
+        float S = red[c0 + j] / R;  // mean(c^p log c)
+        dp_part += dpo * out * (-logf(mean) / (p * p) + S / (p * mean));
+      }
+    }
+    // pass 2: u = coef * c^(p-1) * [a >= eps]
+    for (long r = m.rsub; r < a.rows_per_group; r += m.rpb) {
+      float v[8];
+      load8(y + r * a.C + c0, v);
+      apply_pro8(a.pro.mode, v, sc, sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (v[j] >= a.eps) ? coef[j] * expf((p - 1.0f) * logf(v[j])) : 0.0f;
+      store8(u + r * a.C + c0, v);
+    }
+  }
+  // block-sum dp_part -> one atomic
+  __syncthreads();
+  red[threadIdx.x] = dp_part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 256; ++i) s += red[i];
+    atomicAdd(a.dp, s);
+  }
+}
+extern "C" int mds_gem_bwd(const mds_gem_bwd_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "gem_bwd: bad dims");
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(gem_bwd_kernel<T>, dim3(a->groups), dim3(256), 0, stream, *a));
+  return mds_check_launch("gem_bwd");
+}

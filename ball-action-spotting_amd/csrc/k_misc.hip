@@ -1,0 +1,258 @@
+// k_misc.hip — error plumbing and the latency-class kernels (tiny per-channel / per-group math).
+#include <stdarg.h>
+#include <stdio.h>
+#include "elem.h"
+
+static thread_local char g_err[512] = "";
+
+void mds_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int mds_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    mds_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return MDS_ERR_LAUNCH;
+  }
+  return 0;
+}
+extern "C" int mds_version(void) { return MDS_VERSION; }
+extern "C" const char* mds_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ parameter packing
+template <typename T>
+__global__ void pack_kernel(const mds_pack_job* jobs, int njobs) {
+  const mds_pack_job jb = jobs[blockIdx.y];
+  const int O = jb.O, I = jb.I, taps = jb.taps;
+  T* dst = (T*)jb.dst;
+  if (jb.kind == MDS_PACK_STEM) {
+    // src [O][27] -> dst [O][32]
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < O * 32; e += gridDim.x * blockDim.x) {
+      int o = e >> 5, k = e & 31;
+      Elem<T>::st(dst + e, k < 27 ? jb.src[o * 27 + k] : 0.0f);
+    }
+    return;
+  }
+  const int total = O * I * taps;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    // e indexes the destination
+    if (jb.kind == MDS_PACK_OI) {
+      int i = e % I, t = (e / I) % taps, o = e / (I * taps);
+      Elem<T>::st(dst + e, jb.src[(o * I + i) * taps + t]);
+    } else {  // MDS_PACK_IO_FLIP: dst [I][taps][O], tap flipped
+      int o = e % O, t = (e / O) % taps, i = e / (O * taps);
+      Elem<T>::st(dst + e, jb.src[(o * I + i) * taps + (taps - 1 - t)]);
+    }
+  }
+}
+extern "C" int mds_pack_weights(const mds_pack_job* jobs_dev, int njobs, int max_elems, int dtype,
+                                mds_stream_t stream) {
+  MDS_REQUIRE(jobs_dev && njobs > 0, "pack_weights: empty job table");
+  int bx = cdiv(max_elems, 256 * 4);
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
+  MDS_DISPATCH_DTYPE(dtype, T, MDS_LAUNCH(pack_kernel<T>, dim3(bx, njobs), dim3(256), 0, stream, jobs_dev, njobs));
+  return mds_check_launch("pack_weights");
+}
+
+// ------------------------------------------------------------------ BN finalize (fwd)
+__global__ void bn_finalize_kernel(mds_bn_finalize_args a) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && a.training && a.num_batches_tracked) *a.num_batches_tracked += 1;
+  if (c >= a.C) return;
+  float mean, var;
+  if (a.training) {
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < MDS_STAT_SLOTS; ++k) {
+      s += a.stats[(k * 2 + 0) * a.C + c];
+      ss += a.stats[(k * 2 + 1) * a.C + c];
+    }
+    double m = s / (double)a.count;
+    double v = ss / (double)a.count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (a.running_mean) {
+      float unb = a.count > 1 ? (float)(v * (double)a.count / (double)(a.count - 1)) : var;
+      a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+      a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * unb;
+    }
+  } else {
+    mean = a.running_mean[c];
+    var = a.running_var[c];
+  }
+  float rstd = 1.0f / sqrtf(var + a.eps);
+  float sc = a.gamma[c] * rstd;
+  a.out[0 * a.C + c] = sc;
+  a.out[1 * a.C + c] = a.beta[c] - mean * sc;
+  a.out[2 * a.C + c] = mean;
+  a.out[3 * a.C + c] = rstd;
+}
+extern "C" int mds_bn_finalize(const mds_bn_finalize_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->C > 0 && a->out && a->gamma && a->beta, "bn_finalize: bad args");
+  MDS_REQUIRE(a->training ? (a->stats != 0 && a->count > 0) : (a->running_mean && a->running_var),
+              "bn_finalize: missing stats / running buffers");
+  MDS_LAUNCH(bn_finalize_kernel, dim3(cdiv(a->C, 128)), dim3(128), 0, stream, *a);
+  return mds_check_launch("bn_finalize");
+}
+
+// ------------------------------------------------------------------ BN finalize (bwd)
+__global__ void bn_bwd_finalize_kernel(mds_bn_bwd_finalize_args a) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int k = 0; k < MDS_STAT_SLOTS; ++k) {
+    sg += a.stats[(k * 2 + 0) * a.C + c];
+    sgx += a.stats[(k * 2 + 1) * a.C + c];
+  }
+  if (a.dgamma) a.dgamma[c] += (float)sgx;
+  if (a.dbeta) a.dbeta[c] += (float)sg;
+  a.coef[0 * a.C + c] = a.gamma[c] * a.bn[3 * a.C + c];
+  a.coef[1 * a.C + c] = (float)(sg / (double)a.count);
+  a.coef[2 * a.C + c] = (float)(sgx / (double)a.count);
+}
+extern "C" int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->C > 0 && a->stats && a->gamma && a->bn && a->coef && a->count > 0,
+              "bn_bwd_finalize: bad args");
+  MDS_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(a->C, 128)), dim3(128), 0, stream, *a);
+  return mds_check_launch("bn_bwd_finalize");
+}
+
+// ------------------------------------------------------------------ SE FCs
+#define SE_MAX_GR 4096  // groups * R held in LDS
+__global__ void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
+  __shared__ float hact[SE_MAX_GR];
+  const int G = a.groups, C = a.C, R = a.R;
+  for (int e = threadIdx.x; e < G * R; e += blockDim.x) {
+    int g = e / R, r = e % R;
+    float s = a.b1[r];
+    const float* w = a.w1 + (long)r * C;
+    const float* p = a.pooled + (long)g * C;
+    for (int c = 0; c < C; ++c) s += w[c] * p[c];
+    if (blockIdx.x == 0) a.hidden[e] = s;
+    hact[e] = siluf_(s);
+  }
+  __syncthreads();
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    const float* w = a.w2 + (long)c * R;
+    for (int g = 0; g < G; ++g) {
+      float s = a.b2[c];
+      for (int r = 0; r < R; ++r) s += w[r] * hact[g * R + r];
+      a.gate[(long)g * C + c] = sigmoidf_(s);
+    }
+  }
+}
+extern "C" int mds_se_fc_fwd(const mds_se_fc_fwd_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->R > 0, "se_fc_fwd: bad dims");
+  MDS_REQUIRE(a->groups * a->R <= SE_MAX_GR, "se_fc_fwd: groups*R=%d exceeds %d", a->groups * a->R, SE_MAX_GR);
+  MDS_LAUNCH(se_fc_fwd_kernel, dim3(cdiv(a->C, 256)), dim3(256), 0, stream, *a);
+  return mds_check_launch("se_fc_fwd");
+}
+
+__global__ void se_fc_bwd_kernel(mds_se_fc_bwd_args a) {
+  __shared__ float dhpre[SE_MAX_GR];
+  __shared__ float hact[SE_MAX_GR];
+  const int G = a.groups, C = a.C, R = a.R;
+  // phase 1: dhpre[g][r] = silu'(hidden) * sum_c de[g][c] * w2[c][r],  de = dgate*gate*(1-gate)
+  for (int e = threadIdx.x; e < G * R; e += blockDim.x) {
+    int g = e / R, r = e % R;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float gt = a.gate[(long)g * C + c];
+      s += a.dgate[(long)g * C + c] * gt * (1.0f - gt) * a.w2[(long)c * R + r];
+    }
+    float h = a.hidden[e];
+    dhpre[e] = s * silu_gradf_(h);
+    hact[e] = siluf_(h);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+      float s = 0.f;
+      for (int g = 0; g < G; ++g) s += dhpre[g * R + r];
+      a.db1[r] += s;
+    }
+  }
+  const float invR = 1.0f / (float)a.rows_per_group;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    float db2 = 0.f;
+    for (int g = 0; g < G; ++g) {
+      float gt = a.gate[(long)g * C + c];
+      float de = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
+      db2 += de;
+      float dp = 0.f;
+      for (int r = 0; r < R; ++r) dp += dhpre[g * R + r] * a.w1[(long)r * C + c];
+      a.dpooled[(long)g * C + c] = dp * invR;
+    }
+    a.db2[c] += db2;
+    for (int r = 0; r < R; ++r) {
+      float s2 = 0.f, s1 = 0.f;
+      for (int g = 0; g < G; ++g) {
+        float gt = a.gate[(long)g * C + c];
+        float de = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
+        s2 += de * hact[g * R + r];
+        s1 += dhpre[g * R + r] * a.pooled[(long)g * C + c];
+      }
+      a.dw2[(long)c * R + r] += s2;
+      a.dw1[(long)r * C + c] += s1;
+    }
+  }
+}
+extern "C" int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->R > 0 && a->rows_per_group > 0, "se_fc_bwd: bad dims");
+  MDS_REQUIRE(a->groups * a->R <= SE_MAX_GR, "se_fc_bwd: groups*R too large");
+  MDS_LAUNCH(se_fc_bwd_kernel, dim3(cdiv(a->C, 256)), dim3(256), 0, stream, *a);
+  return mds_check_launch("se_fc_bwd");
+}
+
+// ------------------------------------------------------------------ head (dropout mask + Linear)
+__global__ void head_fwd_kernel(mds_head_fwd_args a) {
+  int b = blockIdx.x / a.NC, k = blockIdx.x % a.NC;
+  float s = 0.f;
+  for (int f = threadIdx.x; f < a.F; f += MDS_WAVE) {
+    float v = a.pooled[(long)b * a.F + f];
+    if (a.mask) v *= a.mask[(long)b * a.F + f];
+    s += v * a.w[(long)k * a.F + f];
+  }
+  s = wave_sum(s);
+  if (threadIdx.x == 0) a.logits[b * a.NC + k] = s + a.b[k];
+}
+extern "C" int mds_head_fwd(const mds_head_fwd_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->B > 0 && a->F > 0 && a->NC > 0, "head_fwd: bad dims");
+  MDS_LAUNCH(head_fwd_kernel, dim3(a->B * a->NC), dim3(MDS_WAVE), 0, stream, *a);
+  return mds_check_launch("head_fwd");
+}
+
+__global__ void head_bwd_kernel(mds_head_bwd_args a) {
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < a.F; f += gridDim.x * blockDim.x) {
+    for (int b = 0; b < a.B; ++b) {
+      float s = 0.f;
+      for (int k = 0; k < a.NC; ++k) s += a.dlogits[b * a.NC + k] * a.w[(long)k * a.F + f];
+      float mk = a.mask ? a.mask[(long)b * a.F + f] : 1.0f;
+      a.dpooled[(long)b * a.F + f] = s * mk;
+    }
+    for (int k = 0; k < a.NC; ++k) {
+      float s = 0.f;
+      for (int b = 0; b < a.B; ++b) {
+        float mk = a.mask ? a.mask[(long)b * a.F + f] : 1.0f;
+        s += a.dlogits[b * a.NC + k] * a.pooled[(long)b * a.F + f] * mk;
+      }
+      a.dw[(long)k * a.F + f] += s;
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < a.NC; k += blockDim.x) {
+      float s = 0.f;
+      for (int b = 0; b < a.B; ++b) s += a.dlogits[b * a.NC + k];
+      a.db[k] += s;
+    }
+  }
+}
+extern "C" int mds_head_bwd(const mds_head_bwd_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->B > 0 && a->F > 0 && a->NC > 0, "head_bwd: bad dims");
+  MDS_LAUNCH(head_bwd_kernel, dim3(cdiv(a->F, 256)), dim3(256), 0, stream, *a);
+  return mds_check_launch("head_bwd");
+}

@@ -1,0 +1,157 @@
+// platform.h — device-side vocabulary shared by every kernel file of libmds_hip.so.
+//
+// Target: gfx950 (MI355X, CDNA4), wave64, hipcc.  The only other build of these sources is the
+// host *simulator* used by the CPU test-suite (tests/hipemu/hipemu.h, -DMDS_EMU): it replaces
+// the three hardware touch-points below (HIP runtime header, MFMA builtins, kernel launch) and
+// nothing else.  It is test infrastructure, not a fallback: the product library is hipcc-only.
+#pragma once
+#include <stdint.h>
+
+#ifndef MDS_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+#include "../../include/mds.h"
+
+#define MDS_DEV __device__ __forceinline__
+#define MDS_WAVE 64
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ scalar helpers
+MDS_DEV float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+MDS_DEV uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+MDS_DEV float bf2f(bf16_t v) { return bits2f((uint32_t)v << 16); }
+MDS_DEV bf16_t f2bf(float f) {  // round-to-nearest-even
+  uint32_t u = f2bits(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+MDS_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+MDS_DEV float siluf_(float x) { return x * sigmoidf_(x); }
+// d silu(z)/dz
+MDS_DEV float silu_gradf_(float z) { float s = sigmoidf_(z); return s * (1.0f + z * (1.0f - s)); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static MDS_DEV float ld(const float* p) { return *p; }
+  static MDS_DEV void st(float* p, float v) { *p = v; }
+  static MDS_DEV float rnd(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static MDS_DEV float ld(const bf16_t* p) { return bf2f(*p); }
+  static MDS_DEV void st(bf16_t* p, float v) { *p = f2bf(v); }
+  static MDS_DEV float rnd(float v) { return bf2f(f2bf(v)); }
+};
+
+// 8 consecutive elements <-> 8 floats (16-byte / 32-byte vector memory ops)
+MDS_DEV void load8(const float* p, float (&v)[8]) {
+  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+MDS_DEV void load8(const bf16_t* p, float (&v)[8]) {
+  u16x8 a = *(const u16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = bf2f(a[i]);
+}
+MDS_DEV void store8(float* p, const float (&v)[8]) {
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
+}
+MDS_DEV void store8(bf16_t* p, const float (&v)[8]) {
+  u16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = f2bf(v[i]);
+  *(u16x8*)p = a;
+}
+MDS_DEV void load4(const float* p, float (&v)[4]) { f32x4 a = *(const f32x4*)p; v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
+MDS_DEV void load4(const bf16_t* p, float (&v)[4]) { u16x4 a = *(const u16x4*)p; for (int i = 0; i < 4; ++i) v[i] = bf2f(a[i]); }
+MDS_DEV void store4(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = a; }
+MDS_DEV void store4(bf16_t* p, const float (&v)[4]) { u16x4 a; for (int i = 0; i < 4; ++i) a[i] = f2bf(v[i]); *(u16x4*)p = a; }
+
+// ------------------------------------------------------------------ MFMA tile op
+// One wave computes C[16x16] += A[16x32] * B[32x16].  Lane l = (i = l & 15, q = l >> 4) holds
+//   A[i][8q .. 8q+7]  and  B[8q .. 8q+7][i]      (8 consecutive k per lane, both operands)
+// and C/D element r of lane l is C[row = 4q + r][col = i]     (guide §3 fragment layout).
+// bf16: one v_mfma_f32_16x16x32_bf16.   f32: eight v_mfma_f32_16x16x4_f32 (exact fp32; MFMA j
+// consumes element j of every lane — any k-permutation is legal as long as A and B agree).
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef u16x8 type; };
+template <> struct Frag<float> { typedef f32x8 type; };
+
+#ifndef MDS_EMU
+typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+MDS_DEV void mma16(const u16x8& a, const u16x8& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a),
+                                              __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+}
+#define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define MDS_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+#else  // ---- host simulator (tests only): same contracts, scalar arithmetic
+MDS_DEV void mma16_emu(const float (&a)[8], const float (&b)[8], f32x4& c, bool round_bf16) {
+  int lane = hipemu::lane_id();
+  float* mine = (float*)hipemu::wave_scratch(lane);
+  for (int j = 0; j < 8; ++j) { mine[j] = a[j]; mine[8 + j] = b[j]; }
+  hipemu::wave_barrier();
+  int i = lane & 15, q = lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * q + r, col = i;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k) {
+      float av = ((float*)hipemu::wave_scratch(row + 16 * (k >> 3)))[k & 7];
+      float bv = ((float*)hipemu::wave_scratch(col + 16 * (k >> 3)))[8 + (k & 7)];
+      acc += av * bv;
+    }
+    c[r] = acc;
+  }
+  (void)round_bf16;
+  hipemu::wave_barrier();
+}
+MDS_DEV void mma16(const u16x8& a, const u16x8& b, f32x4& c) {
+  float fa[8], fb[8];
+  for (int j = 0; j < 8; ++j) { fa[j] = bf2f(a[j]); fb[j] = bf2f(b[j]); }
+  mma16_emu(fa, fb, c, true);
+}
+MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
+  float fa[8], fb[8];
+  for (int j = 0; j < 8; ++j) { fa[j] = a[j]; fb[j] = b[j]; }
+  mma16_emu(fa, fb, c, false);
+}
+#define MDS_DYN_SMEM(name) char* name = hipemu::dyn_smem()
+#define MDS_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipemu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
+#endif
+
+MDS_DEV void frag_set(u16x8& f, int j, float v) { f[j] = f2bf(v); }
+MDS_DEV void frag_set(f32x8& f, int j, float v) { f[j] = v; }
+MDS_DEV void frag_zero(u16x8& f) { f = (u16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
+MDS_DEV void frag_zero(f32x8& f) { f = (f32x8){0, 0, 0, 0, 0, 0, 0, 0}; }
+
+// ------------------------------------------------------------------ wave / block reductions
+MDS_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+// sum over the 16 lanes that share q = lane >> 4 (i.e. over i = lane & 15)
+MDS_DEV float sum_over_i16(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
+
+// ------------------------------------------------------------------ error plumbing (C ABI)
+void mds_set_error(const char* fmt, ...);
+int mds_check_launch(const char* what);
+#define MDS_REQUIRE(cond, ...) \
+  do { if (!(cond)) { mds_set_error(__VA_ARGS__); return MDS_ERR_BAD_ARG; } } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

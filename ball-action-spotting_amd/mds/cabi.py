@@ -1,0 +1,164 @@
+"""ctypes binding of include/mds.h (the C ABI of libmds_hip.so).
+
+The struct layouts are parsed from the header itself, so the Python side cannot drift from the
+C side.  ``load()`` is the product loader: it only ever opens the hipcc-built gfx950 library and
+raises if it is missing — there is no CPU fallback.  (The CPU kernel-logic simulator used by the
+test-suite is opened by ``tests/hipemu/loader.py`` through :class:`Lib` with an explicit path.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Dict
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(HERE)
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+HEADER = os.path.join(REPO_ROOT, "include", "mds.h")
+HIP_LIB = os.path.join(PKG_ROOT, "csrc", "libmds_hip.so")
+
+_SCALARS = {
+    "int": C.c_int, "long": C.c_long, "float": C.c_float, "long long": C.c_longlong,
+}
+
+
+def _parse_header(path: str):
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    defines = {k: int(v) for k, v in re.findall(r"#define\s+(MDS_\w+)\s+\(?(-?\d+)\)?\s*$", text, flags=re.M)}
+    structs: Dict[str, type] = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            if decl.startswith("const "):
+                decl = decl[6:]
+            known = sorted(list(_SCALARS) + ["void"] + list(structs), key=len, reverse=True)
+            base = next((t for t in known if decl.startswith(t + " ") or decl.startswith(t + "*")), None)
+            assert base, f"cannot parse field '{decl}' of {name}"
+            names = decl[len(base):].strip()
+            ptr = ""
+            for nm in names.split(","):
+                nm = nm.strip()
+                is_ptr = bool(ptr) or nm.startswith("*")
+                nm = nm.lstrip("* ")
+                arr = re.match(r"(\w+)\[(\w+)\]", nm)
+                if is_ptr:
+                    ctype = C.c_void_p
+                elif base in _SCALARS:
+                    ctype = _SCALARS[base]
+                elif base in structs:
+                    ctype = structs[base]
+                else:
+                    raise AssertionError(f"unknown type '{base}' in {name}")
+                if arr:
+                    nm = arr.group(1)
+                    n = arr.group(2)
+                    ctype = ctype * (int(n) if n.isdigit() else defines[n])
+                fields.append((nm, ctype))
+        structs[name] = type(name, (C.Structure,), {"_fields_": fields})
+    funcs = re.findall(r"^\s*int\s+(mds_\w+)\s*\(([^)]*)\)\s*;", text, flags=re.M)
+    return defines, structs, funcs
+
+
+DEFINES, STRUCTS, FUNCS = _parse_header(HEADER)
+globals().update(DEFINES)
+
+
+class MdsError(RuntimeError):
+    pass
+
+
+class Lib:
+    """A loaded libmds shared object with typed entry points."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise MdsError(
+                f"{path} not found: the MultiDimStacker HIP kernels are not built. "
+                f"Run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950).")
+        self.path = path
+        self.dll = C.CDLL(path)
+        self.dll.mds_last_error.restype = C.c_char_p
+        self.dll.mds_version.restype = C.c_int
+        if self.dll.mds_version() != DEFINES["MDS_VERSION"]:
+            raise MdsError(f"{path}: ABI version {self.dll.mds_version()} != header {DEFINES['MDS_VERSION']}")
+        self.fn = {}
+        self.missing = []
+        for name, params in FUNCS:
+            if name == "mds_version":
+                continue
+            try:
+                f = getattr(self.dll, name)
+            except AttributeError:
+                self.missing.append(name)   # tests assert this list is empty
+                continue
+            f.restype = C.c_int
+            self.fn[name[4:]] = f
+        for op in list(self.fn):
+            st = STRUCTS.get(f"mds_{op}_args")
+            if st is not None:
+                self.fn[op].argtypes = [C.POINTER(st), C.c_void_p]
+        if "pack_weights" in self.fn:
+            self.fn["pack_weights"].argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+
+    def check(self, rc: int, op: str):
+        if rc != 0:
+            raise MdsError(f"mds_{op} failed ({rc}): {self.dll.mds_last_error().decode()}")
+
+    def call(self, op: str, args, stream: int = 0):
+        if op not in self.fn:
+            raise MdsError(f"mds_{op} is not exported by {self.path}")
+        self.check(self.fn[op](C.byref(args), stream), op)
+
+
+_LIB = None
+
+
+def load() -> Lib:
+    """Product loader: the gfx950 HIP library or an error — never anything else."""
+    global _LIB
+    if _LIB is None:
+        _LIB = Lib(HIP_LIB)
+    return _LIB
+
+
+def ptr(t):
+    """Device (or host, under the test simulator) address of a torch tensor, 0 for None."""
+    if t is None:
+        return 0
+    assert t.is_contiguous(), "mds kernels take contiguous buffers"
+    return t.data_ptr()
+
+
+def make(struct_name: str, **kw):
+    """Build an mds_*_args struct; torch tensors are converted to raw pointers."""
+    st = STRUCTS[struct_name]()
+    keep = []
+    for k, v in kw.items():
+        ftype = dict(st._fields_)[k]
+        if hasattr(v, "data_ptr"):
+            keep.append(v)
+            v = ptr(v)
+        if isinstance(v, C.Structure):
+            setattr(st, k, v)
+        elif isinstance(v, (list, tuple)):
+            arr = getattr(st, k)
+            for i, e in enumerate(v):
+                arr[i] = e
+        else:
+            setattr(st, k, v if v is not None else (0 if ftype is not C.c_void_p else None))
+    st._keep = keep
+    return st
+
+
+def pro(mode=0, scale=None, shift=None, gate=None, rows_per_group=0):
+    return make("mds_pro_t", mode=mode, scale=scale, shift=shift, gate=gate, rows_per_group=rows_per_group)
+
+
+def gsrc(mode=0, u=None, gate=None, dpooled=None, mask=None, rows_per_group=0):
+    return make("mds_gsrc_t", mode=mode, u=u, gate=gate, dpooled=dpooled, mask=mask,
+                rows_per_group=rows_per_group)

@@ -1,0 +1,411 @@
+/* mds.h — C ABI of libmds_hip.so: the MI355X (gfx950) kernels behind the drop-in
+ * MultiDimStacker module (reference: /root/reference/src/models/multidim_stacker.py).
+ *
+ * The reference has no FFI of its own: its hot path is a Python nn.Module that dispatches to
+ * ATen/cuDNN.  Each entry point below replaces the ATen call(s) issued by the cited reference
+ * line(s); the Python host (ball-action-spotting_amd/mds) binds them with ctypes exactly as
+ * INTEGRATION.md shows.
+ *
+ * Conventions
+ *  - Plain C: pointers + sizes only.  Every buffer is caller-owned device memory (PyTorch
+ *    allocations); the library never allocates, frees or retains pointers.
+ *  - Every call is asynchronous on the caller's HIP stream (`stream` = hipStream_t as void*),
+ *    never synchronises, has no global mutable state except a thread-local error string.
+ *  - Return 0 on success, negative MDS_ERR_* otherwise; mds_last_error() describes it.
+ *  - Activations are channels-last "rows": a tensor [rows][C] with C contiguous, rows =
+ *    N*H*W (2D) or B*T*H*W (3D).  dtype selects the storage type of activations and packed
+ *    weights (MDS_F32 / MDS_BF16); statistics, gates, parameters' grads are always fp32.
+ *  - "stats" buffers are fp32 [MDS_STAT_SLOTS][2][C], zeroed by the caller before the producing
+ *    launch: slot s, row 0 = partial sum, row 1 = partial sum of squares (or of g*xhat).
+ */
+#ifndef MDS_H
+#define MDS_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDS_VERSION 100
+#define MDS_F32 0
+#define MDS_BF16 1
+#define MDS_STAT_SLOTS 32
+
+#define MDS_ERR_BAD_ARG (-1)
+#define MDS_ERR_UNSUPPORTED (-2)
+#define MDS_ERR_LAUNCH (-3)
+
+typedef void* mds_stream_t;
+
+int mds_version(void);
+const char* mds_last_error(void);
+
+/* ---- operand transforms ("prologues"): how a consumer reads a producer's raw conv output.
+ * Train-mode BatchNorm needs batch statistics before it can normalise, so producers store the
+ * raw convolution output y (+ its per-channel sums) and every consumer applies
+ *   a = act(y*scale[c] + shift[c]) [* gate[row/rows_per_group][c]]   while loading.          */
+#define MDS_PRO_NONE 0
+#define MDS_PRO_AFFINE 1       /* BN, no activation                                            */
+#define MDS_PRO_BN_SILU 2      /* BN + SiLU   (timm BatchNormAct2d / BatchNormAct3d :53-69)     */
+#define MDS_PRO_BN_SILU_GATE 3 /* BN + SiLU, then squeeze-excite gate (:72-90, timm SE)         */
+typedef struct {
+  int mode;
+  const float* scale; /* [C] gamma*rstd                      */
+  const float* shift; /* [C] beta - mean*gamma*rstd          */
+  const float* gate;  /* [groups][C] sigmoid gate (mode 3)   */
+  long rows_per_group;
+} mds_pro_t;
+
+/* ---- K4: 1x1 convolution = GEMM  y[M][N] = pro(x)[M][K] * w[N][K]^T  (+ residual)
+ * replaces nn.Conv2d/Conv3d k=1 at multidim_stacker.py:106,120,179-183,199-203 and timm
+ * conv_pw/conv_pwl; also used as its own data-gradient (w = transposed pack).                  */
+typedef struct {
+  int dtype;
+  long M;
+  int K, N;
+  const void* x;        /* [M][K]            */
+  const void* w;        /* [N][K] packed     */
+  void* y;              /* [M][N]            */
+  mds_pro_t pro;
+  const void* residual; /* optional [M][N], added after the product                            */
+  float* stats;         /* optional [SLOTS][2][N]                                               */
+} mds_pw_fwd_args;
+int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream);
+
+/* weight gradient of the 1x1 convolution: dw[N][K] += sum_m dy[m][n] * pro(x)[m][k] (fp32,
+ * atomically accumulated into a caller-zeroed buffer laid out like the PyTorch parameter).     */
+typedef struct {
+  int dtype;
+  long M;
+  int K, N;
+  const void* x;  /* [M][K] forward input (raw, pro re-applied) */
+  const void* dy; /* [M][N]                                      */
+  float* dw;      /* [N][K] fp32                                 */
+  mds_pro_t pro;
+} mds_pw_wgrad_args;
+int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream);
+
+/* ---- K2/K3: dense 3x3 convolution as an MFMA implicit GEMM over a tap list.
+ * For output sub-grid point (a,b), a<A, b<B of image n:
+ *   y[n][oy0 + a*os][ox0 + b*os][:] = sum_t pro(x)[n][a*is + dy[t]][b*is + dx[t]][:] * w[:][wi[t]][:]
+ * (out-of-image input pixels contribute 0 AFTER the prologue = zero padding of the activation).
+ * Covers: stride-1 'same' conv (is=1), TF-SAME stride-2 conv (is=2, timm Conv2dSame), the
+ * stride-1 data gradient (flipped taps) and the stride-2 data gradient (os=2, one launch per
+ * output parity class).  replaces timm ConvBnAct.conv / EdgeResidual.conv_exp and their dgrads. */
+#define MDS_MAX_TAPS 9
+typedef struct {
+  int dtype;
+  int N, IH, IW, Cin;   /* input  [N][IH][IW][Cin]                      */
+  int OH, OW, Cout;     /* output [N][OH][OW][Cout] (full tensor dims)  */
+  int A, B;             /* sub-grid extent handled by this launch       */
+  int oy0, ox0, os;     /* output position = (oy0 + a*os, ox0 + b*os)   */
+  int is;               /* input stride                                  */
+  int ntaps;
+  int dy[MDS_MAX_TAPS], dx[MDS_MAX_TAPS], wi[MDS_MAX_TAPS];
+  int wtaps;            /* taps in the packed weight: w[Cout][wtaps][Cin] */
+  const void* x;
+  const void* w;
+  void* y;
+  mds_pro_t pro;        /* modes NONE / AFFINE / BN_SILU                 */
+  const void* residual; /* optional, same indexing as y                  */
+  float* stats;         /* optional [SLOTS][2][Cout]                     */
+} mds_conv_fwd_args;
+int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream);
+
+/* weight gradient of the 3x3 convolution (forward geometry: is = stride, os = 1):
+ * dw[co][ci][tap] += sum_{n,a,b} dy[n][a][b][co] * pro(x)[n][a*is+dy[t]][b*is+dx[t]][ci]
+ * written in PyTorch OIHW order (dw[(co*Cin+ci)*wtaps + wi[t]]).                                */
+typedef struct {
+  int dtype;
+  int N, IH, IW, Cin, OH, OW, Cout;
+  int is, ntaps;
+  int dy[MDS_MAX_TAPS], dx[MDS_MAX_TAPS], wi[MDS_MAX_TAPS];
+  int wtaps;
+  const void* x;
+  const void* dyt; /* [N][OH][OW][Cout] */
+  float* dw;
+  mds_pro_t pro;
+} mds_conv_wgrad_args;
+int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream);
+
+/* ---- stem: 3x3 stride-2 TF-SAME convolution of the fp32 frame triple (Cin = stack_size = 3
+ * planes, NCHW as produced by x.view(b*S, 3, h, w), multidim_stacker.py:214) -> channels-last.  */
+typedef struct {
+  int dtype;
+  int N, H, W, OH, OW, Cout; /* Cout <= 32 */
+  int pad_t, pad_l;
+  const float* x; /* [N][3][H][W] fp32   */
+  const void* w;  /* [Cout][32] packed: k = plane*9 + ky*3 + kx, zero padded to 32 */
+  void* y;        /* [N][OH][OW][Cout]   */
+  float* stats;
+} mds_stem_fwd_args;
+int mds_stem_fwd(const mds_stem_fwd_args* a, mds_stream_t stream);
+
+typedef struct {
+  int dtype;
+  int N, H, W, OH, OW, Cout;
+  int pad_t, pad_l;
+  const float* x;
+  const void* dy; /* [N][OH][OW][Cout] */
+  float* dw;      /* [Cout][3][3][3] fp32 (OIHW) */
+} mds_stem_wgrad_args;
+int mds_stem_wgrad(const mds_stem_wgrad_args* a, mds_stream_t stream);
+
+/* ---- K5/K6: depthwise 3x3 (2D, stride 1 or TF-SAME stride 2) and 3x3x3 (3D, pad 1).
+ * Input is the raw output of the preceding 1x1 conv read through a BN+SiLU prologue.
+ * replaces timm InvertedResidual.conv_dw and multidim_stacker.py:110-113.
+ * 2D is the T == 1 case with kt restricted to the centre tap.                                   */
+typedef struct {
+  int dtype;
+  int N, T, IH, IW, C; /* input [N][T][IH][IW][C] */
+  int OH, OW;          /* output [N][T][OH][OW][C] */
+  int stride, pad_t, pad_l;
+  int kt;              /* 1 (2D) or 3 (3D, temporal pad 1) */
+  const void* x;
+  const float* w;      /* fp32 [C][kt*9] (PyTorch layout [C][1][kt][3][3]) */
+  void* y;
+  mds_pro_t pro;
+  float* stats;
+} mds_dw_fwd_args;
+int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream);
+
+/* depthwise backward: given dy (grad of the raw dw output), produce
+ *   g[n][..][c]  = (sum_taps dy * w) * silu'(z)      z = x*scale+shift   (grad wrt BN output of
+ *                  the producing 1x1 conv, ready for its BN backward) + its stats (sum g, sum g*xhat)
+ *   dw[c][tap]  += sum dy * silu(z)(shifted)                                                  */
+typedef struct {
+  int dtype;
+  int N, T, IH, IW, C, OH, OW;
+  int stride, pad_t, pad_l, kt;
+  const void* x;      /* raw forward input (pre-BN)  */
+  const void* dy;     /* [N][T][OH][OW][C]           */
+  const float* w;
+  void* g;            /* [N][T][IH][IW][C]           */
+  float* dw;          /* fp32 [C][kt*9]              */
+  mds_pro_t pro;      /* BN_SILU of the forward      */
+  const float* mean;  /* [C] of x's BN (for xhat)    */
+  const float* rstd;
+  float* stats;       /* [SLOTS][2][C]: sum g, sum g*xhat */
+} mds_dw_bwd_args;
+int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream);
+
+/* ---- K7: BatchNorm statistics -> per-channel affine (+ running-stat update, momentum, unbiased
+ * running variance, num_batches_tracked += 1): torch.nn.functional.batch_norm semantics used by
+ * timm BatchNormAct2d and BatchNormAct3d (:53-69).  out = fp32 [4][C]: scale, shift, mean, rstd. */
+typedef struct {
+  int C;
+  long count;          /* elements per channel */
+  const float* stats;  /* [SLOTS][2][C]; ignored when training == 0 */
+  const float* gamma;
+  const float* beta;
+  float eps, momentum;
+  int training;
+  float* running_mean; /* updated in place when training */
+  float* running_var;
+  long long* num_batches_tracked;
+  float* out;          /* [4][C] */
+} mds_bn_finalize_args;
+int mds_bn_finalize(const mds_bn_finalize_args* a, mds_stream_t stream);
+
+/* y_out = act(bn(y)) * mask[row / rows_per_group] + shortcut     (block output materialisation:
+ * BN3 + DropPath + residual, multidim_stacker.py:121-133 / timm blocks; or BN+SiLU of a projection) */
+typedef struct {
+  int dtype;
+  long M;
+  int C;
+  const void* y;
+  const float* scale;
+  const float* shift;
+  int act;                /* 0 none, 1 SiLU */
+  const float* mask;      /* optional [groups] DropPath scale (0 or 1/keep) */
+  long rows_per_group;
+  const void* shortcut;   /* optional [M][C] */
+  void* out;
+} mds_bn_res_args;
+int mds_bn_res(const mds_bn_res_args* a, mds_stream_t stream);
+
+/* ---- K8: squeeze-excite.  pool: pooled[g][c] = mean_rows silu(bn(y))   (:82 x.mean((2,3,4))) */
+typedef struct {
+  int dtype;
+  int groups;
+  long rows_per_group;
+  int C;
+  const void* y;
+  const float* scale;
+  const float* shift;
+  float* pooled;  /* [groups][C], caller-zeroed (atomic accumulation of sums/rows) */
+} mds_se_pool_args;
+int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream);
+
+/* gate = sigmoid(W2 * silu(W1 * pooled + b1) + b2)   (:83-86).  hidden pre-activations are kept. */
+typedef struct {
+  int groups, C, R;
+  const float* pooled;  /* [groups][C] */
+  const float* w1;      /* [R][C] */
+  const float* b1;      /* [R]    */
+  const float* w2;      /* [C][R] */
+  const float* b2;      /* [C]    */
+  float* hidden;        /* [groups][R] pre-activation */
+  float* gate;          /* [groups][C] */
+} mds_se_fc_fwd_args;
+int mds_se_fc_fwd(const mds_se_fc_fwd_args* a, mds_stream_t stream);
+
+/* dgate_raw[g][c] = sum_rows u[row][c] * silu(bn(y))[row][c]   (u = grad wrt the gated tensor) */
+typedef struct {
+  int dtype;
+  int groups;
+  long rows_per_group;
+  int C;
+  const void* u;
+  const void* y;
+  const float* scale;
+  const float* shift;
+  float* dgate; /* [groups][C] caller-zeroed */
+} mds_se_bwd_reduce_args;
+int mds_se_bwd_reduce(const mds_se_bwd_reduce_args* a, mds_stream_t stream);
+
+/* backward of the two SE FCs: in dgate_raw, gate, hidden, pooled; out dpooled[g][c] (grad wrt the
+ * pooled mean, already divided by rows_per_group) and parameter grads (+=).                    */
+typedef struct {
+  int groups, C, R;
+  long rows_per_group;
+  const float* dgate;
+  const float* gate;
+  const float* hidden;
+  const float* pooled;
+  const float* w1;
+  const float* w2;
+  float* dpooled; /* [groups][C] */
+  float* dw1;     /* [R][C] */
+  float* db1;
+  float* dw2;     /* [C][R] */
+  float* db2;
+} mds_se_fc_bwd_args;
+int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream);
+
+/* ---- BatchNorm backward, split in reduce / finalize / apply.  g (grad wrt the BN output z) is
+ * derived on the fly from an upstream tensor u:
+ *   MDS_G_PLAIN      g = u
+ *   MDS_G_SILU       g = u * silu'(z)
+ *   MDS_G_SE_SILU    g = (u * gate[grp][c] + dpooled[grp][c]) * silu'(z)
+ *   MDS_G_MASK       g = u * mask[grp]                                   (DropPath)           */
+#define MDS_G_PLAIN 0
+#define MDS_G_SILU 1
+#define MDS_G_SE_SILU 2
+#define MDS_G_MASK 3
+typedef struct {
+  int mode;
+  const void* u;        /* [M][C] */
+  const float* gate;    /* [groups][C] */
+  const float* dpooled; /* [groups][C] */
+  const float* mask;    /* [groups]    */
+  long rows_per_group;
+} mds_gsrc_t;
+
+typedef struct {
+  int dtype;
+  long M;
+  int C;
+  mds_gsrc_t g;
+  const void* y;        /* raw conv output (pre-BN) */
+  const float* bn;      /* [4][C] scale, shift, mean, rstd */
+  float* stats;         /* [SLOTS][2][C]: sum g, sum g*xhat */
+} mds_bn_bwd_reduce_args;
+int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t stream);
+
+/* sums -> dgamma, dbeta (+=) and coef[3][C] = { gamma*rstd, sum_g/M, sum_gx/M } */
+typedef struct {
+  int C;
+  long count;
+  const float* stats;
+  const float* gamma;
+  const float* bn;  /* [4][C] */
+  float* dgamma;    /* optional (NULL when the parameter is frozen) */
+  float* dbeta;
+  float* coef;      /* [3][C] */
+} mds_bn_bwd_finalize_args;
+int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream_t stream);
+
+/* dy = coef0 * (g - coef1 - xhat*coef2)  -> grad of the raw conv output */
+typedef struct {
+  int dtype;
+  long M;
+  int C;
+  mds_gsrc_t g;
+  const void* y;
+  const float* bn;
+  const float* coef;
+  void* dy;
+} mds_bn_bwd_apply_args;
+int mds_bn_bwd_apply(const mds_bn_bwd_apply_args* a, mds_stream_t stream);
+
+/* ---- K11: GeM pooling over (H,W) of silu(bn(y)) for every (b, t, c):  multidim_stacker.py:35-45
+ * pooled[b][t*C + c] = (mean_hw clamp(a, eps)^p)^(1/p);  fp32 math.                              */
+typedef struct {
+  int dtype;
+  int groups;           /* b*t */
+  long rows_per_group;  /* h*w */
+  int C;
+  const void* y;
+  mds_pro_t pro;        /* NONE or BN_SILU */
+  const float* p;       /* [1] learnable exponent */
+  float eps;
+  float* pooled;        /* [groups][C] == [b][t*C + c] */
+} mds_gem_fwd_args;
+int mds_gem_fwd(const mds_gem_fwd_args* a, mds_stream_t stream);
+
+/* GeM backward: u[row][c] = grad wrt a = silu(bn(y)) (or wrt y when pro == NONE), dp += ...     */
+typedef struct {
+  int dtype;
+  int groups;
+  long rows_per_group;
+  int C;
+  const void* y;
+  mds_pro_t pro;
+  const float* p;
+  float eps;
+  const float* pooled;
+  const float* dpooled; /* [groups][C] */
+  void* u;              /* [rows][C] */
+  float* dp;            /* [1] += */
+} mds_gem_bwd_args;
+int mds_gem_bwd(const mds_gem_bwd_args* a, mds_stream_t stream);
+
+/* ---- K12: dropout (host-supplied scaled mask) + Linear  (multidim_stacker.py:232-237)        */
+typedef struct {
+  int B, F, NC;
+  const float* pooled; /* [B][F] */
+  const float* mask;   /* optional [B][F] (0 or 1/(1-p)) */
+  const float* w;      /* [NC][F] */
+  const float* b;      /* [NC]    */
+  float* logits;       /* [B][NC] */
+} mds_head_fwd_args;
+int mds_head_fwd(const mds_head_fwd_args* a, mds_stream_t stream);
+
+typedef struct {
+  int B, F, NC;
+  const float* pooled;
+  const float* mask;
+  const float* w;
+  const float* dlogits; /* [B][NC] */
+  float* dpooled;       /* [B][F]  */
+  float* dw;            /* [NC][F] += */
+  float* db;            /* [NC]    += */
+} mds_head_bwd_args;
+int mds_head_bwd(const mds_head_bwd_args* a, mds_stream_t stream);
+
+/* ---- parameter packing: fp32 PyTorch parameters -> the layouts/dtypes the kernels read.
+ * One launch handles a device-resident table of jobs.                                          */
+#define MDS_PACK_OI 0      /* [O][I][taps] -> [O][taps][I]   (1x1: taps = 1; conv fwd)         */
+#define MDS_PACK_IO_FLIP 1 /* [O][I][taps] -> [I][taps-1-t][O] (data-gradient pack)            */
+#define MDS_PACK_STEM 2    /* [O][3][3][3] -> [O][32] zero padded                              */
+typedef struct {
+  const float* src;
+  void* dst;
+  int kind, O, I, taps;
+} mds_pack_job;
+int mds_pack_weights(const mds_pack_job* jobs_dev, int njobs, int max_elems, int dtype,
+                     mds_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
