@@ -1,1 +1,349 @@
-#include "elem.h"
+// k_conv.hip — dense 3x3 convolutions (EfficientNetV2 stages 0-2) as MFMA implicit GEMMs.
+//
+// One kernel, parameterised by a tap list, serves the stride-1 'same' conv, the TF-SAME stride-2
+// conv, and both data gradients (see mds_conv_fwd_args).  A block owns an 8x16 patch of output
+// sub-grid points; the matching input patch (with halo) is staged in LDS once per 32-channel
+// chunk — with the producer's BN+SiLU applied on the way in and zero padding applied after it —
+// and re-read from LDS by all taps, so HBM sees each input pixel once per block.
+// Arithmetic intensity 100-600 FLOP/B: MFMA-bound layers.
+#include "gemm.h"
+
+#define CV_TA 8
+#define CV_TB 16
+#define CV_BNT 128
+
+template <typename T, int PRO>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW) {
+  typedef typename Frag<T>::type frag_t;
+  const int LD = PwLd<T>::v;
+  MDS_DYN_SMEM(smem);
+  T* xs = (T*)smem;                          // [TH*TW][LD]
+  T* ws = xs + TH * TW * LD;                 // [CV_BNT][LD]
+  float* st_s = (float*)(ws + CV_BNT * LD);  // [CV_BNT]
+  float* st_ss = st_s + CV_BNT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * CV_TB, a0 = blockIdx.y * CV_TA, img = blockIdx.z;
+  const int Cin = a.Cin, Cout = a.Cout;
+  const T* x = (const T*)a.x + (long)img * a.IH * a.IW * Cin;
+  const T* w = (const T*)a.w;
+  T* y = (T*)a.y;
+  const int schunk = tid & 3;
+  const int npix = TH * TW;
+
+  for (int n0 = 0; n0 < Cout; n0 += CV_BNT) {
+    const int nfr = (Cout - n0 >= CV_BNT) ? 8 : ((Cout - n0) >> 4);
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 8; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.stats && tid < CV_BNT) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
+
+    for (int kc = 0; kc < Cin; kc += PW_KC) {
+      const int kk = kc + 8 * schunk;
+      float sc[8], sh[8];
+      if (PRO != MDS_PRO_NONE && kk < Cin) { load8f(a.pro.scale + kk, sc); load8f(a.pro.shift + kk, sh); }
+      __syncthreads();
+      for (int it = tid; it < npix * 4; it += 256) {
+        const int pix = it >> 2;
+        const int ty = pix / TW, tx = pix - ty * TW;
+        const int iy = a0 * a.is + dymin + ty, ix = b0 * a.is + dxmin + tx;
+        float v[8];
+        if (kk < Cin && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
+          load8(x + ((long)iy * a.IW + ix) * Cin + kk, v);
+          if (PRO != MDS_PRO_NONE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float z = v[j] * sc[j] + sh[j];
+              v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+        store8(xs + pix * LD + 8 * schunk, v);
+      }
+      for (int t = 0; t < a.ntaps; ++t) {
+        if (t > 0) __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int r = (tid >> 2) + 64 * p;
+          const int n = n0 + r;
+          float v[8];
+          if (n < Cout && kk < Cin) {
+            load8(w + ((long)n * a.wtaps + a.wi[t]) * Cin + kk, v);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          }
+          store8(ws + r * LD + 8 * schunk, v);
+        }
+        __syncthreads();
+        frag_t xf[2];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+          const int al = 2 * wave + mf;
+          const int pix = (al * a.is + a.dy[t] - dymin) * TW + (i * a.is + a.dx[t] - dxmin);
+          xf[mf] = ld_frag(xs + pix * LD + 8 * q);
+        }
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf) {
+          if (nf < nfr) {
+            frag_t wf = ld_frag(ws + (16 * nf + i) * LD + 8 * q);
+            mma16(wf, xf[0], acc[0][nf]);
+            mma16(wf, xf[1], acc[1][nf]);
+          }
+        }
+      }
+    }
+
+    float part_s[32], part_ss[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) { part_s[e] = 0.f; part_ss[e] = 0.f; }
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      const int aa = a0 + 2 * wave + mf, bb = b0 + i;
+      const bool valid = aa < a.A && bb < a.B;
+      const long row = ((long)img * a.OH + (a.oy0 + aa * a.os)) * a.OW + (a.ox0 + bb * a.os);
+#pragma unroll
+      for (int nf = 0; nf < 8; ++nf) {
+        if (nf < nfr && valid) {
+          const int n = n0 + 16 * nf + 4 * q;
+          float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
+          if (a.residual) {
+            float rr[4];
+            load4((const T*)a.residual + row * Cout + n, rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+          }
+          store4(y + row * Cout + n, v);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            part_s[nf * 4 + r] += v[r];
+            part_ss[nf * 4 + r] += v[r] * v[r];
+          }
+        }
+      }
+    }
+    if (a.stats) {
+      int e0 = reduce_scatter32(part_s, i);
+      reduce_scatter32(part_ss, i);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int e = e0 + t;
+        const int nl = 16 * (e >> 2) + 4 * q + (e & 3);
+        atomicAdd(&st_s[nl], part_s[t]);
+        atomicAdd(&st_ss[nl], part_ss[t]);
+      }
+      __syncthreads();
+      if (tid < CV_BNT && n0 + tid < Cout) {
+        const int slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7) % MDS_STAT_SLOTS;
+        float* st = a.stats + (long)slot * 2 * Cout;
+        atomicAdd(st + n0 + tid, st_s[tid]);
+        atomicAdd(st + Cout + n0 + tid, st_ss[tid]);
+      }
+    }
+  }
+}
+
+static int tap_extent(const int* d, int n, int* dmin) {
+  int lo = d[0], hi = d[0];
+  for (int t = 1; t < n; ++t) { if (d[t] < lo) lo = d[t]; if (d[t] > hi) hi = d[t]; }
+  *dmin = lo;
+  return hi - lo;
+}
+
+extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->N > 0 && a->A > 0 && a->B > 0, "conv_fwd: bad dims");
+  MDS_REQUIRE(a->Cin % 8 == 0 && a->Cout % 16 == 0, "conv_fwd: Cin=%d %% 8, Cout=%d %% 16", a->Cin, a->Cout);
+  MDS_REQUIRE(a->ntaps >= 1 && a->ntaps <= MDS_MAX_TAPS && a->wtaps >= 1, "conv_fwd: ntaps");
+  MDS_REQUIRE(a->is >= 1 && a->os >= 1, "conv_fwd: strides");
+  MDS_REQUIRE(a->x && a->w && a->y, "conv_fwd: null pointer");
+  MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_AFFINE || a->pro.mode == MDS_PRO_BN_SILU, "conv_fwd: prologue mode");
+  MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "conv_fwd: prologue needs scale/shift");
+  MDS_REQUIRE(a->oy0 + (a->A - 1) * a->os < a->OH && a->ox0 + (a->B - 1) * a->os < a->OW, "conv_fwd: sub-grid exceeds output");
+  int dymin, dxmin;
+  const int eh = tap_extent(a->dy, a->ntaps, &dymin), ew = tap_extent(a->dx, a->ntaps, &dxmin);
+  const int TH = (CV_TA - 1) * a->is + eh + 1, TW = (CV_TB - 1) * a->is + ew + 1;
+  dim3 grid(cdiv(a->B, CV_TB), cdiv(a->A, CV_TA), a->N), block(256);
+#define CV_GO(T, PRO)                                                                             \
+  MDS_LAUNCH((conv_fwd_kernel<T, PRO>), grid, block,                                              \
+             (size_t)(TH * TW + CV_BNT) * PwLd<T>::v * sizeof(T) + 2 * CV_BNT * sizeof(float), stream, *a, dymin, dxmin, TH, TW)
+  MDS_DISPATCH_DTYPE(a->dtype, T, {
+    switch (a->pro.mode) {
+      case MDS_PRO_NONE: CV_GO(T, MDS_PRO_NONE); break;
+      case MDS_PRO_AFFINE: CV_GO(T, MDS_PRO_AFFINE); break;
+      default: CV_GO(T, MDS_PRO_BN_SILU); break;
+    }
+  });
+#undef CV_GO
+  return mds_check_launch("conv_fwd");
+}
+
+// ------------------------------------------------------------------------------------ wgrad
+// dw[co][ci][tap] += sum over output points of dy[p][co] * pro(x)[p*is + tap][ci].
+// The MFMA reduction index is the output point; a block walks `tiles_per_block` 8x16 patches and
+// keeps all 9 x Cin x 64 accumulators in registers (wave w owns taps w, w+4, w+8).
+#define CW_COT 64
+template <typename T, int PRO>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, int dymin, int dxmin, int TH, int TW,
+                                                         int tiles_a, int tiles_b, int tiles_per_block) {
+  typedef typename Frag<T>::type frag_t;
+  MDS_DYN_SMEM(smem);
+  const int Cin = a.Cin, Cout = a.Cout;
+  const int LDX = Cin + 2, LDY = CW_COT + 2;
+  T* xs = (T*)smem;            // [TH*TW][LDX]
+  T* dys = xs + TH * TW * LDX;  // [128][LDY]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int co0 = blockIdx.y * CW_COT;
+  const int cofr = (Cout - co0 >= CW_COT) ? 4 : ((Cout - co0) >> 4);
+  const int cifr = Cin >> 4;
+  const int cpp = Cin >> 3;  // 8-channel chunks per pixel
+  const int npix = TH * TW;
+  const long total_tiles = (long)a.N * tiles_a * tiles_b;
+  long tl = (long)blockIdx.x * tiles_per_block;
+  long tl_end = tl + tiles_per_block;
+  if (tl_end > total_tiles) tl_end = total_tiles;
+
+  f32x4 acc[3][3][4];
+#pragma unroll
+  for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+    for (int kf = 0; kf < 3; ++kf)
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) acc[tt][kf][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (; tl < tl_end; ++tl) {
+    const int img = (int)(tl / (tiles_a * tiles_b));
+    const int rem = (int)(tl - (long)img * tiles_a * tiles_b);
+    const int a0 = (rem / tiles_b) * CV_TA, b0 = (rem % tiles_b) * CV_TB;
+    const T* x = (const T*)a.x + (long)img * a.IH * a.IW * Cin;
+    const T* dy = (const T*)a.dyt + (long)img * a.OH * a.OW * Cout;
+    __syncthreads();
+    for (int it = tid; it < npix * cpp; it += 256) {
+      const int pix = it / cpp, ch = it - pix * cpp;
+      const int ty = pix / TW, tx = pix - ty * TW;
+      const int iy = a0 * a.is + dymin + ty, ix = b0 * a.is + dxmin + tx;
+      float v[8];
+      if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
+        load8(x + ((long)iy * a.IW + ix) * Cin + 8 * ch, v);
+        if (PRO != MDS_PRO_NONE) {
+          float sc[8], sh[8];
+          load8f(a.pro.scale + 8 * ch, sc);
+          load8f(a.pro.shift + 8 * ch, sh);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float z = v[j] * sc[j] + sh[j];
+            v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+      lds_store8_u32(xs + pix * LDX + 8 * ch, v);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int it = tid + 256 * p;
+      const int pt = it >> 3, ch = it & 7;
+      const int aa = a0 + (pt >> 4), bb = b0 + (pt & 15);
+      const int co = co0 + 8 * ch;
+      float v[8];
+      if (aa < a.OH && bb < a.OW && co < Cout) {
+        load8(dy + ((long)aa * a.OW + bb) * Cout + co, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+      lds_store8_u32(dys + pt * LDY + 8 * ch, v);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+      const int al = 2 * s + (q >> 1), blb = 8 * (q & 1);
+      frag_t yf[4];
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) {
+        if (cf < cofr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) yf[cf][j] = dys[(al * 16 + blb + j) * LDY + 16 * cf + i];
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        const int t = wave + 4 * tt;
+        if (t < a.ntaps) {
+          const int pbase = (al * a.is + a.dy[t] - dymin) * TW + (blb * a.is + a.dx[t] - dxmin);
+#pragma unroll
+          for (int kf = 0; kf < 3; ++kf) {
+            if (kf < cifr) {
+              frag_t xf;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) xf[j] = xs[(pbase + j * a.is) * LDX + 16 * kf + i];
+#pragma unroll
+              for (int cf = 0; cf < 4; ++cf)
+                if (cf < cofr) mma16(yf[cf], xf, acc[tt][kf][cf]);  // acc[r] = dw[co = 4q + r][ci = i]
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < 3; ++tt) {
+    const int t = wave + 4 * tt;
+    if (t < a.ntaps) {
+#pragma unroll
+      for (int kf = 0; kf < 3; ++kf)
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          if (kf < cifr && cf < cofr) {
+            const int ci = 16 * kf + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = co0 + 16 * cf + 4 * q + r;
+              atomicAdd(a.dw + ((long)co * Cin + ci) * a.wtaps + a.wi[t], acc[tt][kf][cf][r]);
+            }
+          }
+        }
+    }
+  }
+}
+
+extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->N > 0 && a->OH > 0 && a->OW > 0, "conv_wgrad: bad dims");
+  MDS_REQUIRE(a->Cin % 16 == 0 && a->Cin <= 48 && a->Cout % 16 == 0, "conv_wgrad: needs Cin in {16,32,48}, Cout %% 16 (Cin=%d Cout=%d)", a->Cin, a->Cout);
+  MDS_REQUIRE(a->ntaps >= 1 && a->ntaps <= MDS_MAX_TAPS && a->is >= 1, "conv_wgrad: taps/stride");
+  MDS_REQUIRE(a->x && a->dyt && a->dw, "conv_wgrad: null pointer");
+  MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_AFFINE || a->pro.mode == MDS_PRO_BN_SILU, "conv_wgrad: prologue mode");
+  MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "conv_wgrad: prologue needs scale/shift");
+  int dymin, dxmin;
+  const int eh = tap_extent(a->dy, a->ntaps, &dymin), ew = tap_extent(a->dx, a->ntaps, &dxmin);
+  const int TH = (CV_TA - 1) * a->is + eh + 1, TW = (CV_TB - 1) * a->is + ew + 1;
+  const int tiles_a = cdiv(a->OH, CV_TA), tiles_b = cdiv(a->OW, CV_TB);
+  const long total = (long)a->N * tiles_a * tiles_b;
+  const int cot = cdiv(a->Cout, CW_COT);
+  long want = 768 / cot;
+  if (want < 1) want = 1;
+  int tpb = (int)((total + want - 1) / want);
+  if (tpb < 1) tpb = 1;
+  dim3 grid(cdiv(total, tpb), cot), block(256);
+#define CW_GO(T, PRO)                                                                                         \
+  MDS_LAUNCH((conv_wgrad_kernel<T, PRO>), grid, block,                                                        \
+             (size_t)(TH * TW * (a->Cin + 2) + 128 * (CW_COT + 2)) * sizeof(T), stream, *a, dymin, dxmin, TH, TW, \
+             tiles_a, tiles_b, tpb)
+  MDS_DISPATCH_DTYPE(a->dtype, T, {
+    switch (a->pro.mode) {
+      case MDS_PRO_NONE: CW_GO(T, MDS_PRO_NONE); break;
+      case MDS_PRO_AFFINE: CW_GO(T, MDS_PRO_AFFINE); break;
+      default: CW_GO(T, MDS_PRO_BN_SILU); break;
+    }
+  });
+#undef CW_GO
+  return mds_check_launch("conv_wgrad");
+}

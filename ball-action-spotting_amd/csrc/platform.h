@@ -94,8 +94,19 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
   for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
 }
 #define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
-#define MDS_LAUNCH(kernel, grid, block, smem, stream, ...) \
-  hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+// gfx950 has 160 KiB of LDS per CU; launches above the 64 KiB default opt in once per kernel.
+#define MDS_LAUNCH(kernel, grid, block, smem, stream, ...)                                          \
+  do {                                                                                              \
+    const size_t mds_smem_ = (size_t)(smem);                                                        \
+    if (mds_smem_ > 65536) {                                                                        \
+      static size_t mds_cur_ = 0;                                                                   \
+      if (mds_smem_ > mds_cur_) {                                                                   \
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mds_smem_); \
+        mds_cur_ = mds_smem_;                                                                       \
+      }                                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL(kernel, grid, block, mds_smem_, (hipStream_t)(stream), __VA_ARGS__);        \
+  } while (0)
 #else  // ---- host simulator (tests only): same contracts, scalar arithmetic
 MDS_DEV void mma16_emu(const float (&a)[8], const float (&b)[8], f32x4& c, bool round_bf16) {
   int lane = hipemu::lane_id();

@@ -1,0 +1,142 @@
+"""Dense 3x3 conv MFMA kernels (fwd, both dgrads, wgrad) against torch conv2d / autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from backends import be, DT, assert_close  # noqa: F401
+from mds import cabi, geometry as geo
+from oracle.multidim_stacker_ref import Conv2dSame
+
+
+def gen(s):
+    return torch.Generator().manual_seed(s)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def ref_conv(x, w, stride):
+    if stride == 1:
+        return F.conv2d(x, w, None, 1, 1)
+    (pt, pb), (pl, pr) = geo.same_pad(x.shape[2], stride), geo.same_pad(x.shape[3], stride)
+    ref_mod = Conv2dSame(w.shape[1], w.shape[0], 3, stride, bias=False)   # the oracle's padding rule
+    with torch.no_grad():
+        probe = torch.zeros(1, w.shape[1], x.shape[2], x.shape[3])
+        assert ref_mod(probe).shape[2:] == F.conv2d(F.pad(probe, (pl, pr, pt, pb)), w.detach(), None, stride).shape[2:]
+    return F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, None, stride)
+
+
+def pack(w, kind, tdt):
+    O, I = w.shape[:2]
+    w9 = w.reshape(O, I, 9)
+    if kind == "oi":
+        return w9.permute(0, 2, 1).contiguous().to(tdt)          # [O][9][I]
+    return w9.flip(2).permute(1, 2, 0).contiguous().to(tdt)      # [I][9 flipped][O]
+
+
+CASES = [  # N, H, W, Cin, Cout, stride, pro
+    (2, 13, 21, 32, 16, 1, 2),
+    (1, 9, 18, 48, 192, 1, 0),
+    (2, 16, 34, 16, 64, 2, 2),
+    (1, 11, 17, 32, 128, 2, 1),   # odd sizes: TF-SAME pads 1/1
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,mode", CASES)
+def test_conv_fwd(be, dt, N, H, W, Cin, Cout, stride, mode):
+    code, tdt = DT[dt]
+    g = gen(H * W + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).to(tdt)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(tdt)
+    scale = 1 + 0.2 * torch.randn(Cin, generator=g); shift = 0.3 * torch.randn(Cin, generator=g)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
+    dy, dx, wi = geo.taps_fwd(pt, pl)
+    y = torch.full((N, OH, OW, Cout), float("nan")).to(tdt).to(be.device)
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, Cout, device=be.device)
+    args = cabi.make("mds_conv_fwd_args", dtype=code, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout,
+                     A=OH, B=OW, oy0=0, ox0=0, os=1, **{"is": stride}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9,
+                     x=be.t(nhwc(x)), w=be.t(pack(w, "oi", tdt)), y=y,
+                     pro=cabi.pro(mode, be.t(scale), be.t(shift)), residual=None, stats=st)
+    be.call("conv_fwd", args)
+    be.sync()
+    a = x.float()
+    if mode:
+        a = a * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        if mode == 2:
+            a = F.silu(a)
+        if dt == "bf16":
+            a = a.to(tdt).float()
+    ref = nhwc(ref_conv(a, w.float(), stride))
+    assert ref.shape == y.shape
+    assert_close(y, ref, dt, msg="y")
+    s = st.sum(0).cpu()
+    cnt = N * OH * OW
+    assert_close(s[0], ref.sum((0, 1, 2)), dt, scale=cnt ** 0.5, msg="sum")
+    assert_close(s[1], (ref * ref).sum((0, 1, 2)), dt, scale=cnt ** 0.5, msg="sumsq")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,mode", CASES)
+def test_conv_dgrad(be, dt, N, H, W, Cin, Cout, stride, mode):
+    code, tdt = DT[dt]
+    g = gen(H + W + Cout)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(tdt)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
+    dyt = torch.randn(N, Cout, OH, OW, generator=g).to(tdt)
+    res = torch.randn(N, H, W, Cin, generator=g).to(tdt)
+    xx = torch.zeros(N, Cin, H, W, requires_grad=True)
+    ref_conv(xx, w.float(), stride).backward(dyt.float())
+    ref = nhwc(xx.grad) + res.float()
+    dxo = torch.full((N, H, W, Cin), float("nan")).to(tdt).to(be.device)
+    wp = be.t(pack(w, "io", tdt)); dyd = be.t(nhwc(dyt)); rd = be.t(res)
+    common = dict(dtype=code, N=N, IH=OH, IW=OW, Cin=Cout, OH=H, OW=W, Cout=Cin, wtaps=9, x=dyd, w=wp, y=dxo,
+                  pro=cabi.pro(0), residual=rd, stats=None)
+    if stride == 1:
+        dy, dx, wi = geo.taps_dgrad_s1()
+        be.call("conv_fwd", cabi.make("mds_conv_fwd_args", A=H, B=W, oy0=0, ox0=0, os=1, **{"is": 1}, ntaps=9,
+                                      dy=dy, dx=dx, wi=wi, **common))
+    else:
+        for py in range(2):
+            for px in range(2):
+                dy, dx, wi = geo.taps_dgrad_s2(py, px, pt, pl)
+                A, B = (H - py + 1) // 2, (W - px + 1) // 2
+                if A <= 0 or B <= 0 or not dy:
+                    continue
+                be.call("conv_fwd", cabi.make("mds_conv_fwd_args", A=A, B=B, oy0=py, ox0=px, os=2, **{"is": 1},
+                                              ntaps=len(dy), dy=dy, dx=dx, wi=wi, **common))
+    be.sync()
+    assert_close(dxo, ref, dt, msg="dx")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,mode", CASES)
+def test_conv_wgrad(be, dt, N, H, W, Cin, Cout, stride, mode):
+    code, tdt = DT[dt]
+    g = gen(H * 3 + W + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g).to(tdt)
+    scale = 1 + 0.2 * torch.randn(Cin, generator=g); shift = 0.3 * torch.randn(Cin, generator=g)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
+    dyt = torch.randn(N, Cout, OH, OW, generator=g).to(tdt)
+    a = x.float()
+    if mode:
+        a = a * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        if mode == 2:
+            a = F.silu(a)
+        if dt == "bf16":
+            a = a.to(tdt).float()
+    ww = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    ref_conv(a, ww, stride).backward(dyt.float())
+    dy, dx, wi = geo.taps_fwd(pt, pl)
+    dw = torch.zeros(Cout, Cin, 3, 3, device=be.device)
+    be.call("conv_wgrad", cabi.make("mds_conv_wgrad_args", dtype=code, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW,
+                                    Cout=Cout, **{"is": stride}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9,
+                                    x=be.t(nhwc(x)), dyt=be.t(nhwc(dyt)), dw=dw,
+                                    pro=cabi.pro(mode, be.t(scale), be.t(shift))))
+    be.sync()
+    assert_close(dw, ww.grad, dt, scale=(N * OH * OW) ** 0.5, msg="dw")
