@@ -1,0 +1,3 @@
+"""mds — MI355X-native MultiDimStacker hot path (drop-in for src/models/multidim_stacker.py)."""
+from .module import MultiDimStacker  # noqa: F401
+from .cabi import MdsError, load  # noqa: F401

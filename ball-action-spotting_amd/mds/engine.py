@@ -1,0 +1,580 @@
+"""Launch planner / executor for the MultiDimStacker hot path on MI355X.
+
+For one (shape, dtype, mode) the planner walks the module once and records the complete forward
+and backward *launch schedules* as pre-filled C-ABI argument structs (include/mds.h) over
+pre-allocated device buffers — no tracing compiler, no per-step allocation.  A training step is
+then: one memset of the statistics arena, one weight-pack launch, ~300 forward launches, and
+(later) ~500 backward launches, all asynchronous on the caller's HIP stream.
+
+Data layout in HBM (all channels-last "rows", C contiguous):
+  frames      fp32  (B*S, 3, H, W) planes  — the reference's x.view(b*S, 3, h, w), read in place
+  activations T     [N*H*W][C] (2D) / [B*S*h*w][C] (3D), T = bf16 (autocast) or fp32
+  every conv keeps its *raw* output y plus fp32 per-channel sums; BatchNorm(+SiLU)(+SE gate) is
+  applied by the consumer while loading ("prologue"), so each tensor is written once and the
+  normalised copy never exists in memory.  Block outputs (after BN3 + DropPath + skip) are
+  materialised because two consumers need them.
+Reference mapping: forward_2d / forward_3d / forward_head of
+/root/reference/src/models/multidim_stacker.py:210-243 and timm EfficientNetFeatures.forward.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import cabi, geometry as geo
+from .cabi import MDS_STAT_SLOTS as SLOTS
+
+PRO_NONE, PRO_AFFINE, PRO_BN_SILU, PRO_GATE = 0, 1, 2, 3
+G_PLAIN, G_SILU, G_SE, G_MASK = 0, 1, 2, 3
+
+
+class Lazy:
+    """A buffer request that is bound to device memory when the plan is finalised."""
+    __slots__ = ("kind", "numel", "dtype", "tensor", "parent", "off")
+
+    def __init__(self, kind, numel, dtype, parent=None, off=0):
+        self.kind, self.numel, self.dtype = kind, int(numel), dtype
+        self.tensor, self.parent, self.off = None, parent, int(off)
+
+    def sub(self, off, n):
+        return Lazy("sub", n, self.dtype, self, off)
+
+    def resolve(self):
+        if self.tensor is None:
+            assert self.kind == "sub", f"unbound buffer of kind {self.kind}"
+            self.tensor = self.parent.resolve()[self.off:self.off + self.numel]
+        return self.tensor
+
+
+class P:
+    """Reference to a live parameter / buffer tensor of the module."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    def resolve(self):
+        return self.t.detach()
+
+
+class BNL:
+    """One BatchNorm layer: parameters + the fp32 side buffers the kernels exchange."""
+
+    def __init__(self, pb, mod, C_, count):
+        self.mod, self.C, self.count = mod, C_, int(count)
+        self.buf = pb.f32(4 * C_)                      # scale | shift | mean | rstd
+        self.stats = pb.zero_fwd(SLOTS * 2 * C_) if pb.batch_stats else None
+        self.bstats = pb.zero_bwd(SLOTS * 2 * C_) if pb.need_grad else None
+        self.coef = pb.f32(3 * C_) if pb.need_grad else None
+
+    scale = property(lambda s: s.buf.sub(0, s.C))
+    shift = property(lambda s: s.buf.sub(s.C, s.C))
+    mean = property(lambda s: s.buf.sub(2 * s.C, s.C))
+    rstd = property(lambda s: s.buf.sub(3 * s.C, s.C))
+
+    def pro(self, mode=PRO_BN_SILU, gate=None, rpg=0):
+        return dict(mode=mode, scale=self.scale, shift=self.shift, gate=gate, rows_per_group=rpg)
+
+    def finalize(self, pb, seg):
+        m = self.mod
+        pb.op(seg, "bn_finalize", C=self.C, count=self.count, stats=self.stats, gamma=P(m.weight), beta=P(m.bias),
+              eps=float(m.eps), momentum=float(m.momentum if m.momentum is not None else 0.1),
+              training=int(pb.batch_stats), running_mean=P(m.running_mean), running_var=P(m.running_var),
+              num_batches_tracked=P(m.num_batches_tracked) if pb.batch_stats else None, out=self.buf)
+
+    def backward(self, pb, seg, gsrc, y, dy, reduce=True, frozen=False):
+        """emit reduce / finalize / apply; `gsrc` describes how g is derived (mds_gsrc_t)."""
+        M = self.count
+        if reduce:
+            pb.op(seg, "bn_bwd_reduce", dtype=pb.code, M=M, C=self.C, g=gsrc, y=y, bn=self.buf, stats=self.bstats)
+        pb.op(seg, "bn_bwd_finalize", C=self.C, count=M, stats=self.bstats, gamma=P(self.mod.weight), bn=self.buf,
+              dgamma=None if frozen else pb.grad(self.mod.weight), dbeta=None if frozen else pb.grad(self.mod.bias),
+              coef=self.coef)
+        pb.op(seg, "bn_bwd_apply", dtype=pb.code, M=M, C=self.C, g=gsrc, y=y, bn=self.buf, coef=self.coef, dy=dy)
+
+
+def gsrc(mode, u, gate=None, dpooled=None, mask=None, rpg=0):
+    return dict(_struct="mds_gsrc_t", mode=mode, u=u, gate=gate, dpooled=dpooled, mask=mask, rows_per_group=rpg)
+
+
+class Plan:
+    """The recorded schedules + buffers for one configuration."""
+
+    def __init__(self, module, lib, device, kind, B, T, H, W, code, training, need_grad, enc_grad):
+        self.lib, self.device, self.kind = lib, device, kind
+        self.code = code
+        self.tdt = torch.bfloat16 if code == cabi.MDS_BF16 else torch.float32
+        self.training = training
+        self.batch_stats = training            # F.batch_norm(training=True) semantics
+        self.update_running = training
+        self.need_grad = need_grad
+        self.enc_grad = enc_grad and need_grad
+        self.m = module
+        self.in_flight = False
+        self._lazy: List[Lazy] = []
+        self._zf, self._zb = 0, 0
+        self.segs: Dict[str, list] = {"pack": [], "f2d": [], "f3d": [], "fhead": [], "bhead": [], "b3d": [], "b2d": []}
+        self._recs: Dict[str, list] = {"2d": [], "3d": [], "head": []}
+        self.pack_jobs = []
+        self.masks = []          # (Lazy view, keep_prob)
+        self._mask_total = 0
+        self.mask_arena = Lazy("own", 0, torch.float32)
+        self.zf_arena = Lazy("own", 0, torch.float32)
+        self.zb_arena = Lazy("own", 0, torch.float32)
+        # flat gradient arena over all parameters, in parameter order
+        self.params = list(module.parameters())
+        self.poff, off = {}, 0
+        for p in self.params:
+            self.poff[id(p)] = off
+            off += p.numel()
+        self.grad_arena = Lazy("own", off if need_grad else 0, torch.float32)
+        self.B, self.T, self.H, self.W = B, T, H, W
+        self._build()
+        self._finalize()
+
+    # ------------------------------------------------------------------ buffer requests
+    def _own(self, n, dtype):
+        l = Lazy("own", n, dtype)
+        self._lazy.append(l)
+        return l
+
+    def act(self, rows, ch):
+        return self._own(int(rows) * ch, self.tdt)
+
+    def f32(self, n):
+        return self._own(n, torch.float32)
+
+    def zero_fwd(self, n):
+        l = self.zf_arena.sub(self._zf, n)
+        self._zf += n
+        return l
+
+    def zero_bwd(self, n):
+        l = self.zb_arena.sub(self._zb, n)
+        self._zb += n
+        return l
+
+    def grad(self, p):
+        return self.grad_arena.sub(self.poff[id(p)], p.numel())
+
+    def mask(self, n, rate):
+        if not self.training or not rate:
+            return None
+        l = self.mask_arena.sub(self._mask_total, n)
+        self.masks.append((self._mask_total, n, 1.0 - rate))
+        self._mask_total += n
+        return l
+
+    def pack(self, param, kind, O, I, taps):
+        n = O * 32 if kind == cabi.MDS_PACK_STEM else O * I * taps
+        dst = self._own(n, self.tdt)
+        self.pack_jobs.append((param, dst, kind, O, I, taps))
+        return dst
+
+    def op(self, seg, name, **kw):
+        self.segs[seg].append((name, kw))
+
+    # ------------------------------------------------------------------ graph construction
+    def _build(self):
+        m = self.m
+        B, T, H, W = self.B, self.T, self.H, self.W
+        S = T // m.stack_size
+        N = B * S
+        if self.kind in ("full", "2d"):
+            self.x_in = Lazy("input", B * T * H * W, torch.float32)   # bound to the caller's tensor per call
+            feat, h, w = self._build_2d(N, H, W)
+            self.feat, self.h, self.w = feat, h, w
+        else:
+            h, w = H, W  # for '3d' / 'head' plans H, W are the feature-map extent
+            self.h, self.w = h, w
+        if self.kind in ("full", "3d"):
+            if self.kind == "3d":
+                self.feat = self.act(N * h * w, m.num_3d_features)
+            yq, bnq = self._build_3d(B, S, h, w, self.feat)
+            self.yq, self.bnq = yq, bnq
+        if self.kind in ("full", "head"):
+            if self.kind == "head":
+                self.yq, self.bnq = self.act(N * h * w, m.num_features // S), None
+            self._build_head(B, S, h, w, self.yq, self.bnq)
+        if self.kind == "3d":   # separately-called forward_3d returns the activated projection
+            self.out3d = self.act(N * h * w, m.num_features // S)
+            self.op("f3d", "bn_res", dtype=self.code, M=N * h * w, C=m.num_features // S, y=self.yq,
+                    scale=self.bnq.scale, shift=self.bnq.shift, act=1, mask=None, rows_per_group=0,
+                    shortcut=None, out=self.out3d)
+        if self.need_grad:
+            gout = None
+            for name, bseg in (("head", "bhead"), ("3d", "b3d"), ("2d", "b2d")):
+                for rec in reversed(self._recs[name]):
+                    gout = rec(bseg, gout)
+                    if gout is None:
+                        break
+                if gout is None:
+                    break
+
+    # -- helpers emitting a conv + its BN finalize
+    def _pw(self, seg, x, M, K, N_, wparam, pro=None, stats_bn=None, residual=None, wt=None):
+        y = self.act(M, N_)
+        w = wt if wt is not None else self.pack(wparam, cabi.MDS_PACK_OI, N_, K, 1)
+        self.op(seg, "pw_fwd", dtype=self.code, M=M, K=K, N=N_, x=x, w=w, y=y, pro=pro or dict(mode=0),
+                residual=residual, stats=stats_bn.stats if stats_bn is not None else None)
+        if stats_bn is not None:
+            stats_bn.finalize(self, seg)
+        return y
+
+    def _conv(self, seg, x, pro, N, IH, IW, Cin, Cout, stride, wparam, bn_mod):
+        OH, OW, pt, pl = geo.conv_geometry(IH, IW, stride)
+        bn = BNL(self, bn_mod, Cout, N * OH * OW)
+        dy, dx, wi = geo.taps_fwd(pt, pl)
+        y = self.act(N * OH * OW, Cout)
+        w = self.pack(wparam, cabi.MDS_PACK_OI, Cout, Cin, 9)
+        self.op(seg, "conv_fwd", dtype=self.code, N=N, IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, Cout=Cout, A=OH, B=OW,
+                oy0=0, ox0=0, os=1, **{"is": stride}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9, x=x, w=w, y=y,
+                pro=pro or dict(mode=0), residual=None, stats=bn.stats)
+        bn.finalize(self, seg)
+        return y, bn, OH, OW, (pt, pl)
+
+    def _conv_dgrad(self, seg, dyb, N, IH, IW, Cin, Cout, stride, wparam, pads, residual):
+        """grad wrt the conv input ([N][IH][IW][Cin]) from dy ([N][OH][OW][Cout])."""
+        OH, OW, _, _ = geo.conv_geometry(IH, IW, stride)
+        w = self.pack(wparam, cabi.MDS_PACK_IO_FLIP, Cout, Cin, 9)
+        dxb = self.act(N * IH * IW, Cin)
+        common = dict(dtype=self.code, N=N, IH=OH, IW=OW, Cin=Cout, OH=IH, OW=IW, Cout=Cin, wtaps=9, x=dyb, w=w,
+                      y=dxb, pro=dict(mode=0), residual=residual, stats=None)
+        if stride == 1:
+            dy, dx, wi = geo.taps_dgrad_s1()
+            self.op(seg, "conv_fwd", A=IH, B=IW, oy0=0, ox0=0, os=1, **{"is": 1}, ntaps=9, dy=dy, dx=dx, wi=wi, **common)
+        else:
+            assert residual is None
+            for py in range(2):
+                for px in range(2):
+                    dy, dx, wi = geo.taps_dgrad_s2(py, px, pads[0], pads[1])
+                    A, B_ = (IH - py + 1) // 2, (IW - px + 1) // 2
+                    assert dy and A > 0 and B_ > 0
+                    self.op(seg, "conv_fwd", A=A, B=B_, oy0=py, ox0=px, os=2, **{"is": 1}, ntaps=len(dy), dy=dy, dx=dx,
+                            wi=wi, **common)
+        return dxb
+
+    def _pw_bwd(self, seg, xin, pro, M, K, N_, wparam, dy, need_dx, residual=None, frozen=False):
+        """wgrad (+ dgrad) of a 1x1 conv y[M][N] = pro(x)[M][K] w^T."""
+        if not frozen:
+            self.op(seg, "pw_wgrad", dtype=self.code, M=M, K=K, N=N_, x=xin, dy=dy, dw=self.grad(wparam),
+                    pro=pro or dict(mode=0))
+        if not need_dx:
+            return None
+        wt = self.pack(wparam, cabi.MDS_PACK_IO_FLIP, N_, K, 1)       # [K][N]
+        dx = self.act(M, K)
+        self.op(seg, "pw_fwd", dtype=self.code, M=M, K=N_, N=K, x=dy, w=wt, y=dx, pro=dict(mode=0),
+                residual=residual, stats=None)
+        return dx
+
+    # -- inverted-residual block (2D: T=1, kt=1 ; 3D: kt=3), shared by encoder stages 3-5 and conv3d_encoder
+    def _ir_block(self, fseg, recs, blk, bn1m, bn2m, bn3m, xin, N, T, IH, IW, stride, groups, has_skip, frozen):
+        cin, mid, cout = blk.cin, blk.mid, blk.cout
+        kt = 3 if isinstance(blk.conv_dw, torch.nn.Conv3d) else 1
+        OH, OW, pt, pl = geo.conv_geometry(IH, IW, stride)
+        Min, Mout = N * T * IH * IW, N * T * OH * OW
+        rpg = Mout // groups
+        bn1, bn2, bn3 = BNL(self, bn1m, mid, Min), BNL(self, bn2m, mid, Mout), BNL(self, bn3m, cout, Mout)
+        y1 = self._pw(fseg, xin, Min, cin, mid, blk.conv_pw.weight, stats_bn=bn1)
+        y2 = self.act(Mout, mid)
+        wdw = P(blk.conv_dw.weight)
+        self.op(fseg, "dw_fwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
+                pad_l=pl, kt=kt, x=y1, w=wdw, y=y2, pro=bn1.pro(), stats=bn2.stats)
+        bn2.finalize(self, fseg)
+        R = blk.se.rd
+        pooled, hidden, gate = self.zero_fwd(groups * mid), self.f32(groups * R), self.f32(groups * mid)
+        self.op(fseg, "se_pool", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, y=y2, scale=bn2.scale,
+                shift=bn2.shift, pooled=pooled)
+        se = blk.se
+        self.op(fseg, "se_fc_fwd", groups=groups, C=mid, R=R, pooled=pooled, w1=P(se.conv_reduce.weight),
+                b1=P(se.conv_reduce.bias), w2=P(se.conv_expand.weight), b2=P(se.conv_expand.bias), hidden=hidden, gate=gate)
+        y3 = self._pw(fseg, y2, Mout, mid, cout, blk.conv_pwl.weight, pro=bn2.pro(PRO_GATE, gate, rpg), stats_bn=bn3)
+        mask = self.mask(groups, blk.dpr) if has_skip else None
+        xout = self.act(Mout, cout)
+        self.op(fseg, "bn_res", dtype=self.code, M=Mout, C=cout, y=y3, scale=bn3.scale, shift=bn3.shift, act=0, mask=mask,
+                rows_per_group=rpg, shortcut=xin if has_skip else None, out=xout)
+
+        def bwd(seg, dout):
+            g3 = gsrc(G_MASK, dout, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout)
+            dy3 = self.act(Mout, cout)
+            bn3.backward(self, seg, g3, y3, dy3, frozen=frozen)
+            u2 = self._pw_bwd(seg, y2, bn2.pro(PRO_GATE, gate, rpg), Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen)
+            dgate, dpool = self.zero_bwd(groups * mid), self.f32(groups * mid)
+            self.op(seg, "se_bwd_reduce", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, u=u2, y=y2,
+                    scale=bn2.scale, shift=bn2.shift, dgate=dgate)
+            if frozen:
+                sg = [self.f32(se.conv_reduce.weight.numel()), self.f32(R), self.f32(se.conv_expand.weight.numel()), self.f32(mid)]
+            else:
+                sg = [self.grad(se.conv_reduce.weight), self.grad(se.conv_reduce.bias), self.grad(se.conv_expand.weight),
+                      self.grad(se.conv_expand.bias)]
+            self.op(seg, "se_fc_bwd", groups=groups, C=mid, R=R, rows_per_group=rpg, dgate=dgate, gate=gate, hidden=hidden,
+                    pooled=pooled, w1=P(se.conv_reduce.weight), w2=P(se.conv_expand.weight), dpooled=dpool,
+                    dw1=sg[0], db1=sg[1], dw2=sg[2], db2=sg[3])
+            dy2 = self.act(Mout, mid)
+            bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, frozen=frozen)
+            g1 = self.act(Min, mid)
+            self.op(seg, "dw_bwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
+                    pad_l=pl, kt=kt, x=y1, dy=dy2, w=wdw, g=g1, dw=self.f32(mid * kt * 9) if frozen else self.grad(blk.conv_dw.weight),
+                    pro=bn1.pro(), mean=bn1.mean, rstd=bn1.rstd, stats=bn1.bstats)
+            dy1 = self.act(Min, mid)
+            bn1.backward(self, seg, gsrc(G_PLAIN, g1), y1, dy1, reduce=False, frozen=frozen)
+            return self._pw_bwd(seg, xin, None, Min, cin, mid, blk.conv_pw.weight, dy1, True,
+                                residual=dout if has_skip else None, frozen=frozen)
+
+        recs.append(bwd)
+        return xout, OH, OW
+
+    # -- 2D: stem + 21 encoder blocks + conv2d_projection  (forward_2d, :210-219)
+    def _build_2d(self, N, H, W):
+        m, enc = self.m, self.m.conv2d_encoder
+        recs = self._recs["2d"]
+        fr = not self.enc_grad
+        OH, OW, pt, pl = geo.conv_geometry(H, W, 2)
+        y0 = self.act(N * OH * OW, 32)
+        bn0 = BNL(self, enc.bn1, 32, N * OH * OW)
+        wst = self.pack(enc.conv_stem.weight, cabi.MDS_PACK_STEM, 32, 27, 1)
+        self.op("f2d", "stem_fwd", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl, x=self.x_in,
+                w=wst, y=y0, stats=bn0.stats)
+        bn0.finalize(self, "f2d")
+
+        def stem_bwd(seg, u0):
+            if fr:
+                return None
+            dy0 = self.act(N * OH * OW, 32)
+            bn0.backward(self, seg, gsrc(G_SILU, u0), y0, dy0)
+            self.op(seg, "stem_wgrad", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
+                    x=self.x_in, dy=dy0, dw=self.grad(enc.conv_stem.weight))
+            return None
+
+        recs.append(stem_bwd)
+        cur, cur_bn, ch, cw = y0, bn0, OH, OW      # cur_bn != None: `cur` is a raw tensor read through BN+SiLU
+        for blk in enc.block_list():
+            if blk.kind == "cn":
+                cur, cur_bn, ch, cw = self._cn_block(recs, blk, cur, cur_bn, N, ch, cw, fr)
+            elif blk.kind == "er":
+                cur, ch, cw = self._er_block(recs, blk, cur, cur_bn, N, ch, cw, fr)
+                cur_bn = None
+            else:
+                assert cur_bn is None
+                cur, ch, cw = self._ir_block("f2d", recs, blk, blk.bn1, blk.bn2, blk.bn3, cur, N, 1, ch, cw, blk.stride,
+                                             N, blk.has_skip, fr)
+        # conv2d_projection: 1x1 + BN + SiLU, materialised (it is block 0's input AND shortcut)
+        M, cf = N * ch * cw, m.num_3d_features
+        cenc = enc.feature_info[-1]["num_chs"]
+        bnp = BNL(self, m.conv2d_projection[1], cf, M)
+        yp = self._pw("f2d", cur, M, cenc, cf, m.conv2d_projection[0].weight, stats_bn=bnp)
+        feat = self.act(M, cf)
+        self.op("f2d", "bn_res", dtype=self.code, M=M, C=cf, y=yp, scale=bnp.scale, shift=bnp.shift, act=1, mask=None,
+                rows_per_group=0, shortcut=None, out=feat)
+        xenc = cur
+
+        def proj_bwd(seg, dfeat):
+            dyp = self.act(M, cf)
+            bnp.backward(self, seg, gsrc(G_SILU, dfeat), yp, dyp)
+            return self._pw_bwd(seg, xenc, None, M, cenc, cf, m.conv2d_projection[0].weight, dyp, need_dx=not fr)
+
+        recs.append(proj_bwd)
+        return feat, ch, cw
+
+    def _cn_block(self, recs, blk, xin, xin_bn, N, IH, IW, fr):
+        assert not blk.has_skip and xin_bn is not None
+        y, bn1, OH, OW, pads = self._conv("f2d", xin, xin_bn.pro(), N, IH, IW, blk.cin, blk.cout, blk.stride,
+                                          blk.conv.weight, blk.bn1)
+
+        def bwd(seg, u):
+            if fr:
+                return None
+            dy_ = self.act(N * OH * OW, blk.cout)
+            bn1.backward(self, seg, gsrc(G_SILU, u), y, dy_)
+            self._conv_wgrad(seg, xin, xin_bn.pro(), N, IH, IW, blk.cin, OH, OW, blk.cout, blk.stride, pads, dy_, blk.conv.weight)
+            return self._conv_dgrad(seg, dy_, N, IH, IW, blk.cin, blk.cout, blk.stride, blk.conv.weight, pads, None)
+
+        recs.append(bwd)
+        return y, bn1, OH, OW
+
+    def _conv_wgrad(self, seg, x, pro, N, IH, IW, Cin, OH, OW, Cout, stride, pads, dyb, wparam):
+        dy, dx, wi = geo.taps_fwd(pads[0], pads[1])
+        self.op(seg, "conv_wgrad", dtype=self.code, N=N, IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, Cout=Cout,
+                **{"is": stride}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9, x=x, dyt=dyb, dw=self.grad(wparam),
+                pro=pro or dict(mode=0))
+
+    def _er_block(self, recs, blk, xin, xin_bn, N, IH, IW, fr):
+        cin, mid, cout = blk.cin, blk.mid, blk.cout
+        pro_in = xin_bn.pro() if xin_bn is not None else None
+        ya, bn1, OH, OW, pads = self._conv("f2d", xin, pro_in, N, IH, IW, cin, mid, blk.stride, blk.conv_exp.weight, blk.bn1)
+        M = N * OH * OW
+        bn2 = BNL(self, blk.bn2, cout, M)
+        yb = self._pw("f2d", ya, M, mid, cout, blk.conv_pwl.weight, pro=bn1.pro(), stats_bn=bn2)
+        has_skip = blk.has_skip
+        assert not has_skip or xin_bn is None
+        mask = self.mask(N, blk.dpr) if has_skip else None
+        rpg = OH * OW
+        xout = self.act(M, cout)
+        self.op("f2d", "bn_res", dtype=self.code, M=M, C=cout, y=yb, scale=bn2.scale, shift=bn2.shift, act=0, mask=mask,
+                rows_per_group=rpg, shortcut=xin if has_skip else None, out=xout)
+
+        def bwd(seg, dout):
+            if fr:
+                return None
+            g2 = gsrc(G_MASK, dout, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout)
+            dyb = self.act(M, cout)
+            bn2.backward(self, seg, g2, yb, dyb)
+            ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
+            dya = self.act(M, mid)
+            bn1.backward(self, seg, gsrc(G_SILU, ua), ya, dya)
+            self._conv_wgrad(seg, xin, pro_in, N, IH, IW, cin, OH, OW, mid, blk.stride, pads, dya, blk.conv_exp.weight)
+            return self._conv_dgrad(seg, dya, N, IH, IW, cin, mid, blk.stride, blk.conv_exp.weight, pads,
+                                    dout if has_skip else None)
+
+        recs.append(bwd)
+        return xout, OH, OW
+
+    # -- 3D: 4 inverted-residual blocks + conv3d_projection  (forward_3d, :221-230).  Channels-last
+    #    rows [b][t][h][w][c] make both transposes of the reference disappear.
+    def _build_3d(self, B, S, h, w, feat):
+        m = self.m
+        recs = self._recs["3d"]
+        cur = feat
+        for blk in m.conv3d_encoder:
+            cur, _, _ = self._ir_block("f3d", recs, blk, blk.bn1.bn3d, blk.bn2.bn3d, blk.bn3.bn3d, cur, B, S, h, w, 1, B,
+                                       True, False)
+        M, cf, cq = B * S * h * w, m.num_3d_features, m.num_features // S
+        bnq = BNL(self, m.conv3d_projection[1], cq, M)
+        yq = self._pw("f3d", cur, M, cf, cq, m.conv3d_projection[0].weight, stats_bn=bnq)
+        x3 = cur
+
+        def bwd(seg, uq):
+            dyq = self.act(M, cq)
+            bnq.backward(self, seg, gsrc(G_SILU, uq), yq, dyq)
+            return self._pw_bwd(seg, x3, None, M, cf, cq, m.conv3d_projection[0].weight, dyq, True)
+
+        recs.append(bwd)
+        return yq, bnq
+
+    # -- head: GeM over (h, w) for every (b, t, c) + dropout + Linear  (forward_head, :232-237)
+    def _build_head(self, B, S, h, w, yq, bnq):
+        m = self.m
+        cq = m.num_features // S
+        F_ = S * cq
+        pro = bnq.pro() if bnq is not None else dict(mode=0)
+        gp = m.global_pool
+        pooled = self.f32(B * F_)
+        self.op("fhead", "gem_fwd", dtype=self.code, groups=B * S, rows_per_group=h * w, C=cq, y=yq, pro=pro, p=P(gp.p),
+                eps=float(gp.eps), pooled=pooled)
+        dmask = self.mask(B * F_, m.drop_rate) if m.drop_rate > 0 else None
+        ncls = m.classifier.out_features
+        self.logits = self.f32(B * ncls)
+        self.op("fhead", "head_fwd", B=B, F=F_, NC=ncls, pooled=pooled, mask=dmask, w=P(m.classifier.weight),
+                b=P(m.classifier.bias), logits=self.logits)
+        self.dlogits = self.f32(B * ncls) if self.need_grad else None
+
+        def bwd(seg, _):
+            dpo = self.f32(B * F_)
+            self.op(seg, "head_bwd", B=B, F=F_, NC=ncls, pooled=pooled, mask=dmask, w=P(m.classifier.weight),
+                    dlogits=self.dlogits, dpooled=dpo, dw=self.grad(m.classifier.weight), db=self.grad(m.classifier.bias))
+            uq = self.act(B * S * h * w, cq)
+            self.op(seg, "gem_bwd", dtype=self.code, groups=B * S, rows_per_group=h * w, C=cq, y=yq, pro=pro, p=P(gp.p),
+                    eps=float(gp.eps), pooled=pooled, dpooled=dpo, u=uq, dp=self.grad(gp.p))
+            return uq
+
+        self._recs["head"].append(bwd)
+
+    # ------------------------------------------------------------------ binding
+    def _finalize(self):
+        dev = self.device
+        self.zf_arena.numel, self.zb_arena.numel, self.mask_arena.numel = self._zf, self._zb, self._mask_total
+        for arena in (self.zf_arena, self.zb_arena, self.mask_arena, self.grad_arena):
+            arena.tensor = torch.zeros(max(arena.numel, 1), dtype=torch.float32, device=dev)
+        for l in self._lazy:
+            l.tensor = torch.empty(max(l.numel, 1), dtype=l.dtype, device=dev)
+        if self.masks:
+            keep = torch.empty(self._mask_total, dtype=torch.float32)
+            for off, n, kp in self.masks:
+                keep[off:off + n] = kp
+            self.mask_keep = keep.to(dev)
+        # weight-pack job table (device resident)
+        Job = cabi.STRUCTS["mds_pack_job"]
+        jobs = (Job * max(len(self.pack_jobs), 1))()
+        self.pack_max = 1
+        for j, (p, dst, kind, O, I, taps) in enumerate(self.pack_jobs):
+            jobs[j].src = p.detach().data_ptr()
+            jobs[j].dst = dst.resolve().data_ptr()
+            jobs[j].kind, jobs[j].O, jobs[j].I, jobs[j].taps = kind, O, I, taps
+            self.pack_max = max(self.pack_max, dst.numel)
+        self.pack_table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        self.param_ptrs = tuple(p.data_ptr() for p, *_ in self.pack_jobs)
+        # bind every recorded launch
+        self.bound: Dict[str, list] = {}
+        self._keep = []
+        self.input_slots = []
+        for seg, ops in self.segs.items():
+            out = []
+            for name, kw in ops:
+                self._input_fields = []
+                st = self._bind(f"mds_{name}_args", kw)
+                for _, field in self._input_fields:
+                    self.input_slots.append((st, field))
+                out.append((name, self.lib.fn[name], st, C.byref(st)))
+            self.bound[seg] = out
+        self.nbytes = sum(l.tensor.numel() * l.tensor.element_size() for l in self._lazy)
+
+    def _bind(self, struct_name, kw):
+        vals = {}
+        for k, v in kw.items():
+            if k == "_struct":
+                continue
+            if isinstance(v, dict):
+                sub = "mds_gsrc_t" if v.get("_struct") == "mds_gsrc_t" else "mds_pro_t"
+                v = self._bind(sub, v)
+            elif isinstance(v, Lazy) and v.kind == "input":
+                self._input_fields.append((struct_name, k))
+                v = 0
+            elif isinstance(v, (Lazy, P)):
+                t = v.resolve()
+                self._keep.append(t)
+                v = t
+            vals[k] = v
+        return cabi.make(struct_name, **vals)
+
+    # ------------------------------------------------------------------ execution
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
+
+    def run(self, seg):
+        stream = self._stream()
+        for name, fn, st, ref in self.bound[seg]:
+            rc = fn(ref, stream)
+            if rc:
+                self.lib.check(rc, name)
+
+    def pack_weights(self):
+        if self.pack_jobs:
+            self.lib.check(self.lib.fn["pack_weights"](self.pack_table.data_ptr(), len(self.pack_jobs), self.pack_max,
+                                                       self.code, self._stream()), "pack_weights")
+
+    def bind_input(self, x):
+        """point the stem kernels at the caller's (B,T,H,W) fp32 frame stack — no staging copy."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == self.x_in.numel
+        ptr = x.data_ptr()
+        for st, field in self.input_slots:
+            setattr(st, field, ptr)
+        self._x_ref = x
+
+    def begin_forward(self, mask_override=None):
+        self.zf_arena.tensor.zero_()
+        if self.masks:
+            if mask_override is not None:
+                self.mask_arena.tensor.copy_(mask_override.to(self.device, torch.float32).view(-1))
+            else:
+                r = torch.rand(self._mask_total, device=self.device)
+                self.mask_arena.tensor.copy_((r < self.mask_keep).float() / self.mask_keep)
+        self.pack_weights()
+
+    def begin_backward(self):
+        self.zb_arena.tensor.zero_()
+        self.grad_arena.tensor.zero_()
+
+    def stale(self):
+        return self.param_ptrs != tuple(p.data_ptr() for p, *_ in self.pack_jobs)

@@ -1,0 +1,124 @@
+"""Depthwise (2D/3D) and stem kernels against torch conv / autograd references."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from backends import be, DT, assert_close  # noqa: F401
+from mds import cabi, geometry as geo
+
+SLOTS = cabi.MDS_STAT_SLOTS
+
+
+def gen(s):
+    return torch.Generator().manual_seed(s)
+
+
+def to_rows(x):   # (N,C,T,H,W) -> [N][T][H][W][C]
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def dw_ref(a, w, stride, kt, pads):
+    """a: (N,C,T,H,W) activated input, w: (C,1,kt,3,3)."""
+    (pt, pb), (pl, pr) = pads
+    tp = 1 if kt == 3 else 0
+    a = F.pad(a, (pl, pr, pt, pb, tp, tp))
+    return F.conv3d(a, w, None, (1, stride, stride), 0, 1, a.shape[1])
+
+
+DW_CASES = [  # N,T,H,W,C,stride,kt
+    (2, 1, 9, 13, 48, 1, 1),
+    (1, 1, 12, 18, 16, 2, 1),     # even: pad 0/1
+    (2, 1, 11, 15, 24, 2, 1),     # odd: pad 1/1
+    (2, 3, 5, 7, 24, 1, 3),
+    (1, 5, 6, 9, 576, 1, 3),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,T,H,W,C,stride,kt", DW_CASES)
+def test_dw_fwd_bwd(be, dt, N, T, H, W, C, stride, kt):
+    code, tdt = DT[dt]
+    g = gen(H * W + C + kt)
+    x = (torch.randn(N, C, T, H, W, generator=g) * 1.3).to(tdt)
+    w = torch.randn(C, 1, kt, 3, 3, generator=g) * 0.3
+    gamma = 1 + 0.2 * torch.randn(C, generator=g); beta = 0.2 * torch.randn(C, generator=g)
+    eps = 1e-3
+    OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
+    pads = (geo.same_pad(H, stride), geo.same_pad(W, stride)) if stride == 2 else ((1, 1), (1, 1))
+    # reference: a = silu(bn(x)) with the batch statistics held constant; y = dw(a)
+    xf = x.float()
+    wf = w.clone().requires_grad_(True)
+    mean = xf.mean((0, 2, 3, 4)); var = xf.var((0, 2, 3, 4), unbiased=False)
+    rstd = 1 / torch.sqrt(var + eps)
+    scale = gamma * rstd; shift = beta - mean * scale
+    z = (xf * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)).requires_grad_(True)
+    a = F.silu(z)
+    if dt == "bf16":
+        a = a + (a.detach().to(tdt).float() - a.detach())               # bf16-rounded activations
+    yref = dw_ref(a, wf, stride, kt, pads)
+    dyt = torch.randn(yref.shape, generator=g).to(tdt)
+    yref.backward(dyt.float())
+    # forward kernel
+    xd = be.t(to_rows(x)); wd = be.t(w.view(C, kt * 9))
+    scd, shd = be.t(scale), be.t(shift)
+    y = torch.full((N, T, OH, OW, C), float("nan")).to(tdt).to(be.device)
+    st = torch.zeros(SLOTS, 2, C, device=be.device)
+    pro = cabi.pro(2, scd, shd)
+    be.call("dw_fwd", cabi.make("mds_dw_fwd_args", dtype=code, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=stride,
+                                pad_t=pt, pad_l=pl, kt=kt, x=xd, w=wd, y=y, pro=pro, stats=st))
+    be.sync()
+    yr = to_rows(yref.detach())
+    assert_close(y, yr, dt, msg="y")
+    s = st.sum(0).cpu()
+    cnt = N * T * OH * OW
+    assert_close(s[0], yr.sum((0, 1, 2, 3)), dt, scale=cnt ** 0.5, msg="sum")
+    assert_close(s[1], (yr * yr).sum((0, 1, 2, 3)), dt, scale=cnt ** 0.5, msg="sumsq")
+    # backward kernel
+    gout = torch.full((N, T, H, W, C), float("nan")).to(tdt).to(be.device)
+    dw = torch.zeros(C, kt * 9, device=be.device)
+    st2 = torch.zeros(SLOTS, 2, C, device=be.device)
+    be.call("dw_bwd", cabi.make("mds_dw_bwd_args", dtype=code, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=stride,
+                                pad_t=pt, pad_l=pl, kt=kt, x=xd, dy=be.t(to_rows(dyt)), w=wd, g=gout, dw=dw, pro=pro,
+                                mean=be.t(mean), rstd=be.t(rstd), stats=st2))
+    be.sync()
+    gref = to_rows(z.grad)
+    assert_close(gout, gref, dt, msg="g")
+    assert_close(dw, wf.grad.view(C, kt * 9), dt, scale=cnt ** 0.5, msg="dw")
+    s2 = st2.sum(0).cpu()
+    xhat = to_rows((xf - mean.view(1, -1, 1, 1, 1)) * rstd.view(1, -1, 1, 1, 1))
+    cin = N * T * H * W
+    assert_close(s2[0], gref.sum((0, 1, 2, 3)), dt, scale=cin ** 0.5, msg="sum g")
+    assert_close(s2[1], (gref * xhat).sum((0, 1, 2, 3)), dt, scale=cin ** 0.5, msg="sum g*xhat")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W", [(2, 20, 36), (1, 17, 23), (3, 6, 70)])
+def test_stem_fwd_wgrad(be, dt, N, H, W):
+    code, tdt = DT[dt]
+    g = gen(H * W)
+    x = torch.rand(N, 3, H, W, generator=g)
+    w = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    OH, OW, pt, pl = geo.conv_geometry(H, W, 2)
+    (pt_, pb), (pl_, pr) = geo.same_pad(H, 2), geo.same_pad(W, 2)
+    xq = x.to(tdt).float()
+    wq = w.to(tdt).float().requires_grad_(True)
+    yref = F.conv2d(F.pad(xq, (pl_, pr, pt_, pb)), wq, None, 2)
+    dyt = torch.randn(yref.shape, generator=g).to(tdt)
+    yref.backward(dyt.float())
+    wp = torch.zeros(32, 32); wp[:, :27] = w.view(32, 27)
+    y = torch.full((N, OH, OW, 32), float("nan")).to(tdt).to(be.device)
+    st = torch.zeros(SLOTS, 2, 32, device=be.device)
+    xd = be.t(x)
+    be.call("stem_fwd", cabi.make("mds_stem_fwd_args", dtype=code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
+                                  x=xd, w=be.t(wp.to(tdt)), y=y, stats=st))
+    dw = torch.zeros(32, 3, 3, 3, device=be.device)
+    be.call("stem_wgrad", cabi.make("mds_stem_wgrad_args", dtype=code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt,
+                                    pad_l=pl, x=xd, dy=be.t(dyt.permute(0, 2, 3, 1)), dw=dw))
+    be.sync()
+    yr = yref.detach().permute(0, 2, 3, 1)
+    assert_close(y, yr, dt, msg="y")
+    s = st.sum(0).cpu()
+    cnt = N * OH * OW
+    assert_close(s[0], yr.sum((0, 1, 2)), dt, scale=cnt ** 0.5, msg="sum")
+    assert_close(s[1], (yr * yr).sum((0, 1, 2)), dt, scale=cnt ** 0.5, msg="sumsq")
+    assert_close(dw, wq.grad, dt, scale=cnt ** 0.5, msg="dw")

@@ -1,0 +1,85 @@
+"""The whole drop-in module (planner + every kernel source) stepped through the host kernel
+simulator against the oracle, fp32: logits, loss gradients for every parameter, BN buffers."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import multidim_stacker_ref as orc
+from det_init import fill_deterministic
+import mds
+from conftest import GOLDEN
+
+
+def _pair(kw, seed=3, scale=0.05):
+    ref = fill_deterministic(orc.MultiDimStacker(**kw), seed, scale=scale)
+    prod = mds.MultiDimStacker(**kw)
+    prod.load_state_dict(ref.state_dict())
+    from hipemu.loader import load_emulator
+    prod._lib = load_emulator()
+    return ref, prod
+
+
+def _cmp(name, got, want, rtol, atol_rel):
+    got, want = got.detach().float(), want.detach().float()
+    err = (got - want).abs().max().item()
+    bound = atol_rel * max(want.abs().max().item(), 1e-12) + rtol * want.abs().max().item()
+    assert err <= bound, f"{name}: max err {err:.3e} > {bound:.3e} (ref max {want.abs().max().item():.3e})"
+
+
+def test_state_dict_contract_of_product_module():
+    m = mds.MultiDimStacker(**orc.BASIC_CONFIG_KWARGS)
+    lines = open(os.path.join(GOLDEN, "state_dict_contract.txt")).read().strip().split("\n")
+    assert [f"{k} {tuple(v.shape)}" for k, v in m.state_dict().items()] == lines
+    assert sum(p.numel() for p in m.parameters()) == 6_770_547
+    m2 = copy.deepcopy(m)                      # src/ema.py:40
+    assert m2._cache is not m._cache
+    for a in ("num_stacks", "stack_size", "num_3d_features", "num_features", "drop_rate", "conv2d_encoder"):
+        assert hasattr(m, a)
+
+
+def test_product_refuses_cpu_without_hip_library():
+    m = mds.MultiDimStacker(**orc.BASIC_CONFIG_KWARGS)
+    with pytest.raises(mds.MdsError):
+        m(torch.rand(1, 15, 64, 64))
+
+
+def test_full_model_train_step_fp32_vs_oracle():
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    ref, prod = _pair(kw)
+    ref.train(); prod.train()
+    x = torch.rand(1, 15, 64, 64, generator=torch.Generator().manual_seed(1))
+    tgt = torch.tensor([[1.0, 0.0]])
+    lr = ref(x)
+    orc.sigmoid_focal_loss(lr, tgt, alpha=-1.0, gamma=1.2).backward()
+    lp = prod(x)
+    orc.sigmoid_focal_loss(lp, tgt, alpha=-1.0, gamma=1.2).backward()
+    _cmp("logits", lp, lr, 1e-4, 1e-4)
+    rp, pp = dict(ref.named_parameters()), dict(prod.named_parameters())
+    worst = []
+    # biases that feed a train-mode BatchNorm have an analytically zero gradient (~1e-8 noise):
+    # measure every error against max(|ref grad|, 1e-2 * typical grad magnitude)
+    floor = 1e-2 * float(np.median([p.grad.abs().max().item() for p in rp.values()]))
+    for n in rp:
+        g, w = pp[n].grad, rp[n].grad
+        assert g is not None, n
+        err = (g - w).abs().max().item() / max(w.abs().max().item(), floor)
+        worst.append((err, n))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 2e-3, f"worst relative grad errors: {worst[:8]}"
+    for (n, b), (_, b2) in zip(ref.named_buffers(), prod.named_buffers()):
+        _cmp("buffer " + n, b2, b, 1e-4, 1e-4)
+    # eval mode (running statistics), no grad.  The deterministic fill gives arbitrary running
+    # statistics that make the eval network blow up to ~1e5 (ill-conditioned in fp32), so first
+    # overwrite them with this batch's statistics (momentum 1) as a trained model would have.
+    for bn in ref.modules():
+        if isinstance(bn, torch.nn.modules.batchnorm._BatchNorm):
+            bn.momentum = 1.0
+    with torch.no_grad():
+        ref(x)
+    prod.load_state_dict(ref.state_dict())
+    ref.eval(); prod.eval()
+    with torch.no_grad():
+        _cmp("eval logits", prod(x), ref(x), 1e-4, 1e-4)
