@@ -95,6 +95,52 @@ class BNL:
         pb.op(seg, "bn_bwd_apply", dtype=pb.code, M=M, C=self.C, g=gsrc, y=y, bn=self.buf, coef=self.coef, dy=dy)
 
 
+def op_cost(name, kw, es):
+    """(algorithmic HBM bytes, flops) of one launch: every operand tensor read or written once
+    (layer-granular compulsory traffic).  es = activation element size."""
+    g = kw.get
+    if name == "pw_fwd":
+        M, K, N = g("M"), g("K"), g("N")
+        return (M * K + M * N * (2 if g("residual") is not None else 1) + N * K) * es, 2 * M * K * N
+    if name == "pw_wgrad":
+        M, K, N = g("M"), g("K"), g("N")
+        return (M * K + M * N) * es + N * K * 4, 2 * M * K * N
+    if name == "conv_fwd":
+        frac = 1.0 / (g("os") * g("os"))
+        nin = g("N") * g("IH") * g("IW") * g("Cin") * frac
+        nout = g("N") * g("A") * g("B") * g("Cout")
+        return (nin + nout * (2 if g("residual") is not None else 1)) * es + g("Cout") * g("wtaps") * g("Cin") * es, \
+            2 * g("N") * g("A") * g("B") * g("ntaps") * g("Cin") * g("Cout")
+    if name == "conv_wgrad":
+        return (g("N") * g("IH") * g("IW") * g("Cin") + g("N") * g("OH") * g("OW") * g("Cout")) * es + g("Cout") * 9 * g("Cin") * 4, \
+            2 * g("N") * g("OH") * g("OW") * 9 * g("Cin") * g("Cout")
+    if name == "stem_fwd":
+        px = g("N") * g("OH") * g("OW")
+        return g("N") * 3 * g("H") * g("W") * 4 + px * g("Cout") * es, 2 * 27 * g("Cout") * px
+    if name == "stem_wgrad":
+        px = g("N") * g("OH") * g("OW")
+        return g("N") * 3 * g("H") * g("W") * 4 + px * g("Cout") * es, 2 * 27 * g("Cout") * px
+    if name == "dw_fwd":
+        nin = g("N") * g("T") * g("IH") * g("IW") * g("C")
+        nout = g("N") * g("T") * g("OH") * g("OW") * g("C")
+        return (nin + nout) * es, 2 * 9 * g("kt") * nout
+    if name == "dw_bwd":
+        nin = g("N") * g("T") * g("IH") * g("IW") * g("C")
+        nout = g("N") * g("T") * g("OH") * g("OW") * g("C")
+        return (2 * nin + nout) * es, 4 * 9 * g("kt") * nout
+    if name == "bn_res":
+        return g("M") * g("C") * es * (3 if g("shortcut") is not None else 2), 4 * g("M") * g("C")
+    if name in ("se_pool", "gem_fwd"):
+        return g("groups") * g("rows_per_group") * g("C") * es, 8 * g("groups") * g("rows_per_group") * g("C")
+    if name in ("se_bwd_reduce", "bn_bwd_reduce"):
+        n = g("M") * g("C") if name == "bn_bwd_reduce" else g("groups") * g("rows_per_group") * g("C")
+        return 2 * n * es, 10 * n
+    if name in ("bn_bwd_apply", "gem_bwd"):
+        n = g("M") * g("C") if name == "bn_bwd_apply" else g("groups") * g("rows_per_group") * g("C")
+        return 3 * n * es, 12 * n
+    return 0, 0
+
+
 def gsrc(mode, u, gate=None, dpooled=None, mask=None, rpg=0):
     return dict(_struct="mds_gsrc_t", mode=mode, u=u, gate=gate, dpooled=dpooled, mask=mask, rows_per_group=rpg)
 
@@ -113,6 +159,7 @@ class Plan:
         self.enc_grad = enc_grad and need_grad
         self.m = module
         self.in_flight = False
+        self.profile = None      # list -> run() brackets every launch with HIP events
         self._lazy: List[Lazy] = []
         self._zf, self._zb = 0, 0
         self.segs: Dict[str, list] = {"pack": [], "f2d": [], "f3d": [], "fhead": [], "bhead": [], "b3d": [], "b2d": []}
@@ -507,6 +554,7 @@ class Plan:
         self.param_ptrs = tuple(p.data_ptr() for p, *_ in self.pack_jobs)
         # bind every recorded launch
         self.bound: Dict[str, list] = {}
+        self.costs: Dict[str, list] = {}
         self._keep = []
         self.input_slots = []
         for seg, ops in self.segs.items():
@@ -518,6 +566,7 @@ class Plan:
                     self.input_slots.append((st, field))
                 out.append((name, self.lib.fn[name], st, C.byref(st)))
             self.bound[seg] = out
+            self.costs[seg] = [op_cost(name, kw, 2 if self.code == cabi.MDS_BF16 else 4) for name, kw in ops]
         self.nbytes = sum(l.tensor.numel() * l.tensor.element_size() for l in self._lazy)
 
     def _bind(self, struct_name, kw):
@@ -543,11 +592,25 @@ class Plan:
         return torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
 
     def run(self, seg):
+        if self.profile is not None:
+            return self._run_profiled(seg)
         stream = self._stream()
         for name, fn, st, ref in self.bound[seg]:
             rc = fn(ref, stream)
             if rc:
                 self.lib.check(rc, name)
+
+    def _run_profiled(self, seg):
+        """bench.py's per-kernel pass: a HIP event pair (on the launch stream) around every launch."""
+        stream = self._stream()
+        for (name, fn, st, ref), cost in zip(self.bound[seg], self.costs[seg]):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(ref, stream)
+            e1.record()
+            if rc:
+                self.lib.check(rc, name)
+            self.profile.append((name, seg, e0, e1, cost))
 
     def pack_weights(self):
         if self.pack_jobs:

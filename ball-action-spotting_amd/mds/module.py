@@ -61,6 +61,9 @@ class _MDSFunction(torch.autograd.Function):
         plan.begin_backward()
         plan.run("bhead"); plan.run("b3d"); plan.run("b2d")
         flat = plan.grad_arena.tensor.clone()      # one launch; the arena is reused next step
+        sync = getattr(ctx.module, "_grad_sync", None)
+        if sync is not None:
+            sync(flat)                             # data parallel: one RCCL all-reduce of the flat buffer
         grads = []
         for p in plan.params:
             if p.requires_grad:
@@ -108,6 +111,7 @@ class MultiDimStacker(nn.Module):
         self._cache = _PlanCache()
         self._lib: Optional[cabi.Lib] = None  # tests inject the kernel simulator here; product: cabi.load()
         self._mask_override = None            # parity tests: host-supplied DropPath/dropout masks
+        self._grad_sync = None                # mds.parallel.data_parallel installs the all-reduce here
 
     # ------------------------------------------------------------------ plumbing
     def _apply(self, fn, *a, **k):
