@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
   const int LDX = Cin + 2, LDY = CW_COT + 2;
   T* xs = (T*)smem;            // [TH*TW][LDX]
   T* dys = xs + TH * TW * LDX;  // [128][LDY]
+  float* flush = (float*)(dys + 128 * LDY);  // [16][Cin*wtaps] filter-gradient staging
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int co0 = blockIdx.y * CW_COT;
@@ -294,24 +295,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
       }
     }
   }
+  // flush: per 16-output-channel slab, transpose the accumulators through LDS into the parameter's
+  // OIHW order and add them with coalesced atomics (one L2 transaction per 16 lanes, not per lane)
+  const int slab = Cin * a.wtaps;  // floats per output channel
+  for (int cf = 0; cf < cofr; ++cf) {
+    __syncthreads();
 #pragma unroll
-  for (int tt = 0; tt < 3; ++tt) {
-    const int t = wave + 4 * tt;
-    if (t < a.ntaps) {
+    for (int tt = 0; tt < 3; ++tt) {
+      const int t = wave + 4 * tt;
+      if (t < a.ntaps) {
 #pragma unroll
-      for (int kf = 0; kf < 3; ++kf)
+        for (int kf = 0; kf < 3; ++kf) {
+          if (kf < cifr) {
 #pragma unroll
-        for (int cf = 0; cf < 4; ++cf) {
-          if (kf < cifr && cf < cofr) {
-            const int ci = 16 * kf + i;
+            for (int cfi = 0; cfi < 4; ++cfi) {
+              if (cfi == cf) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int co = co0 + 16 * cf + 4 * q + r;
-              atomicAdd(a.dw + ((long)co * Cin + ci) * a.wtaps + a.wi[t], acc[tt][kf][cf][r]);
+                for (int r = 0; r < 4; ++r)
+                  flush[(4 * q + r) * slab + (16 * kf + i) * a.wtaps + a.wi[t]] = acc[tt][kf][cfi][r];
+              }
             }
           }
         }
+      }
     }
+    __syncthreads();
+    float* dst = a.dw + (long)(co0 + 16 * cf) * slab;
+    for (int e = tid; e < 16 * slab; e += 256) atomicAdd(dst + e, flush[e]);
   }
 }
 
@@ -335,7 +345,8 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
   dim3 grid(cdiv(total, tpb), cot), block(256);
 #define CW_GO(T, PRO)                                                                                         \
   MDS_LAUNCH((conv_wgrad_kernel<T, PRO>), grid, block,                                                        \
-             (size_t)(TH * TW * (a->Cin + 2) + 128 * (CW_COT + 2)) * sizeof(T), stream, *a, dymin, dxmin, TH, TW, \
+             (size_t)(TH * TW * (a->Cin + 2) + 128 * (CW_COT + 2)) * sizeof(T) + (size_t)16 * a->Cin * a->wtaps * 4, \
+             stream, *a, dymin, dxmin, TH, TW, \
              tiles_a, tiles_b, tpb)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {

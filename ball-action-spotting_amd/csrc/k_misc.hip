@@ -122,89 +122,92 @@ extern "C" int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream
 }
 
 // ------------------------------------------------------------------ SE FCs
-#define SE_MAX_GR 4096  // groups * R held in LDS
-__global__ void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
-  __shared__ float hact[SE_MAX_GR];
-  const int G = a.groups, C = a.C, R = a.R;
-  for (int e = threadIdx.x; e < G * R; e += blockDim.x) {
-    int g = e / R, r = e % R;
-    float s = a.b1[r];
-    const float* w = a.w1 + (long)r * C;
-    const float* p = a.pooled + (long)g * C;
-    for (int c = 0; c < C; ++c) s += w[c] * p[c];
-    if (blockIdx.x == 0) a.hidden[e] = s;
-    hact[e] = siluf_(s);
-  }
-  __syncthreads();
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-    const float* w = a.w2 + (long)c * R;
-    for (int g = 0; g < G; ++g) {
-      float s = a.b2[c];
-      for (int r = 0; r < R; ++r) s += w[r] * hact[g * R + r];
-      a.gate[(long)g * C + c] = sigmoidf_(s);
-    }
-  }
+// Latency-class: groups <= 44, C <= 1152, R <= 48.  One wave per (group, r) dot product for the
+// C-long reductions (coalesced, wave_sum); one thread per (group, c) / per c for the R-long ones.
+__global__ void se_fc1_kernel(mds_se_fc_fwd_args a) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= a.groups * a.R) return;
+  const int g = e / a.R, r = e % a.R;
+  const float* w = a.w1 + (long)r * a.C;
+  const float* p = a.pooled + (long)g * a.C;
+  float s = 0.f;
+  for (int c = lane; c < a.C; c += MDS_WAVE) s += w[c] * p[c];
+  s = wave_sum(s);
+  if (lane == 0) a.hidden[e] = s + a.b1[r];
+}
+__global__ void se_fc2_kernel(mds_se_fc_fwd_args a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.groups * a.C) return;
+  const int g = e / a.C, c = e % a.C;
+  const float* w = a.w2 + (long)c * a.R;
+  const float* h = a.hidden + (long)g * a.R;
+  float s = a.b2[c];
+  for (int r = 0; r < a.R; ++r) s += w[r] * siluf_(h[r]);
+  a.gate[e] = sigmoidf_(s);
 }
 extern "C" int mds_se_fc_fwd(const mds_se_fc_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->R > 0, "se_fc_fwd: bad dims");
-  MDS_REQUIRE(a->groups * a->R <= SE_MAX_GR, "se_fc_fwd: groups*R=%d exceeds %d", a->groups * a->R, SE_MAX_GR);
-  MDS_LAUNCH(se_fc_fwd_kernel, dim3(cdiv(a->C, 256)), dim3(256), 0, stream, *a);
+  MDS_REQUIRE(a->pooled && a->w1 && a->b1 && a->w2 && a->b2 && a->hidden && a->gate, "se_fc_fwd: null pointer");
+  MDS_LAUNCH(se_fc1_kernel, dim3(cdiv(a->groups * a->R, 4)), dim3(256), 0, stream, *a);
+  MDS_LAUNCH(se_fc2_kernel, dim3(cdiv((long)a->groups * a->C, 256)), dim3(256), 0, stream, *a);
   return mds_check_launch("se_fc_fwd");
 }
 
-__global__ void se_fc_bwd_kernel(mds_se_fc_bwd_args a) {
-  __shared__ float dhpre[SE_MAX_GR];
-  __shared__ float hact[SE_MAX_GR];
-  const int G = a.groups, C = a.C, R = a.R;
-  // phase 1: dhpre[g][r] = silu'(hidden) * sum_c de[g][c] * w2[c][r],  de = dgate*gate*(1-gate)
-  for (int e = threadIdx.x; e < G * R; e += blockDim.x) {
-    int g = e / R, r = e % R;
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) {
-      float gt = a.gate[(long)g * C + c];
-      s += a.dgate[(long)g * C + c] * gt * (1.0f - gt) * a.w2[(long)c * R + r];
-    }
-    float h = a.hidden[e];
-    dhpre[e] = s * silu_gradf_(h);
-    hact[e] = siluf_(h);
+// dhpre[g][r] = silu'(hidden) * sum_c de[g][c] * w2[c][r],  de = dgate * gate * (1 - gate)
+__global__ void se_bwd1_kernel(mds_se_fc_bwd_args a) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= a.groups * a.R) return;
+  const int g = e / a.R, r = e % a.R;
+  float s = 0.f;
+  for (int c = lane; c < a.C; c += MDS_WAVE) {
+    const float gt = a.gate[(long)g * a.C + c];
+    s += a.dgate[(long)g * a.C + c] * gt * (1.0f - gt) * a.w2[(long)c * a.R + r];
   }
-  __syncthreads();
+  s = wave_sum(s);
+  if (lane == 0) a.scratch[e] = s * silu_gradf_(a.hidden[e]);
+}
+// dpooled[g][c] = sum_r dhpre[g][r] * w1[r][c] / rows        (thread per (g, c))
+__global__ void se_bwd2_kernel(mds_se_fc_bwd_args a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.groups * a.C) return;
+  const int g = e / a.C, c = e % a.C;
+  float dp = 0.f;
+  for (int r = 0; r < a.R; ++r) dp += a.scratch[g * a.R + r] * a.w1[(long)r * a.C + c];
+  a.dpooled[e] = dp / (float)a.rows_per_group;
+}
+// dw2[c][r], dw1[r][c] (thread per (r, c), c fastest); r == 0 threads also do db2[c]; block 0 db1
+__global__ void se_bwd3_kernel(mds_se_fc_bwd_args a) {
+  const int G = a.groups, C = a.C, R = a.R;
   if (blockIdx.x == 0) {
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
       float s = 0.f;
-      for (int g = 0; g < G; ++g) s += dhpre[g * R + r];
+      for (int g = 0; g < G; ++g) s += a.scratch[g * R + r];
       a.db1[r] += s;
     }
   }
-  const float invR = 1.0f / (float)a.rows_per_group;
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-    float db2 = 0.f;
-    for (int g = 0; g < G; ++g) {
-      float gt = a.gate[(long)g * C + c];
-      float de = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
-      db2 += de;
-      float dp = 0.f;
-      for (int r = 0; r < R; ++r) dp += dhpre[g * R + r] * a.w1[(long)r * C + c];
-      a.dpooled[(long)g * C + c] = dp * invR;
-    }
-    a.db2[c] += db2;
-    for (int r = 0; r < R; ++r) {
-      float s2 = 0.f, s1 = 0.f;
-      for (int g = 0; g < G; ++g) {
-        float gt = a.gate[(long)g * C + c];
-        float de = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
-        s2 += de * hact[g * R + r];
-        s1 += dhpre[g * R + r] * a.pooled[(long)g * C + c];
-      }
-      a.dw2[(long)c * R + r] += s2;
-      a.dw1[(long)r * C + c] += s1;
-    }
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= R * C) return;
+  const int r = e / C, c = e % C;
+  float s2 = 0.f, s1 = 0.f, db2 = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float gt = a.gate[(long)g * C + c];
+    const float de = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
+    db2 += de;
+    s2 += de * siluf_(a.hidden[g * R + r]);
+    s1 += a.scratch[g * R + r] * a.pooled[(long)g * C + c];
   }
+  a.dw2[(long)c * R + r] += s2;
+  a.dw1[(long)r * C + c] += s1;
+  if (r == 0) a.db2[c] += db2;
 }
 extern "C" int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->R > 0 && a->rows_per_group > 0, "se_fc_bwd: bad dims");
-  MDS_REQUIRE(a->groups * a->R <= SE_MAX_GR, "se_fc_bwd: groups*R too large");
-  MDS_LAUNCH(se_fc_bwd_kernel, dim3(cdiv(a->C, 256)), dim3(256), 0, stream, *a);
+  MDS_REQUIRE(a->scratch && a->dgate && a->gate && a->hidden && a->pooled && a->dpooled, "se_fc_bwd: null pointer");
+  MDS_LAUNCH(se_bwd1_kernel, dim3(cdiv(a->groups * a->R, 4)), dim3(256), 0, stream, *a);
+  MDS_LAUNCH(se_bwd2_kernel, dim3(cdiv((long)a->groups * a->C, 256)), dim3(256), 0, stream, *a);
+  MDS_LAUNCH(se_bwd3_kernel, dim3(cdiv((long)a->R * a->C, 256)), dim3(256), 0, stream, *a);
   return mds_check_launch("se_fc_bwd");
 }
 

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(mds_pw_fwd_args a) {
   // staging coordinates: 4 threads per row (8 k each), 64 rows per pass, 2 passes
   const int schunk = tid & 3, srow = tid >> 2;
 
-  for (int n0 = 0; n0 < N; n0 += PW_BNT) {
+  // n-tiles are spread over gridDim.y when there are too few row tiles to fill 256 CUs
+  for (int n0 = blockIdx.y * PW_BNT; n0 < N; n0 += gridDim.y * PW_BNT) {
     const int nfr = (N - n0 >= PW_BNT) ? 8 : ((N - n0) >> 4);
     f32x4 acc[2][8];
 #pragma unroll
@@ -163,7 +164,8 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->x && a->w && a->y, "pw_fwd: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "pw_fwd: prologue needs scale/shift");
   MDS_REQUIRE(a->pro.mode != MDS_PRO_BN_SILU_GATE || (a->pro.gate && a->pro.rows_per_group > 0), "pw_fwd: gate prologue");
-  dim3 grid(cdiv(a->M, PW_BM)), block(256);
+  const int mt = cdiv(a->M, PW_BM), nt = cdiv(a->N, PW_BNT);
+  dim3 grid(mt, (mt < 2048 && nt > 1) ? nt : 1), block(256);
 #define PW_GO(T, PRO) MDS_LAUNCH((pw_fwd_kernel<T, PRO>), grid, block, pw_fwd_smem<T>(a->K), stream, *a)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {

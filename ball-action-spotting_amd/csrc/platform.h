@@ -31,7 +31,17 @@ MDS_DEV bf16_t f2bf(float f) {  // round-to-nearest-even
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
-MDS_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// SiLU/sigmoid run on every element of every activation tensor (several times, because the
+// normalised tensor is never materialised): hardware v_exp_f32 / v_rcp_f32 (~1 ulp) instead of
+// the multi-instruction libm expansions.
+#ifndef MDS_EMU
+MDS_DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+MDS_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+MDS_DEV float fast_exp(float x) { return expf(x); }
+MDS_DEV float fast_rcp(float x) { return 1.0f / x; }
+#endif
+MDS_DEV float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 MDS_DEV float siluf_(float x) { return x * sigmoidf_(x); }
 // d silu(z)/dz
 MDS_DEV float silu_gradf_(float z) { float s = sigmoidf_(z); return s * (1.0f + z * (1.0f - s)); }

@@ -358,7 +358,7 @@ class Plan:
                       self.grad(se.conv_expand.bias)]
             self.op(seg, "se_fc_bwd", groups=groups, C=mid, R=R, rows_per_group=rpg, dgate=dgate, gate=gate, hidden=hidden,
                     pooled=pooled, w1=P(se.conv_reduce.weight), w2=P(se.conv_expand.weight), dpooled=dpool,
-                    dw1=sg[0], db1=sg[1], dw2=sg[2], db2=sg[3])
+                    scratch=self.f32(groups * R), dw1=sg[0], db1=sg[1], dw2=sg[2], db2=sg[3])
             dy2 = self.act(Mout, mid)
             bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, frozen=frozen)
             g1 = self.act(Min, mid)

@@ -274,6 +274,7 @@ typedef struct {
   const float* w1;
   const float* w2;
   float* dpooled; /* [groups][C] */
+  float* scratch; /* [groups][R] workspace (grad of the hidden pre-activations) */
   float* dw1;     /* [R][C] */
   float* db1;
   float* dw2;     /* [C][R] */

@@ -110,7 +110,7 @@ def test_se_forward_backward(be, dt):
     dw2 = torch.zeros(C, RD, device=be.device); db2 = torch.zeros(C, device=be.device)
     be.call("se_fc_bwd", cabi.make("mds_se_fc_bwd_args", groups=G, C=C, R=RD, rows_per_group=R_, dgate=dgate,
                                    gate=gate, hidden=hidden, pooled=pooled, w1=w1d, w2=w2d, dpooled=dpooled,
-                                   dw1=dw1, db1=db1, dw2=dw2, db2=db2))
+                                   scratch=torch.empty(G, RD, device=be.device), dw1=dw1, db1=db1, dw2=dw2, db2=db2))
     be.sync()
     assert_close(pooled, pooled_ref, dt, msg="pooled")
     assert_close(gate, gate_ref, dt, msg="gate")

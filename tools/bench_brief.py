@@ -1,0 +1,13 @@
+import json,sys
+for line in sys.stdin:
+    line=line.strip()
+    if line.startswith('{"metric"'):
+        d=json.loads(line)
+        print("value", d["value"], "ms/step", d["ms_per_step"], "mem", d["peak_mem_GB"], "loss", d["loss"])
+        print("roofline", {k:v for k,v in d["roofline"].items() if k!="whole_path"})
+        tot=0
+        for k,v in d["kernel_breakdown"].items():
+            tot+=v["ms_per_step"]; print(f'  {k:16s} {v["ms_per_step"]:8.3f} ms  n={v["launches_per_step"]:3d}  {v["GBps"]:8.1f} GB/s {v["TFLOPs"]:7.2f} TF')
+        print("  total kernel ms", round(tot,2))
+        if d.get("cpu_baseline"): print("cpu", d["cpu_baseline"])
+    elif line: print(line[:300])
