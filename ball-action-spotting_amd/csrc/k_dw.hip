@@ -1,60 +1,44 @@
 // k_dw.hip — depthwise 3x3 (2D, stride 1 / TF-SAME stride 2) and 3x3x3 (3D) convolutions.
 //
-// HBM-bound VALU kernels (9 or 27 MACs per element).  A thread owns V channels (one 16-byte
-// vector in the forward, one 8/16-byte vector in the backward) of a 4-pixel strip; filter taps
-// sit transposed in LDS ([tap][C]) and are read as broadcast vectors; the producer's BN+SiLU is
-// applied while loading (zero padding after it); input vectors are consumed one at a time so the
-// live register set stays small enough for 3-4 waves per SIMD (latency hiding is occupancy here);
-// BatchNorm sums of the output are accumulated in registers, then one LDS reduction + one atomic
-// per channel per block.
+// HBM-bound VALU kernels (9 or 27 MACs per element); what limits them in practice is memory
+// latency, so both directions are LDS-tiled: a block owns an 8x16 pixel patch of a 128-byte
+// channel slab (64 bf16 / 32 fp32 channels), issues ALL global loads of the patch (+halo) back to
+// back (clamped addresses, masked afterwards), applies the producer's BN+SiLU once per element on
+// the way into LDS (zero padding after the activation), and then computes out of LDS.  For the
+// 3x3x3 case the block walks the T slices with a 3-slot ring, so every input slice is read once.
+// Filter taps sit in LDS ([tap][slab]); BatchNorm sums and filter gradients are reduced with wave
+// shuffles + LDS, then written with coalesced atomics in the parameter's own order.
+#include <stdlib.h>
 #include "elem.h"
 
-#define DW_WS 4  // output (fwd) / input (bwd) pixels per thread along W
+template <typename T> struct DwCfg { static const int CC = 128 / sizeof(T); };  // channels per slab
 
-// ---- V-wide channel vectors
-template <int V> struct Vec;
-template <> struct Vec<8> {
-  template <typename T> static MDS_DEV void ld(const T* p, float (&v)[8]) { load8(p, v); }
-  template <typename T> static MDS_DEV void st(T* p, const float (&v)[8]) { store8(p, v); }
-};
-template <> struct Vec<4> {
-  template <typename T> static MDS_DEV void ld(const T* p, float (&v)[4]) { load4(p, v); }
-  template <typename T> static MDS_DEV void st(T* p, const float (&v)[4]) { store4(p, v); }
-};
-
-template <int V>
-struct VMap {  // like RowMap, for a channel span [cbeg, cbeg + span) walked V channels per thread
-  int cpr, rpb, chunk, rsub, c0;
-  bool valid;
-};
-template <int V>
-MDS_DEV VMap<V> vmap(int cbeg, int span) {
-  VMap<V> m;
-  m.cpr = span / V;
-  m.rpb = 256 / m.cpr;
-  m.chunk = threadIdx.x % m.cpr;
-  m.rsub = threadIdx.x / m.cpr;
-  m.valid = m.rsub < m.rpb;
-  m.c0 = cbeg + m.chunk * V;
-  return m;
-}
-template <int NV, int V>
-MDS_DEV void block_reduce_v(float (&acc)[NV][V], const VMap<V>& m, float* red) {
-  __syncthreads();
-  if (m.valid) {
+// ---- raw (storage-typed) V-channel vectors: loaded first, converted when consumed
+template <typename T, int V> struct Raw;
+template <int V> struct Raw<bf16_t, V> {
+  typedef unsigned short vt __attribute__((ext_vector_type(V)));
+  vt v;
+  MDS_DEV void ld(const bf16_t* p) { v = *(const vt*)p; }
+  MDS_DEV void get(float (&o)[V]) const {
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-      for (int j = 0; j < V; ++j) red[((m.rsub * NV + v) * m.cpr + m.chunk) * V + j] = acc[v][j];
+    for (int j = 0; j < V; ++j) o[j] = bf2f(v[j]);
   }
-  __syncthreads();
-  if (m.valid && m.rsub == 0) {
-    for (int r = 1; r < m.rpb; ++r)
+};
+template <int V> struct Raw<float, V> {
+  f32x4 v[V / 4];
+  MDS_DEV void ld(const float* p) {
 #pragma unroll
-      for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[v][j] += red[((r * NV + v) * m.cpr + m.chunk) * V + j];
+    for (int k = 0; k < V / 4; ++k) v[k] = *(const f32x4*)(p + 4 * k);
   }
+  MDS_DEV void get(float (&o)[V]) const {
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = v[j >> 2][j & 3];
+  }
+};
+template <typename T, int V>
+MDS_DEV void stv(T* p, const float (&v)[V]) {
+  if (V == 8) store8(p, (const float(&)[8])v);
+  else store4(p, (const float(&)[4])v);
 }
 template <int V>
 MDS_DEV void ldv(const float* p, float (&v)[V]) {
@@ -64,304 +48,432 @@ MDS_DEV void ldv(const float* p, float (&v)[V]) {
     v[j] = a[0]; v[j + 1] = a[1]; v[j + 2] = a[2]; v[j + 3] = a[3];
   }
 }
+MDS_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// sum over the lanes of a wave that share (lane % NCH)
+template <int NCH>
+MDS_DEV float sum_same_chunk(float v) {
+#pragma unroll
+  for (int m = NCH; m < 64; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
 
 // ------------------------------------------------------------------------------------ forward
-template <typename T, int S>
-__global__ __launch_bounds__(256, 3) void dw_fwd_kernel(mds_dw_fwd_args a) {
-  const int V = 8;
+template <typename T, int S, int KT>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(mds_dw_fwd_args a, int nchunks, int tpb) {
+  constexpr int V = 8, CC = DwCfg<T>::CC, NCH = CC / V, NPT = 256 / NCH;
+  constexpr int TOH = 8, TOW = 16, WS = TOH * TOW / NPT, NSTR = TOW / WS;
+  constexpr int TH = (TOH - 1) * S + 3, TW = (TOW - 1) * S + 3, NPIX = TH * TW;
+  constexpr int MAXL = (NPIX * NCH + 255) / 256;
+  constexpr int NSEG = (WS - 1) * S + 3, NTAP = KT * 9;
   MDS_DYN_SMEM(smem);
-  float* wl = (float*)smem;          // [ntap][C]
-  float* red = wl + a.kt * 9 * a.C;  // [256*8*2]
-  const int C = a.C, ntap = a.kt * 9;
-  for (int e = threadIdx.x; e < ntap * C; e += 256) {
-    int t = e / C, c = e - t * C;
-    wl[e] = a.w[(long)c * ntap + t];
+  T* tile = (T*)smem;                             // [KT][NPIX][CC]
+  float* wl = (float*)(tile + KT * NPIX * CC);    // [NTAP][CC]
+  float* st_l = wl + NTAP * CC;                   // [2][CC]
+  const int tid = threadIdx.x, ch = tid % NCH, pt = tid / NCH;
+  const int C = a.C;
+  const int cz = blockIdx.z % nchunks, n = blockIdx.z / nchunks;
+  const int cbeg = cz * CC, c0 = cbeg + ch * V;
+  const bool cvalid = c0 < C;
+  const int oy0 = blockIdx.y * TOH;
+  const int iy0 = oy0 * S - a.pad_t;
+  int ox0 = 0, ix0 = 0;  // set per tile: a block walks `tpb` consecutive tiles along W
+  for (int e = tid; e < NTAP * CC; e += 256) {
+    const int t = e / CC, c = e - t * CC;
+    wl[e] = (cbeg + c < C) ? a.w[(long)(cbeg + c) * NTAP + t] : 0.f;
   }
-  const VMap<V> m = vmap<V>(0, C);
-  const int c0 = m.c0;
+  if (tid < 2 * CC) st_l[tid] = 0.f;
   const int mode = a.pro.mode;
   float sc[V], sh[V];
-  if (m.valid && mode != MDS_PRO_NONE) { ldv<V>(a.pro.scale + c0, sc); ldv<V>(a.pro.shift + c0, sh); }
-  __syncthreads();
+  if (cvalid && mode != MDS_PRO_NONE) { ldv<V>(a.pro.scale + c0, sc); ldv<V>(a.pro.shift + c0, sh); }
+  const T* x = (const T*)a.x;
+  T* y = (T*)a.y;
+  const int r = pt / NSTR, sx = pt % NSTR;
   float st[2][V];
 #pragma unroll
   for (int j = 0; j < V; ++j) { st[0][j] = 0.f; st[1][j] = 0.f; }
-  const int strips_w = (a.OW + DW_WS - 1) / DW_WS;
-  const long nstrips = (long)a.N * a.T * a.OH * strips_w;
-  const T* x = (const T*)a.x;
-  T* y = (T*)a.y;
-  const int tpad = a.kt == 3 ? 1 : 0;
-  const int NSEG = (DW_WS - 1) * S + 3;
-  if (m.valid) {
-    for (long sidx = (long)blockIdx.x * m.rpb + m.rsub; sidx < nstrips; sidx += (long)gridDim.x * m.rpb) {
-      const int sw = (int)(sidx % strips_w);
-      long r = sidx / strips_w;
-      const int oy = (int)(r % a.OH); r /= a.OH;
-      const int ot = (int)(r % a.T);
-      const int n = (int)(r / a.T);
-      const int ox0 = sw * DW_WS;
-      float acc[DW_WS][V];
+
+  auto load_slice = [&](int it, int slot) {
+    const T* plane = x + ((long)(n * a.T + it) * a.IH * a.IW) * C + (cvalid ? c0 : 0);
+    T* dst = tile + (long)slot * NPIX * CC + ch * V;
+    Raw<T, V> raw[MAXL];
 #pragma unroll
-      for (int o = 0; o < DW_WS; ++o)
+    for (int l = 0; l < MAXL; ++l) {
+      const int pix = pt + NPT * l;
+      const int ty = pix / TW, tx = pix - ty * TW;
+      if (pix < NPIX)
+        raw[l].ld(plane + ((long)clampi(iy0 + ty, 0, a.IH - 1) * a.IW + clampi(ix0 + tx, 0, a.IW - 1)) * C);
+    }
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[o][j] = 0.f;
-      for (int dt = 0; dt < a.kt; ++dt) {
-        const int it = ot + dt - tpad;
-        if (it < 0 || it >= a.T) continue;
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = oy * S + ky - a.pad_t;
-          if (iy < 0 || iy >= a.IH) continue;
-          const T* xrow = x + (((long)(n * a.T + it) * a.IH + iy) * a.IW) * C + c0;
-          float w3[3][V];
+    for (int l = 0; l < MAXL; ++l) {
+      const int pix = pt + NPT * l;
+      const int ty = pix / TW, tx = pix - ty * TW;
+      if (pix < NPIX) {
+        const int iy = iy0 + ty, ix = ix0 + tx;
+        const bool ok = cvalid && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        float v[V];
+        raw[l].get(v);
+        if (mode != MDS_PRO_NONE) {
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) ldv<V>(wl + ((dt * 3 + ky) * 3 + kx) * C + c0, w3[kx]);
+          for (int j = 0; j < V; ++j) {
+            float z = v[j] * sc[j] + sh[j];
+            v[j] = (mode == MDS_PRO_AFFINE) ? z : siluf_(z);
+          }
+        }
 #pragma unroll
-          for (int s = 0; s < NSEG; ++s) {
-            const int ix = ox0 * S - a.pad_l + s;
-            if (ix < 0 || ix >= a.IW) continue;  // zero padding (after the activation)
-            float v[V];
-            Vec<V>::ld(xrow + (long)ix * C, v);
-            if (mode != MDS_PRO_NONE) {
+        for (int j = 0; j < V; ++j) v[j] = ok ? v[j] : 0.f;  // zero padding AFTER the activation
+        stv<T, V>(dst + (long)pix * CC, v);
+      }
+    }
+  };
+
+  auto compute = [&](int ot) {
+    float acc[WS][V];
 #pragma unroll
-              for (int j = 0; j < V; ++j) {
-                float z = v[j] * sc[j] + sh[j];
-                v[j] = (mode == MDS_PRO_AFFINE) ? z : siluf_(z);
-              }
-            }
+    for (int o = 0; o < WS; ++o)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              if ((s - kx) >= 0 && ((s - kx) % S) == 0 && (s - kx) / S < DW_WS) {
-                const int o = (s - kx) / S;
+      for (int j = 0; j < V; ++j) acc[o][j] = 0.f;
 #pragma unroll
-                for (int j = 0; j < V; ++j) acc[o][j] += v[j] * w3[kx][j];
-              }
+    for (int dt = 0; dt < KT; ++dt) {
+      const int it = ot + dt - (KT == 3 ? 1 : 0);
+      if (it < 0 || it >= a.T) continue;
+      const T* src = tile + (long)(KT == 3 ? (it % 3) : 0) * NPIX * CC + ch * V;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        float w3[3][V];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) ldv<V>(wl + ((dt * 3 + ky) * 3 + kx) * CC + ch * V, w3[kx]);
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+          Raw<T, V> rv;
+          rv.ld(src + (long)((r * S + ky) * TW + sx * WS * S + s) * CC);
+          float v[V];
+          rv.get(v);
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            if ((s - kx) >= 0 && ((s - kx) % S) == 0 && (s - kx) / S < WS) {
+              const int o = (s - kx) / S;
+#pragma unroll
+              for (int j = 0; j < V; ++j) acc[o][j] += v[j] * w3[kx][j];
             }
           }
         }
       }
+    }
+    const int oy = oy0 + r;
+    if (cvalid && oy < a.OH) {
       T* yrow = y + (((long)(n * a.T + ot) * a.OH + oy) * a.OW) * C + c0;
 #pragma unroll
-      for (int o = 0; o < DW_WS; ++o) {
-        if (ox0 + o < a.OW) {
-          Vec<V>::st(yrow + (long)(ox0 + o) * C, acc[o]);
+      for (int o = 0; o < WS; ++o) {
+        const int ox = ox0 + sx * WS + o;
+        if (ox < a.OW) {
+          stv<T, V>(yrow + (long)ox * C, acc[o]);
 #pragma unroll
           for (int j = 0; j < V; ++j) { st[0][j] += acc[o][j]; st[1][j] += acc[o][j] * acc[o][j]; }
         }
       }
     }
+  };
+
+  for (int tt = 0; tt < tpb; ++tt) {
+    ox0 = (blockIdx.x * tpb + tt) * TOW;
+    if (ox0 >= a.OW) break;
+    ix0 = ox0 * S - a.pad_l;
+    if (KT == 3) {
+      load_slice(0, 0);
+      for (int ot = 0; ot < a.T; ++ot) {
+        if (ot + 1 < a.T) load_slice(ot + 1, (ot + 1) % 3);
+        __syncthreads();
+        compute(ot);
+        __syncthreads();
+      }
+    } else {
+      for (int ot = 0; ot < a.T; ++ot) {
+        load_slice(ot, 0);
+        __syncthreads();
+        compute(ot);
+        __syncthreads();
+      }
+    }
   }
   if (a.stats) {
-    block_reduce_v<2, V>(st, m, red);
-    if (m.valid && m.rsub == 0) {
-      float* sp = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * C;
 #pragma unroll
-      for (int j = 0; j < V; ++j) { atomicAdd(sp + c0 + j, st[0][j]); atomicAdd(sp + C + c0 + j, st[1][j]); }
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float s = sum_same_chunk<NCH>(st[k][j]);
+        if ((tid & 63) < NCH) atomicAdd(&st_l[k * CC + ch * V + j], s);
+      }
+    __syncthreads();
+    if (tid < 2 * CC) {
+      const int k = tid / CC, c = tid - k * CC;
+      if (cbeg + c < C) {
+        const int slot = (blockIdx.x + blockIdx.y * gridDim.x + n * 5) % MDS_STAT_SLOTS;
+        atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, st_l[tid]);
+      }
     }
   }
 }
 
-static int dw_blocks(long nstrips, int rows_pp, int cap) {
-  long b = (nstrips + rows_pp - 1) / rows_pp;
-  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
-}
-
 extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
-  MDS_REQUIRE(a && a->N > 0 && a->T > 0 && a->C % 8 == 0 && a->C <= 2048, "dw_fwd: bad dims");
+  MDS_REQUIRE(a && a->N > 0 && a->T > 0 && a->C % 8 == 0, "dw_fwd: bad dims");
   MDS_REQUIRE(a->kt == 1 || a->kt == 3, "dw_fwd: kt must be 1 or 3");
   MDS_REQUIRE(a->stride == 1 || a->stride == 2, "dw_fwd: stride");
+  MDS_REQUIRE(!(a->kt == 3 && a->stride == 2), "dw_fwd: 3x3x3 is stride 1 only");
+  MDS_REQUIRE(a->kt == 3 || a->T >= 1, "dw_fwd: T");
   MDS_REQUIRE(a->x && a->w && a->y, "dw_fwd: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "dw_fwd: prologue");
   MDS_REQUIRE(a->pro.mode != MDS_PRO_BN_SILU_GATE, "dw_fwd: gate prologue unsupported");
-  const long nstrips = (long)a->N * a->T * a->OH * ((a->OW + DW_WS - 1) / DW_WS);
-  const size_t smem = ((size_t)a->kt * 9 * a->C + 256 * 8 * 2) * sizeof(float);
-  dim3 grid(dw_blocks(nstrips, rows_per_pass(a->C), 2048)), block(256);
+  MDS_REQUIRE((long)a->N * 64 < 65536, "dw_fwd: grid.z");
   MDS_DISPATCH_DTYPE(a->dtype, T, {
-    if (a->stride == 1) MDS_LAUNCH((dw_fwd_kernel<T, 1>), grid, block, smem, stream, *a);
-    else MDS_LAUNCH((dw_fwd_kernel<T, 2>), grid, block, smem, stream, *a);
+    const int CC = DwCfg<T>::CC;
+    const int nchunks = cdiv(a->C, CC);
+    const int tiles_x = cdiv(a->OW, 16), tpb = 1;  // forward: parallelism beats amortisation
+    dim3 grid(cdiv(tiles_x, tpb), cdiv(a->OH, 8), a->N * nchunks), block(256);
+    const int S = a->stride, TH = 7 * S + 3, TW = 15 * S + 3;
+    const size_t smem = (size_t)a->kt * TH * TW * CC * sizeof(T) + ((size_t)a->kt * 9 * CC + 2 * CC) * sizeof(float);
+    if (a->kt == 3) MDS_LAUNCH((dw_fwd_kernel<T, 1, 3>), grid, block, smem, stream, *a, nchunks, tpb);
+    else if (S == 1) MDS_LAUNCH((dw_fwd_kernel<T, 1, 1>), grid, block, smem, stream, *a, nchunks, tpb);
+    else MDS_LAUNCH((dw_fwd_kernel<T, 2, 1>), grid, block, smem, stream, *a, nchunks, tpb);
   });
   return mds_check_launch("dw_fwd");
 }
 
 // ------------------------------------------------------------------------------------ backward
-// Thread owns 4 channels of a 4-pixel strip of the INPUT.  Outputs g = (dgrad) * silu'(z) (the
-// gradient wrt the BN output of the producing 1x1 conv), the BN-backward sums of g, and the
-// filter gradient (9 x 4 register accumulators).  blockIdx.y splits the channels when C/4 > 256.
-// For the 3x3x3 case the strip loop runs once per temporal tap for the filter gradient
-// (the 3D tensors are small: 4x5x23x40x576).
-template <typename T, int S, int PL>
-__global__ __launch_bounds__(256, 3) void dw_bwd_kernel(mds_dw_bwd_args a, int span) {
-  const int V = 4;
+// Block = 8x16 INPUT pixels of a channel slab; thread = 4 channels x strip(s) of 4 pixels.
+// Produces g = (dgrad) * silu'(z) (gradient wrt the BN output of the producing 1x1 conv), the
+// BN-backward sums of g, and the filter gradient.  dy (+halo) is staged raw in LDS; x needs no
+// halo and stays in registers.
+template <typename T, int S, int PL, int KT>
+__global__ __launch_bounds__(256) void dw_bwd_kernel(mds_dw_bwd_args a, int nchunks, int tpb) {
+  constexpr int V = 4, CC = DwCfg<T>::CC, NCH = CC / V, NPT = 256 / NCH;
+  constexpr int TIH = 8, TIW = 16, SPT = (TIH * TIW / 4) / NPT;  // strips of 4 pixels per thread
+  constexpr int DTH = (S == 1) ? TIH + 2 : TIH / 2 + 2, DTW = (S == 1) ? TIW + 2 : TIW / 2 + 2, DNPIX = DTH * DTW;
+  constexpr int MAXL = (DNPIX * NCH + 255) / 256;
+  constexpr int NSEG = (S == 1) ? 6 : 4, NTAP = KT * 9;
   MDS_DYN_SMEM(smem);
-  const int C = a.C, ntap = a.kt * 9;
-  const int cbeg = blockIdx.y * span;
-  float* wl = (float*)smem;        // [ntap][span]
-  float* red = wl + ntap * span;   // [256*4*3]
-  float* dwt = red + 256 * 4 * 3;  // [span][9] filter-gradient staging
-  for (int e = threadIdx.x; e < ntap * span; e += 256) {
-    int t = e / span, c = e - t * span;
-    wl[e] = a.w[(long)(cbeg + c) * ntap + t];
+  T* dyt = (T*)smem;                             // [KT][DNPIX][CC]
+  float* wl = (float*)(dyt + KT * DNPIX * CC);   // [NTAP][CC]
+  float* dwl = wl + NTAP * CC;                   // [CC][NTAP]
+  float* st_l = dwl + NTAP * CC;                 // [2][CC]
+  const int tid = threadIdx.x, ch = tid % NCH, pt = tid / NCH;
+  const int C = a.C;
+  const int cz = blockIdx.z % nchunks, n = blockIdx.z / nchunks;
+  const int cbeg = cz * CC, c0 = cbeg + ch * V;
+  const bool cvalid = c0 < C;
+  const int iy0 = blockIdx.y * TIH;
+  const int oy_lo = iy0 / S - 1;
+  int ix0 = 0, ox_lo = 0;  // set per tile: a block walks `tpb` consecutive tiles along W
+  for (int e = tid; e < NTAP * CC; e += 256) {
+    const int t = e / CC, c = e - t * CC;
+    wl[e] = (cbeg + c < C) ? a.w[(long)(cbeg + c) * NTAP + t] : 0.f;
+    dwl[e] = 0.f;
   }
-  const VMap<V> m = vmap<V>(cbeg, span);
-  const int c0 = m.c0, cl = m.chunk * V;
+  if (tid < 2 * CC) st_l[tid] = 0.f;
   float sc[V], sh[V], mu[V], rs[V];
-  if (m.valid) {
+  if (cvalid) {
     ldv<V>(a.pro.scale + c0, sc); ldv<V>(a.pro.shift + c0, sh);
     ldv<V>(a.mean + c0, mu); ldv<V>(a.rstd + c0, rs);
   }
-  __syncthreads();
-  const int strips_w = (a.IW + DW_WS - 1) / DW_WS;
-  const long nstrips = (long)a.N * a.T * a.IH * strips_w;
   const T* x = (const T*)a.x;
   const T* dy = (const T*)a.dy;
   T* g = (T*)a.g;
-  const int tpad = a.kt == 3 ? 1 : 0;
-  const int NSEG = (S == 1) ? DW_WS + 2 : DW_WS / 2 + 2;  // dy columns touching the strip
-  float st[2][V];
+  float st[2][V], dwacc[NTAP][V];
 #pragma unroll
   for (int j = 0; j < V; ++j) { st[0][j] = 0.f; st[1][j] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int j = 0; j < V; ++j) dwacc[t][j] = 0.f;
 
-  for (int dtw = 0; dtw < a.kt; ++dtw) {
-    float dwacc[9][V];
+  auto load_slice = [&](int ot, int slot) {
+    const T* plane = dy + ((long)(n * a.T + ot) * a.OH * a.OW) * C + (cvalid ? c0 : 0);
+    T* dst = dyt + (long)slot * DNPIX * CC + ch * V;
+    Raw<T, V> raw[MAXL];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int l = 0; l < MAXL; ++l) {
+      const int pix = pt + NPT * l;
+      const int ty = pix / DTW, tx = pix - ty * DTW;
+      if (pix < DNPIX)
+        raw[l].ld(plane + ((long)clampi(oy_lo + ty, 0, a.OH - 1) * a.OW + clampi(ox_lo + tx, 0, a.OW - 1)) * C);
+    }
 #pragma unroll
-      for (int j = 0; j < V; ++j) dwacc[t][j] = 0.f;
-    if (m.valid) {
-      for (long sidx = (long)blockIdx.x * m.rpb + m.rsub; sidx < nstrips; sidx += (long)gridDim.x * m.rpb) {
-        const int sw = (int)(sidx % strips_w);
-        long r = sidx / strips_w;
-        const int iy = (int)(r % a.IH); r /= a.IH;
-        const int it = (int)(r % a.T);
-        const int n = (int)(r / a.T);
-        const int ix0 = sw * DW_WS;
-        float xv[DW_WS][V], act[DW_WS][V], da[DW_WS][V];
-        const T* xrow = x + (((long)(n * a.T + it) * a.IH + iy) * a.IW) * C + c0;
+    for (int l = 0; l < MAXL; ++l) {
+      const int pix = pt + NPT * l;
+      const int ty = pix / DTW, tx = pix - ty * DTW;
+      if (pix < DNPIX) {
+        const int oy = oy_lo + ty, ox = ox_lo + tx;
+        const bool ok = cvalid && oy >= 0 && oy < a.OH && ox >= 0 && ox < a.OW;
+        float v[V];
+        raw[l].get(v);
 #pragma unroll
-        for (int o = 0; o < DW_WS; ++o) {
-          if (ix0 + o < a.IW) {
-            Vec<V>::ld(xrow + (long)(ix0 + o) * C, xv[o]);
+        for (int j = 0; j < V; ++j) v[j] = ok ? v[j] : 0.f;
+        stv<T, V>(dst + (long)pix * CC, v);
+      }
+    }
+  };
+
+  auto compute = [&](int it, const Raw<T, V> (&xraw)[SPT][4]) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) act[o][j] = siluf_(xv[o][j] * sc[j] + sh[j]);
-          } else {
+    for (int sp = 0; sp < SPT; ++sp) {
+      const int sid = pt + NPT * sp, r = sid / 4, sx = sid % 4;
+      const int iy = iy0 + r, ixb = ix0 + 4 * sx;
+      float xv[4][V], act[4][V], da[4][V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) { xv[o][j] = 0.f; act[o][j] = 0.f; }
-          }
+      for (int o = 0; o < 4; ++o) {
+        const bool ok = cvalid && iy < a.IH && ixb + o < a.IW;
+        xraw[sp][o].get(xv[o]);
 #pragma unroll
-          for (int j = 0; j < V; ++j) da[o][j] = 0.f;
+        for (int j = 0; j < V; ++j) {
+          act[o][j] = ok ? siluf_(xv[o][j] * sc[j] + sh[j]) : 0.f;
+          da[o][j] = 0.f;
         }
-        for (int dt = 0; dt < a.kt; ++dt) {
-          const bool do_da = (dtw == 0), do_dw = (dt == dtw);
-          if (!do_da && !do_dw) continue;
-          const int ot = it - dt + tpad;
-          if (ot < 0 || ot >= a.T) continue;
-          for (int ky = 0; ky < 3; ++ky) {
-            const int num = iy + a.pad_t - ky;
-            if (num < 0 || (num % S) != 0) continue;
-            const int oy = num / S;
-            if (oy >= a.OH) continue;
-            const T* drow = dy + (((long)(n * a.T + ot) * a.OH + oy) * a.OW) * C + c0;
-            const int seg_lo = (S == 1) ? (ix0 + PL - 2) : (ix0 / 2 - 1);
-            float w3[3][V];
+      }
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) ldv<V>(wl + ((dt * 3 + ky) * 3 + kx) * span + cl, w3[kx]);
+      for (int dt = 0; dt < KT; ++dt) {
+        const int ot = it - dt + (KT == 3 ? 1 : 0);
+        if (ot < 0 || ot >= a.T) continue;
+        const T* src = dyt + (long)(KT == 3 ? (ot % 3) : 0) * DNPIX * CC + ch * V;
 #pragma unroll
-            for (int s = 0; s < NSEG; ++s) {
-              const int ox = seg_lo + s;
-              if (ox < 0 || ox >= a.OW) continue;
-              float v[V];
-              Vec<V>::ld(drow + (long)ox * C, v);
+        for (int ky = 0; ky < 3; ++ky) {
+          const int num = iy + a.pad_t - ky;
+          const int oy = num / S;
+          if (num < 0 || (num % S) != 0 || oy >= a.OH) continue;
+          const int trow = oy - oy_lo;
+          float w3[3][V];
 #pragma unroll
-              for (int kx = 0; kx < 3; ++kx)
+          for (int kx = 0; kx < 3; ++kx) ldv<V>(wl + ((dt * 3 + ky) * 3 + kx) * CC + ch * V, w3[kx]);
 #pragma unroll
-                for (int o = 0; o < DW_WS; ++o) {
-                  // ox = (ix0 + o + PL - kx) / S must be an integer equal to seg_lo + s (ix0 % 4 == 0)
-                  const bool hit = (S == 1) ? ((o - kx + 2) == s)
-                                            : ((((o + PL - kx) % 2) == 0) && (((o + PL - kx + 2) / 2) == s));
-                  if (hit) {
-                    if (do_da) {
+          for (int s = 0; s < NSEG; ++s) {
+            // dy column ox = seg_lo + s, seg_lo = ixb + PL - 2 (S=1) | ixb/2 - 1 (S=2); tile col = ox - ox_lo
+            const int tcol = (S == 1) ? (4 * sx + PL - 1 + s) : (2 * sx + s);
+            Raw<T, V> rv;
+            rv.ld(src + (long)(trow * DTW + tcol) * CC);
+            float v[V];
+            rv.get(v);
 #pragma unroll
-                      for (int j = 0; j < V; ++j) da[o][j] += v[j] * w3[kx][j];
-                    }
-                    if (do_dw) {
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                      for (int j = 0; j < V; ++j) dwacc[ky * 3 + kx][j] += v[j] * act[o][j];
-                    }
+              for (int o = 0; o < 4; ++o) {
+                const bool hit = (S == 1) ? ((o - kx + 2) == s)
+                                          : ((((o + PL - kx) % 2) == 0) && (((o + PL - kx + 2) / 2) == s));
+                if (hit) {
+#pragma unroll
+                  for (int j = 0; j < V; ++j) {
+                    da[o][j] += v[j] * w3[kx][j];
+                    dwacc[(dt * 3 + ky) * 3 + kx][j] += v[j] * act[o][j];
                   }
                 }
-            }
-          }
-        }
-        if (dtw == 0) {
-          T* grow = g + (((long)(n * a.T + it) * a.IH + iy) * a.IW) * C + c0;
-#pragma unroll
-          for (int o = 0; o < DW_WS; ++o) {
-            if (ix0 + o < a.IW) {
-              float gv[V];
-#pragma unroll
-              for (int j = 0; j < V; ++j) {
-                gv[j] = da[o][j] * silu_gradf_(xv[o][j] * sc[j] + sh[j]);
-                st[0][j] += gv[j];
-                st[1][j] += gv[j] * ((xv[o][j] - mu[j]) * rs[j]);
               }
-              Vec<V>::st(grow + (long)(ix0 + o) * C, gv);
+          }
+        }
+      }
+      if (cvalid && iy < a.IH) {
+        T* grow = g + (((long)(n * a.T + it) * a.IH + iy) * a.IW) * C + c0;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          if (ixb + o < a.IW) {
+            float gv[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+              gv[j] = da[o][j] * silu_gradf_(xv[o][j] * sc[j] + sh[j]);
+              st[0][j] += gv[j];
+              st[1][j] += gv[j] * ((xv[o][j] - mu[j]) * rs[j]);
             }
+            stv<T, V>(grow + (long)(ixb + o) * C, gv);
           }
         }
       }
     }
-    // flush this temporal tap's 9 filter-gradient rows: block-reduce, transpose through LDS into
-    // the parameter's [C][kt*9] order, then coalesced atomics (uncoalesced ones cost one L2
-    // transaction per lane and dominated this kernel)
+  };
+
+  auto load_x = [&](int it, Raw<T, V> (&xraw)[SPT][4]) {
+    const T* plane = x + ((long)(n * a.T + it) * a.IH * a.IW) * C + (cvalid ? c0 : 0);
 #pragma unroll
-    for (int rnd = 0; rnd < 3; ++rnd) {
-      float part[3][V];
+    for (int sp = 0; sp < SPT; ++sp) {
+      const int sid = pt + NPT * sp, r = sid / 4, sx = sid % 4;
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int j = 0; j < V; ++j) part[t][j] = dwacc[rnd * 3 + t][j];
-      block_reduce_v<3, V>(part, m, red);
-      if (m.valid && m.rsub == 0) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int j = 0; j < V; ++j) dwt[(cl + j) * 9 + rnd * 3 + t] = part[t][j];
+      for (int o = 0; o < 4; ++o)
+        xraw[sp][o].ld(plane + ((long)clampi(iy0 + r, 0, a.IH - 1) * a.IW + clampi(ix0 + 4 * sx + o, 0, a.IW - 1)) * C);
+    }
+  };
+
+  for (int tt = 0; tt < tpb; ++tt) {
+    ix0 = (blockIdx.x * tpb + tt) * TIW;
+    if (ix0 >= a.IW) break;
+    ox_lo = ix0 / S - 1;
+    if (KT == 3) {
+      load_slice(0, 0);
+      for (int it = 0; it < a.T; ++it) {
+        Raw<T, V> xraw[SPT][4];
+        load_x(it, xraw);
+        if (it + 1 < a.T) load_slice(it + 1, (it + 1) % 3);
+        __syncthreads();
+        compute(it, xraw);
+        __syncthreads();
+      }
+    } else {
+      for (int it = 0; it < a.T; ++it) {
+        Raw<T, V> xraw[SPT][4];
+        load_x(it, xraw);
+        load_slice(it, 0);
+        __syncthreads();
+        compute(it, xraw);
+        __syncthreads();
       }
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < span * 9; e += 256) {
-      const int c = e / 9, t = e - c * 9;
-      atomicAdd(a.dw + (long)(cbeg + c) * ntap + dtw * 9 + t, dwt[e]);
-    }
-    __syncthreads();
   }
-  block_reduce_v<2, V>(st, m, red);
-  if (m.valid && m.rsub == 0) {
-    float* sp = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * C;
+  // reductions: same-chunk lanes of the wave by shuffles, then LDS, then coalesced global atomics
 #pragma unroll
-    for (int j = 0; j < V; ++j) { atomicAdd(sp + c0 + j, st[0][j]); atomicAdd(sp + C + c0 + j, st[1][j]); }
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float s = sum_same_chunk<NCH>(dwacc[t][j]);
+      if ((tid & 63) < NCH) atomicAdd(&dwl[(ch * V + j) * NTAP + t], s);
+    }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float s = sum_same_chunk<NCH>(st[k][j]);
+      if ((tid & 63) < NCH) atomicAdd(&st_l[k * CC + ch * V + j], s);
+    }
+  __syncthreads();
+  for (int e = tid; e < NTAP * CC; e += 256) {
+    if (cbeg + e / NTAP < C) atomicAdd(a.dw + (long)cbeg * NTAP + e, dwl[e]);
+  }
+  if (tid < 2 * CC) {
+    const int k = tid / CC, c = tid - k * CC;
+    if (cbeg + c < C) {
+      const int slot = (blockIdx.x + blockIdx.y * gridDim.x + n * 5) % MDS_STAT_SLOTS;
+      atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, st_l[tid]);
+    }
   }
 }
 
 extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
-  MDS_REQUIRE(a && a->N > 0 && a->T > 0 && a->C % 8 == 0 && a->C <= 2048, "dw_bwd: bad dims");
+  MDS_REQUIRE(a && a->N > 0 && a->T > 0 && a->C % 8 == 0, "dw_bwd: bad dims");
   MDS_REQUIRE(a->kt == 1 || a->kt == 3, "dw_bwd: kt must be 1 or 3");
   MDS_REQUIRE(a->stride == 1 || a->stride == 2, "dw_bwd: stride");
+  MDS_REQUIRE(!(a->kt == 3 && a->stride == 2), "dw_bwd: 3x3x3 is stride 1 only");
   MDS_REQUIRE(a->x && a->dy && a->w && a->g && a->dw && a->stats && a->mean && a->rstd, "dw_bwd: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_BN_SILU && a->pro.scale && a->pro.shift, "dw_bwd: needs the BN+SiLU prologue of the forward");
-  MDS_REQUIRE(a->stride == 2 ? (a->pad_l == 0 || a->pad_l == 1) : (a->pad_l == 1), "dw_bwd: pad_l=%d unsupported for stride %d", a->pad_l, a->stride);
-  int nsplit = 1;
-  while (a->C / (4 * nsplit) > 256 || a->C % (4 * nsplit) != 0) {
-    ++nsplit;
-    MDS_REQUIRE(nsplit <= 8, "dw_bwd: cannot split C=%d", a->C);
-  }
-  const int span = a->C / nsplit;
-  const long nstrips = (long)a->N * a->T * a->IH * ((a->IW + DW_WS - 1) / DW_WS);
-  const size_t smem = ((size_t)a->kt * 9 * span + 256 * 4 * 3 + 9 * span) * sizeof(float);
-  dim3 grid(dw_blocks(nstrips, 256 / (span / 4), 512 / nsplit), nsplit), block(256);
+  MDS_REQUIRE(a->stride == 2 ? (a->pad_l == 0 || a->pad_l == 1) : (a->pad_l == 1 && a->pad_t == 1), "dw_bwd: pad=(%d,%d) unsupported for stride %d", a->pad_t, a->pad_l, a->stride);
+  MDS_REQUIRE((long)a->N * 64 < 65536, "dw_bwd: grid.z");
   MDS_DISPATCH_DTYPE(a->dtype, T, {
-    if (a->stride == 1) MDS_LAUNCH((dw_bwd_kernel<T, 1, 1>), grid, block, smem, stream, *a, span);
-    else if (a->pad_l == 0) MDS_LAUNCH((dw_bwd_kernel<T, 2, 0>), grid, block, smem, stream, *a, span);
-    else MDS_LAUNCH((dw_bwd_kernel<T, 2, 1>), grid, block, smem, stream, *a, span);
+    const int CC = DwCfg<T>::CC;
+    const int nchunks = cdiv(a->C, CC);
+    const int tiles_x = cdiv(a->IW, 16);
+    // the per-block fixed cost (tap staging, 36-value wave reductions, atomics) is amortised over a
+    // whole row band in 2D (measured: 342 -> 215 us at 46x80x672); 3D blocks already walk T slices
+    int tpb = a->kt == 3 ? 2 : (tiles_x < 8 ? tiles_x : 8);
+    if (getenv("MDS_DW_TPB")) tpb = atoi(getenv("MDS_DW_TPB"));
+    dim3 grid(cdiv(tiles_x, tpb), cdiv(a->IH, 8), a->N * nchunks), block(256);
+    const int dnpix = a->stride == 1 ? 10 * 18 : 6 * 10;
+    const size_t smem = (size_t)a->kt * dnpix * CC * sizeof(T) + ((size_t)2 * a->kt * 9 * CC + 2 * CC) * sizeof(float);
+    if (a->kt == 3) MDS_LAUNCH((dw_bwd_kernel<T, 1, 1, 3>), grid, block, smem, stream, *a, nchunks, tpb);
+    else if (a->stride == 1) MDS_LAUNCH((dw_bwd_kernel<T, 1, 1, 1>), grid, block, smem, stream, *a, nchunks, tpb);
+    else if (a->pad_l == 0) MDS_LAUNCH((dw_bwd_kernel<T, 2, 0, 1>), grid, block, smem, stream, *a, nchunks, tpb);
+    else MDS_LAUNCH((dw_bwd_kernel<T, 2, 1, 1>), grid, block, smem, stream, *a, nchunks, tpb);
   });
   return mds_check_launch("dw_bwd");
 }

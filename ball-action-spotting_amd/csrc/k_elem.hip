@@ -54,11 +54,13 @@ __global__ void se_pool_kernel(mds_se_pool_args a) {
     load8f(a.scale + c0, sc);
     load8f(a.shift + c0, sh);
     const T* y = (const T*)a.y + (long)blockIdx.y * a.rows_per_group * a.C;
+    T* act = a.act ? (T*)a.act + (long)blockIdx.y * a.rows_per_group * a.C : (T*)0;
     for (long r = (long)blockIdx.x * m.rpb + m.rsub; r < a.rows_per_group; r += (long)gridDim.x * m.rpb) {
       float v[8];
       load8(y + r * a.C + c0, v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[0][j] += siluf_(v[j] * sc[j] + sh[j]);
+      for (int j = 0; j < 8; ++j) { v[j] = siluf_(v[j] * sc[j] + sh[j]); acc[0][j] += v[j]; }
+      if (act) store8(act + r * a.C + c0, v);
     }
   }
   block_reduce_rows<1>(acc, m, red);
@@ -86,8 +88,8 @@ __global__ void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
   float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
   if (m.valid) {
     float sc[8], sh[8];
-    load8f(a.scale + c0, sc);
-    load8f(a.shift + c0, sh);
+    const bool raw = a.scale != 0;  // raw conv output: re-apply BN+SiLU; else y IS the activation
+    if (raw) { load8f(a.scale + c0, sc); load8f(a.shift + c0, sh); }
     const long base = (long)blockIdx.y * a.rows_per_group * a.C;
     const T* y = (const T*)a.y + base;
     const T* u = (const T*)a.u + base;
@@ -95,8 +97,12 @@ __global__ void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
       float v[8], uu[8];
       load8(y + r * a.C + c0, v);
       load8(u + r * a.C + c0, uu);
+      if (raw) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[0][j] += uu[j] * siluf_(v[j] * sc[j] + sh[j]);
+        for (int j = 0; j < 8; ++j) v[j] = siluf_(v[j] * sc[j] + sh[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[0][j] += uu[j] * v[j];
     }
   }
   block_reduce_rows<1>(acc, m, red);

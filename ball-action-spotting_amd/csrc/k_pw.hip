@@ -4,116 +4,180 @@
 //   mds_pw_wgrad : dw[N][K] += dy[M][N]^T * pro(x)[M][K]
 //
 // Roofline: these GEMMs are skinny (K, N <= 1152, M up to 4.7 M rows): bytes/row = 2(K+N),
-// flops/row = 2KN -> 25..165 FLOP/B, below the 312 FLOP/B ridge of MI355X, i.e. HBM-bound; the
-// design goal is one pass over x and y with 16-byte accesses and MFMA work hidden behind it.
+// flops/row = 2KN -> 25..165 FLOP/B, below the 312 FLOP/B ridge of MI355X, i.e. HBM-bound IF the
+// MFMA side sustains ~1 PFLOP/s; with K this short the kernel is really latency/issue bound, so:
+//   * 128x128 block tile, 2x2 waves of 64x64 (16 accumulator fragments, 8 LDS fragment reads per
+//     16 MFMAs), K staged 256 bytes per row at a time (128 bf16 / 64 fp32) -> 4 k-steps per barrier;
+//   * every global load of a K-chunk is issued at once into raw registers, and the NEXT chunk's
+//     loads are in flight while the current chunk's MFMAs run (register software pipeline);
+//   * LDS row pitch 272 B: the 16 rows of a fragment read land on 16 distinct 16-byte bank groups.
 #include "gemm.h"
 
-#define PW_BM 128   // rows per block tile
-#define PW_BNT 128  // output channels per n-tile (8 MFMA column fragments)
+#define PW_BM 128
+#define PW_BN 128
+
+template <typename T> struct PwCfg;
+template <> struct PwCfg<bf16_t> { static const int KC = 128, LD = 136; };
+template <> struct PwCfg<float> { static const int KC = 64, LD = 68; };
+
+template <typename T> struct RawV8;   // 8 consecutive elements as loaded (no conversion yet)
+template <> struct RawV8<bf16_t> {
+  u16x8 v;
+  MDS_DEV void ld(const bf16_t* p) { v = *(const u16x8*)p; }
+  MDS_DEV void zero() { v = (u16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
+  MDS_DEV void get(float (&o)[8]) const {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bf2f(v[j]);
+  }
+  MDS_DEV void st(bf16_t* p) const { *(u16x8*)p = v; }
+};
+template <> struct RawV8<float> {
+  f32x4 a, b;
+  MDS_DEV void ld(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+  MDS_DEV void zero() { a = (f32x4){0, 0, 0, 0}; b = a; }
+  MDS_DEV void get(float (&o)[8]) const {
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  }
+  MDS_DEV void st(float* p) const { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
+};
+
+// reduce-scatter of 16 per-lane partials over the 16 lanes sharing q; returns the entry index
+MDS_DEV int reduce_scatter16(float (&vals)[16], int i) {
+  int e0 = 0;
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int half = 8 >> step, mask = 8 >> step;
+    const bool bit = (i & mask) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      float lo = vals[k], hi = vals[k + half];
+      float send = bit ? lo : hi;
+      float keep = bit ? hi : lo;
+      vals[k] = keep + __shfl_xor(send, mask);
+    }
+    if (bit) e0 += half;
+  }
+  return e0;
+}
 
 template <typename T, int PRO>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(mds_pw_fwd_args a) {
   typedef typename Frag<T>::type frag_t;
-  const int LD = PwLd<T>::v;
+  constexpr int KC = PwCfg<T>::KC, LD = PwCfg<T>::LD, VPR = KC / 8, RPP = 256 / VPR, NL = PW_BM / RPP;
   MDS_DYN_SMEM(smem);
-  T* xs = (T*)smem;                         // [PW_BM][LD]
-  T* ws = xs + PW_BM * LD;                  // [PW_BNT][LD]
-  float* psc = (float*)(ws + PW_BNT * LD);  // [Kpad] scale
-  const int Kpad = (a.K + 31) & ~31;
-  float* psh = psc + Kpad;                  // [Kpad] shift
-  float* st_s = psh + Kpad;                 // [PW_BNT]
-  float* st_ss = st_s + PW_BNT;             // [PW_BNT]
+  T* xs = (T*)smem;                          // [PW_BM][LD]
+  T* ws = xs + PW_BM * LD;                   // [PW_BN][LD]
+  float* st_s = (float*)(ws + PW_BN * LD);   // [PW_BN]
+  float* st_ss = st_s + PW_BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
   const long m0 = (long)blockIdx.x * PW_BM;
   const int K = a.K, N = a.N;
   const T* x = (const T*)a.x;
   const T* w = (const T*)a.w;
   T* y = (T*)a.y;
-
-  if (PRO != MDS_PRO_NONE) {
-    for (int k = tid; k < Kpad; k += 256) {
-      psc[k] = k < K ? a.pro.scale[k] : 0.f;
-      psh[k] = k < K ? a.pro.shift[k] : 0.f;
+  const int svec = tid % VPR, srow = tid / VPR;  // staging: this thread's k-offset and first row
+  int grow[NL];  // squeeze-excite gate row of each staged row (one division per row per block)
+  if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const long m = m0 + srow + RPP * l;
+      grow[l] = (int)((m < a.M ? m : a.M - 1) / a.pro.rows_per_group);
     }
   }
-  // staging coordinates: 4 threads per row (8 k each), 64 rows per pass, 2 passes
-  const int schunk = tid & 3, srow = tid >> 2;
 
-  // n-tiles are spread over gridDim.y when there are too few row tiles to fill 256 CUs
-  for (int n0 = blockIdx.y * PW_BNT; n0 < N; n0 += gridDim.y * PW_BNT) {
-    const int nfr = (N - n0 >= PW_BNT) ? 8 : ((N - n0) >> 4);
-    f32x4 acc[2][8];
+  for (int n0 = blockIdx.y * PW_BN; n0 < N; n0 += gridDim.y * PW_BN) {
+    int nfr = (N - n0 - 64 * wn) >> 4;  // valid 16-column fragments of this wave
+    nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+    for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-      for (int nf = 0; nf < 8; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.stats && tid < PW_BNT) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
+      for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.stats && tid < PW_BN) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
 
-    for (int k0 = 0; k0 < K; k0 += PW_KC) {
-      __syncthreads();  // previous step's fragment reads done (also orders psc/psh, st_* init)
-      const int kk = k0 + 8 * schunk;
+    RawV8<T> rx[NL], rw[NL];
+    auto issue = [&](int kc) {  // all global loads of one K-chunk
+      const int kk = kc + 8 * svec;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int r = srow + 64 * p;
+      for (int l = 0; l < NL; ++l) {
+        const int r = srow + RPP * l;
         const long m = m0 + r;
-        float v[8];
-        if (m < a.M && kk < K) {
-          load8(x + m * K + kk, v);
-          if (PRO != MDS_PRO_NONE) {
+        if (m < a.M && kk < K) rx[l].ld(x + m * K + kk); else rx[l].zero();
+        const int n = n0 + r;
+        if (n < N && kk < K) rw[l].ld(w + (long)n * K + kk); else rw[l].zero();
+      }
+    };
+    issue(0);
+    for (int kc = 0; kc < K; kc += KC) {
+      const int kk = kc + 8 * svec;
+      __syncthreads();  // previous chunk's fragment reads are done
+      if (PRO == MDS_PRO_NONE) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float z = v[j] * psc[kk + j] + psh[kk + j];
-              v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+        for (int l = 0; l < NL; ++l) rx[l].st(xs + (srow + RPP * l) * LD + 8 * svec);
+      } else {
+        float sc[8], sh[8];
+        if (PRO != MDS_PRO_GATE && kk < K) { load8f(a.pro.scale + kk, sc); load8f(a.pro.shift + kk, sh); }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          const int r = srow + RPP * l;
+          const long m = m0 + r;
+          float v[8];
+          rx[l].get(v);
+          if (m < a.M && kk < K) {
+            if (PRO != MDS_PRO_GATE) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                float z = v[j] * sc[j] + sh[j];
+                v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+              }
             }
-            if (PRO == MDS_PRO_BN_SILU_GATE) {
+            if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
               float g[8];
-              load8f(a.pro.gate + (m / a.pro.rows_per_group) * K + kk, g);
+              load8f(a.pro.gate + (long)grow[l] * K + kk, g);
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] *= g[j];
             }
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          store8(xs + r * LD + 8 * svec, v);
         }
-        store8(xs + r * LD + 8 * schunk, v);
-        // weights: rows n0 + r
-        const int n = n0 + r;
-        if (n < N && kk < K) {
-          load8(w + (long)n * K + kk, v);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        }
-        store8(ws + r * LD + 8 * schunk, v);
       }
+#pragma unroll
+      for (int l = 0; l < NL; ++l) rw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
       __syncthreads();
-      frag_t xf[2];
+      if (kc + KC < K) issue(kc + KC);  // in flight while the MFMAs below run
+      const int ksteps = (K - kc >= KC) ? KC / 32 : ((K - kc + 31) >> 5);
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf) xf[mf] = ld_frag(xs + (32 * wave + 16 * mf + i) * LD + 8 * q);
+      for (int ks = 0; ks < KC / 32; ++ks) {
+        if (ks < ksteps) {
+          frag_t xf[4];
 #pragma unroll
-      for (int nf = 0; nf < 8; ++nf) {
-        if (nf < nfr) {
-          frag_t wf = ld_frag(ws + (16 * nf + i) * LD + 8 * q);
-          mma16(wf, xf[0], acc[0][nf]);  // acc[r] = y[m = i][n = 4q + r]
-          mma16(wf, xf[1], acc[1][nf]);
+          for (int mf = 0; mf < 4; ++mf) xf[mf] = ld_frag(xs + (64 * wm + 16 * mf + i) * LD + 32 * ks + 8 * q);
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) {
+            if (nf < nfr) {
+              frag_t wf = ld_frag(ws + (64 * wn + 16 * nf + i) * LD + 32 * ks + 8 * q);
+#pragma unroll
+              for (int mf = 0; mf < 4; ++mf) mma16(wf, xf[mf], acc[mf][nf]);  // acc[r] = y[m = i][n = 4q + r]
+            }
+          }
         }
       }
     }
 
     // ---- epilogue: residual, store, statistics
-    float part_s[32], part_ss[32];
+    float ps[16], pss[16];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) { part_s[e] = 0.f; part_ss[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-      const long m = m0 + 32 * wave + 16 * mf + i;
+    for (int mf = 0; mf < 4; ++mf) {
+      const long m = m0 + 64 * wm + 16 * mf + i;
 #pragma unroll
-      for (int nf = 0; nf < 8; ++nf) {
+      for (int nf = 0; nf < 4; ++nf) {
         if (nf < nfr) {
-          const int n = n0 + 16 * nf + 4 * q;
+          const int n = n0 + 64 * wn + 16 * nf + 4 * q;
           float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
           if (m < a.M) {
             if (a.residual) {
@@ -125,25 +189,18 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(mds_pw_fwd_args a) {
             store4(y + m * N + n, v);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            part_s[nf * 4 + r] += v[r];
-            part_ss[nf * 4 + r] += v[r] * v[r];
-          }
+          for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[r]; pss[nf * 4 + r] += v[r] * v[r]; }
         }
       }
     }
     if (a.stats) {
-      int e0 = reduce_scatter32(part_s, i);
-      reduce_scatter32(part_ss, i);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int e = e0 + t;
-        const int nl = 16 * (e >> 2) + 4 * q + (e & 3);
-        atomicAdd(&st_s[nl], part_s[t]);
-        atomicAdd(&st_ss[nl], part_ss[t]);
-      }
+      const int e = reduce_scatter16(ps, i);
+      reduce_scatter16(pss, i);
+      const int nl = 64 * wn + 16 * (e >> 2) + 4 * q + (e & 3);
+      atomicAdd(&st_s[nl], ps[0]);
+      atomicAdd(&st_ss[nl], pss[0]);
       __syncthreads();
-      if (tid < PW_BNT && n0 + tid < N) {
+      if (tid < PW_BN && n0 + tid < N) {
         float* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * N;
         atomicAdd(st + n0 + tid, st_s[tid]);
         atomicAdd(st + N + n0 + tid, st_ss[tid]);
@@ -152,27 +209,25 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(mds_pw_fwd_args a) {
   }
 }
 
-template <typename T>
-static size_t pw_fwd_smem(int K) {
-  int Kpad = (K + 31) & ~31;
-  return (size_t)(PW_BM + PW_BNT) * PwLd<T>::v * sizeof(T) + (size_t)(2 * Kpad + 2 * PW_BNT) * sizeof(float);
-}
-
 extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_fwd: bad dims");
   MDS_REQUIRE(a->K % 8 == 0 && a->N % 16 == 0, "pw_fwd: K=%d must be a multiple of 8, N=%d of 16", a->K, a->N);
   MDS_REQUIRE(a->x && a->w && a->y, "pw_fwd: null pointer");
-  MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "pw_fwd: prologue needs scale/shift");
-  MDS_REQUIRE(a->pro.mode != MDS_PRO_BN_SILU_GATE || (a->pro.gate && a->pro.rows_per_group > 0), "pw_fwd: gate prologue");
-  const int mt = cdiv(a->M, PW_BM), nt = cdiv(a->N, PW_BNT);
-  dim3 grid(mt, (mt < 2048 && nt > 1) ? nt : 1), block(256);
-#define PW_GO(T, PRO) MDS_LAUNCH((pw_fwd_kernel<T, PRO>), grid, block, pw_fwd_smem<T>(a->K), stream, *a)
+  MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || (a->pro.scale && a->pro.shift), "pw_fwd: prologue needs scale/shift");
+  MDS_REQUIRE((a->pro.mode != MDS_PRO_BN_SILU_GATE && a->pro.mode != MDS_PRO_GATE) || (a->pro.gate && a->pro.rows_per_group > 0), "pw_fwd: gate prologue");
+  const int mt = cdiv(a->M, PW_BM), nt = cdiv(a->N, PW_BN);
+  int gy = 1;
+  if (nt > 1) { gy = cdiv(1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
+  dim3 grid(mt, gy), block(256);
+#define PW_GO(T, PRO) \
+  MDS_LAUNCH((pw_fwd_kernel<T, PRO>), grid, block, (size_t)(PW_BM + PW_BN) * PwCfg<T>::LD * sizeof(T) + 2 * PW_BN * sizeof(float), stream, *a)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: PW_GO(T, MDS_PRO_NONE); break;
       case MDS_PRO_AFFINE: PW_GO(T, MDS_PRO_AFFINE); break;
       case MDS_PRO_BN_SILU: PW_GO(T, MDS_PRO_BN_SILU); break;
       case MDS_PRO_BN_SILU_GATE: PW_GO(T, MDS_PRO_BN_SILU_GATE); break;
+      case MDS_PRO_GATE: PW_GO(T, MDS_PRO_GATE); break;
       default: mds_set_error("pw_fwd: prologue mode %d", a->pro.mode); return MDS_ERR_BAD_ARG;
     }
   });
@@ -209,7 +264,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(mds_pw_wgrad_args a, int 
   const int yc = tid & 15, yr = tid >> 4;
   float sc[8], sh[8];
   const int kx = kt0 + 8 * xc;
-  if (PRO != MDS_PRO_NONE && kx < K) { load8f(a.pro.scale + kx, sc); load8f(a.pro.shift + kx, sh); }
+  if (PRO != MDS_PRO_NONE && PRO != MDS_PRO_GATE && kx < K) { load8f(a.pro.scale + kx, sc); load8f(a.pro.shift + kx, sh); }
 
   f32x4 acc[2][4];  // wave owns n-fragments {2*wave, 2*wave+1} x 4 k-fragments
 #pragma unroll
@@ -227,14 +282,16 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(mds_pw_wgrad_args a, int 
       if (m < mend && kx < K) {
         load8(x + m * K + kx, v);
         if (PRO != MDS_PRO_NONE) {
+          if (PRO != MDS_PRO_GATE) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float z = v[j] * sc[j] + sh[j];
-            v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+            for (int j = 0; j < 8; ++j) {
+              float z = v[j] * sc[j] + sh[j];
+              v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+            }
           }
-          if (PRO == MDS_PRO_BN_SILU_GATE) {
+          if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
             float g[8];
-            load8f(a.pro.gate + (m / a.pro.rows_per_group) * K + kx, g);
+            load8f(a.pro.gate + (long)((unsigned)m / (unsigned)a.pro.rows_per_group) * K + kx, g);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] *= g[j];
           }
@@ -295,8 +352,9 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_wgrad: bad dims");
   MDS_REQUIRE(a->K % 8 == 0 && a->N % 8 == 0, "pw_wgrad: K, N must be multiples of 8");
   MDS_REQUIRE(a->x && a->dy && a->dw, "pw_wgrad: null pointer");
-  MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "pw_wgrad: prologue needs scale/shift");
-  MDS_REQUIRE(a->pro.mode != MDS_PRO_BN_SILU_GATE || (a->pro.gate && a->pro.rows_per_group > 0), "pw_wgrad: gate prologue");
+  MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || (a->pro.scale && a->pro.shift), "pw_wgrad: prologue needs scale/shift");
+  MDS_REQUIRE((a->pro.mode != MDS_PRO_BN_SILU_GATE && a->pro.mode != MDS_PRO_GATE) || (a->pro.gate && a->pro.rows_per_group > 0), "pw_wgrad: gate prologue");
+  MDS_REQUIRE(a->M < 2147483647L, "pw_wgrad: M too large");
   const int tiles = cdiv(a->N, WG_NT) * cdiv(a->K, WG_KT);
   long want_blocks = 1024 / tiles;
   if (want_blocks < 1) want_blocks = 1;
@@ -311,6 +369,7 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
       case MDS_PRO_AFFINE: WG_GO(T, MDS_PRO_AFFINE); break;
       case MDS_PRO_BN_SILU: WG_GO(T, MDS_PRO_BN_SILU); break;
       case MDS_PRO_BN_SILU_GATE: WG_GO(T, MDS_PRO_BN_SILU_GATE); break;
+      case MDS_PRO_GATE: WG_GO(T, MDS_PRO_GATE); break;
       default: mds_set_error("pw_wgrad: prologue mode %d", a->pro.mode); return MDS_ERR_BAD_ARG;
     }
   });

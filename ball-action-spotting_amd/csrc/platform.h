@@ -26,11 +26,16 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 MDS_DEV float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 MDS_DEV uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 MDS_DEV float bf2f(bf16_t v) { return bits2f((uint32_t)v << 16); }
+#ifndef MDS_EMU
+// round-to-nearest-even in hardware: pairs of these fold into one v_cvt_pk_bf16_f32
+MDS_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+#else
 MDS_DEV bf16_t f2bf(float f) {  // round-to-nearest-even
   uint32_t u = f2bits(f);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+#endif
 // SiLU/sigmoid run on every element of every activation tensor (several times, because the
 // normalised tensor is never materialised): hardware v_exp_f32 / v_rcp_f32 (~1 ulp) instead of
 // the multi-instruction libm expansions.

@@ -26,7 +26,7 @@ import torch
 from . import cabi, geometry as geo
 from .cabi import MDS_STAT_SLOTS as SLOTS
 
-PRO_NONE, PRO_AFFINE, PRO_BN_SILU, PRO_GATE = 0, 1, 2, 3
+PRO_NONE, PRO_AFFINE, PRO_BN_SILU, PRO_BN_GATE, PRO_GATE = 0, 1, 2, 3, 4
 G_PLAIN, G_SILU, G_SE, G_MASK = 0, 1, 2, 3
 
 
@@ -131,7 +131,8 @@ def op_cost(name, kw, es):
     if name == "bn_res":
         return g("M") * g("C") * es * (3 if g("shortcut") is not None else 2), 4 * g("M") * g("C")
     if name in ("se_pool", "gem_fwd"):
-        return g("groups") * g("rows_per_group") * g("C") * es, 8 * g("groups") * g("rows_per_group") * g("C")
+        n = g("groups") * g("rows_per_group") * g("C")
+        return n * es * (2 if g("act") is not None else 1), 8 * n
     if name in ("se_bwd_reduce", "bn_bwd_reduce"):
         n = g("M") * g("C") if name == "bn_bwd_reduce" else g("groups") * g("rows_per_group") * g("C")
         return 2 * n * es, 10 * n
@@ -332,12 +333,14 @@ class Plan:
         bn2.finalize(self, fseg)
         R = blk.se.rd
         pooled, hidden, gate = self.zero_fwd(groups * mid), self.f32(groups * R), self.f32(groups * mid)
+        a2 = self.act(Mout, mid)   # silu(bn2(y2)), written by the pooling pass it shares its reads with
         self.op(fseg, "se_pool", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, y=y2, scale=bn2.scale,
-                shift=bn2.shift, pooled=pooled)
+                shift=bn2.shift, pooled=pooled, act=a2)
+        gate_pro = dict(mode=PRO_GATE, scale=None, shift=None, gate=gate, rows_per_group=rpg)
         se = blk.se
         self.op(fseg, "se_fc_fwd", groups=groups, C=mid, R=R, pooled=pooled, w1=P(se.conv_reduce.weight),
                 b1=P(se.conv_reduce.bias), w2=P(se.conv_expand.weight), b2=P(se.conv_expand.bias), hidden=hidden, gate=gate)
-        y3 = self._pw(fseg, y2, Mout, mid, cout, blk.conv_pwl.weight, pro=bn2.pro(PRO_GATE, gate, rpg), stats_bn=bn3)
+        y3 = self._pw(fseg, a2, Mout, mid, cout, blk.conv_pwl.weight, pro=gate_pro, stats_bn=bn3)
         mask = self.mask(groups, blk.dpr) if has_skip else None
         xout = self.act(Mout, cout)
         self.op(fseg, "bn_res", dtype=self.code, M=Mout, C=cout, y=y3, scale=bn3.scale, shift=bn3.shift, act=0, mask=mask,
@@ -347,10 +350,10 @@ class Plan:
             g3 = gsrc(G_MASK, dout, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout)
             dy3 = self.act(Mout, cout)
             bn3.backward(self, seg, g3, y3, dy3, frozen=frozen)
-            u2 = self._pw_bwd(seg, y2, bn2.pro(PRO_GATE, gate, rpg), Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen)
+            u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen)
             dgate, dpool = self.zero_bwd(groups * mid), self.f32(groups * mid)
-            self.op(seg, "se_bwd_reduce", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, u=u2, y=y2,
-                    scale=bn2.scale, shift=bn2.shift, dgate=dgate)
+            self.op(seg, "se_bwd_reduce", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, u=u2, y=a2,
+                    scale=None, shift=None, dgate=dgate)
             if frozen:
                 sg = [self.f32(se.conv_reduce.weight.numel()), self.f32(R), self.f32(se.conv_expand.weight.numel()), self.f32(mid)]
             else:

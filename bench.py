@@ -141,7 +141,7 @@ def main():
     assert torch.isfinite(loss).item(), "non-finite loss"
 
     # ---- per-kernel pass: HIP event pairs around every launch (on the launch stream)
-    roofline, breakdown = None, None
+    roofline, breakdown, top_launches = None, None, None
     if rank == 0 and args.profile_steps > 0:
         plan = next(p for pool in model._cache.plans.values() for p in pool if p.kind == "full" and p.need_grad)
         plan.profile = []
@@ -153,6 +153,11 @@ def main():
             key = name + (".bwd" if seg.startswith("b") and name in ("pw_fwd", "conv_fwd") else "")
             a = agg.setdefault(key, [0.0, 0, 0.0, 0.0])
             a[0] += e0.elapsed_time(e1); a[1] += 1; a[2] += nbytes; a[3] += flops
+        top = sorted(plan.profile, key=lambda r: -r[2].elapsed_time(r[3]))[:30]
+        top_launches = [{"kernel": r[0], "seg": r[1], "us": round(r[2].elapsed_time(r[3]) * 1e3, 1),
+                         "GBps": round(r[4][0] / max(r[2].elapsed_time(r[3]), 1e-6) / 1e6, 1),
+                         "TFLOPs": round(r[4][1] / max(r[2].elapsed_time(r[3]), 1e-6) / 1e9, 1),
+                         "MB": round(r[4][0] / 1e6, 1)} for r in top]
         plan.profile = None
         tot = sum(a[0] for a in agg.values())
         breakdown = {k: {"ms_per_step": round(a[0] / args.profile_steps, 3), "launches_per_step": a[1] // args.profile_steps,
@@ -185,7 +190,8 @@ def main():
                                       "fwd + focal loss + bwd + grad all-reduce + AdamW",
                           "global_batch": B * world, "parallelism": f"dp{world}", "drop_rate": 0.2, "drop_path_rate": 0.2},
                "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
-               "loss": round(float(loss), 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+               "top_launches": top_launches if rank == 0 and args.profile_steps > 0 else None,
+               "loss": round(float(loss.detach()), 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -46,6 +46,7 @@ const char* mds_last_error(void);
 #define MDS_PRO_AFFINE 1       /* BN, no activation                                            */
 #define MDS_PRO_BN_SILU 2      /* BN + SiLU   (timm BatchNormAct2d / BatchNormAct3d :53-69)     */
 #define MDS_PRO_BN_SILU_GATE 3 /* BN + SiLU, then squeeze-excite gate (:72-90, timm SE)         */
+#define MDS_PRO_GATE 4         /* squeeze-excite gate only: x is the materialised activation   */
 typedef struct {
   int mode;
   const float* scale; /* [C] gamma*rstd                      */
@@ -232,6 +233,9 @@ typedef struct {
   const float* scale;
   const float* shift;
   float* pooled;  /* [groups][C], caller-zeroed (atomic accumulation of sums/rows) */
+  void* act;      /* optional [rows][C]: the activation silu(bn(y)) is also written out, so that the
+                     three later consumers (gated 1x1 conv, its weight gradient, the SE backward
+                     reduction) do not redo the exp/rcp work (they are VALU-bound otherwise) */
 } mds_se_pool_args;
 int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream);
 
@@ -255,7 +259,7 @@ typedef struct {
   long rows_per_group;
   int C;
   const void* u;
-  const void* y;
+  const void* y;      /* raw conv output, or the materialised activation when scale == NULL */
   const float* scale;
   const float* shift;
   float* dgate; /* [groups][C] caller-zeroed */

@@ -9,5 +9,6 @@ for line in sys.stdin:
         for k,v in d["kernel_breakdown"].items():
             tot+=v["ms_per_step"]; print(f'  {k:16s} {v["ms_per_step"]:8.3f} ms  n={v["launches_per_step"]:3d}  {v["GBps"]:8.1f} GB/s {v["TFLOPs"]:7.2f} TF')
         print("  total kernel ms", round(tot,2))
+        for r in (d.get("top_launches") or []): print("   top", r)
         if d.get("cpu_baseline"): print("cpu", d["cpu_baseline"])
     elif line: print(line[:300])

@@ -1,0 +1,131 @@
+"""Micro-benchmark single kernels of libmds_hip.so at the real layer shapes (developer tool).
+
+  python tools/kbench.py dw_fwd dw_bwd pw_fwd ...        # HIP-event timing, 20 reps
+Used under rocprofv3 (--kernel-trace --stats / --pmc ...) to study one kernel in isolation.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "ball-action-spotting_amd")]
+import torch
+from mds import cabi, geometry as geo
+
+dev = torch.device("cuda:0")
+lib = cabi.load()
+BF = torch.bfloat16
+SLOTS = cabi.MDS_STAT_SLOTS
+
+
+def timeit(name, fn, nbytes, flops, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    print(f"{name:42s} {us:9.1f} us  {nbytes / us / 1e3:8.1f} GB/s  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rnd(*shape, dtype=BF):
+    return torch.randn(*shape, device=dev).to(dtype)
+
+
+def bench_dw(which):
+    for (N, T, H, W, C, s, kt, tag) in [(20, 1, 46, 80, 672, 1, 1, "s4 46x80x672"), (20, 1, 23, 40, 1152, 1, 1, "s5 23x40x1152"),
+                                        (20, 1, 92, 160, 192, 2, 1, "s3.0 92x160x192 s2"), (4, 5, 23, 40, 576, 1, 3, "3d 5x23x40x576")]:
+        OH, OW, pt, pl = geo.conv_geometry(H, W, s)
+        x = rnd(N * T * H * W, C); w = torch.randn(C, kt * 9, device=dev) * 0.3
+        sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev) * 0.1
+        mean = torch.randn(C, device=dev) * 0.1; rstd = torch.rand(C, device=dev) + 0.5
+        y = torch.empty(N * T * OH * OW, C, device=dev, dtype=BF)
+        st = torch.zeros(SLOTS, 2, C, device=dev)
+        pro = cabi.pro(2, sc, sh)
+        nin, nout = x.numel(), y.numel()
+        if which == "dw_fwd":
+            a = cabi.make("mds_dw_fwd_args", dtype=1, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=s, pad_t=pt, pad_l=pl,
+                          kt=kt, x=x, w=w, y=y, pro=pro, stats=st)
+            timeit(f"dw_fwd {tag}", lambda: lib.call("dw_fwd", a, stream()), (nin + nout) * 2, 2 * 9 * kt * nout)
+        else:
+            dy = rnd(N * T * OH * OW, C); g = torch.empty_like(x); dw = torch.zeros(C, kt * 9, device=dev)
+            a = cabi.make("mds_dw_bwd_args", dtype=1, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=s, pad_t=pt, pad_l=pl,
+                          kt=kt, x=x, dy=dy, w=w, g=g, dw=dw, pro=pro, mean=mean, rstd=rstd, stats=st)
+            timeit(f"dw_bwd {tag}", lambda: lib.call("dw_bwd", a, stream()), (2 * nin + nout) * 2, 4 * 9 * kt * nout)
+
+
+PW_SHAPES = [  # M, K, N, pro, tag
+    (20 * 184 * 320, 128, 32, 2, "b1.1 pwl 128->32"), (20 * 92 * 160, 48, 192, 0, "b3.0 pw 48->192"),
+    (20 * 46 * 80, 112, 672, 0, "b4.x pw 112->672"), (20 * 46 * 80, 672, 112, 3, "b4.x pwl 672->112"),
+    (20 * 23 * 40, 192, 1152, 0, "b5.x pw 192->1152"), (20 * 23 * 40, 1152, 192, 3, "b5.x pwl 1152->192"),
+    (4 * 5 * 23 * 40, 192, 576, 0, "3d pw 192->576"), (4 * 5 * 23 * 40, 576, 192, 3, "3d pwl 576->192"),
+]
+
+
+def bench_pw(which):
+    for (M, K, N, mode, tag) in PW_SHAPES:
+        x = rnd(M, K); w = rnd(N, K); y = torch.empty(M, N, device=dev, dtype=BF)
+        sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
+        rpg = M // 20
+        gate = torch.rand(20, K, device=dev)
+        st = torch.zeros(SLOTS, 2, N, device=dev)
+        pro = cabi.pro(mode, sc, sh, gate, rpg)
+        if which == "pw_fwd":
+            a = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=pro, residual=None, stats=st)
+            timeit(f"pw_fwd {tag}", lambda: lib.call("pw_fwd", a, stream()), (M * K + M * N + N * K) * 2, 2 * M * K * N)
+        else:
+            dy = rnd(M, N); dw = torch.zeros(N, K, device=dev)
+            a = cabi.make("mds_pw_wgrad_args", dtype=1, M=M, K=K, N=N, x=x, dy=dy, dw=dw, pro=pro)
+            timeit(f"pw_wgrad {tag}", lambda: lib.call("pw_wgrad", a, stream()), (M * K + M * N) * 2, 2 * M * K * N)
+
+
+CONV_SHAPES = [(20, 368, 640, 32, 16, 1, 2, "b0.0 32->16"), (20, 368, 640, 16, 64, 2, 2, "b1.0 16->64 s2"),
+               (20, 184, 320, 32, 128, 1, 0, "b1.1 32->128"), (20, 184, 320, 32, 128, 2, 0, "b2.0 32->128 s2"),
+               (20, 92, 160, 48, 192, 1, 0, "b2.1 48->192")]
+
+
+def bench_conv(which):
+    for (N, H, W, Cin, Cout, s, mode, tag) in CONV_SHAPES:
+        OH, OW, pt, pl = geo.conv_geometry(H, W, s)
+        dy_, dx_, wi = geo.taps_fwd(pt, pl)
+        x = rnd(N * H * W, Cin); w = rnd(Cout * 9 * Cin)
+        sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
+        pro = cabi.pro(mode, sc, sh)
+        flops = 2 * N * OH * OW * 9 * Cin * Cout
+        if which == "conv_fwd":
+            y = torch.empty(N * OH * OW, Cout, device=dev, dtype=BF); st = torch.zeros(SLOTS, 2, Cout, device=dev)
+            a = cabi.make("mds_conv_fwd_args", dtype=1, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout, A=OH, B=OW, oy0=0,
+                          ox0=0, os=1, **{"is": s}, ntaps=9, dy=dy_, dx=dx_, wi=wi, wtaps=9, x=x, w=w, y=y, pro=pro,
+                          residual=None, stats=st)
+            timeit(f"conv_fwd {tag}", lambda: lib.call("conv_fwd", a, stream()), (x.numel() + y.numel()) * 2, flops)
+        else:
+            dyt = rnd(N * OH * OW, Cout); dw = torch.zeros(Cout, Cin, 3, 3, device=dev)
+            a = cabi.make("mds_conv_wgrad_args", dtype=1, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout, **{"is": s},
+                          ntaps=9, dy=dy_, dx=dx_, wi=wi, wtaps=9, x=x, dyt=dyt, dw=dw, pro=pro)
+            timeit(f"conv_wgrad {tag}", lambda: lib.call("conv_wgrad", a, stream()), (x.numel() + dyt.numel()) * 2, flops)
+
+
+def bench_copy():
+    n = 256 * 1024 * 1024
+    a = torch.empty(n, device=dev, dtype=torch.uint8); b = torch.empty_like(a)
+    timeit("torch copy 256MB (HBM reference)", lambda: b.copy_(a), 2 * n, 0)
+
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or ["copy", "dw_fwd", "dw_bwd", "pw_fwd", "pw_wgrad", "conv_fwd", "conv_wgrad"]
+    for t in todo:
+        if t == "copy":
+            bench_copy()
+        elif t.startswith("dw"):
+            bench_dw(t)
+        elif t.startswith("pw"):
+            bench_pw(t)
+        else:
+            bench_conv(t)
