@@ -6,13 +6,12 @@
 // libmds_emu.so with -DMDS_EMU and is never part of the product library (libmds_hip.so), which
 // is hipcc/gfx950 only.  Nothing here is a fallback: the Python product path cannot load it.
 //
-// Model: one OS thread; every HIP thread of a block is a ucontext fiber; blocks run one after
+// Model: one OS thread; every HIP thread of a block is a fiber (own stack, hand-rolled context switch); blocks run one after
 // another.  __syncthreads() and the wave-level operations (shuffles, MFMA) are rendezvous
 // points: a fiber that reaches one yields to the scheduler until all live fibers of the block
 // (or of its 64-lane wave) have arrived.  A round in which no fiber can make progress is a
 // divergent-barrier deadlock and aborts with a message.
 #pragma once
-#include <ucontext.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -43,8 +42,28 @@ namespace hipemu {
 
 enum { RUNNING = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3, READY = 4 };
 
+// Minimal x86-64 fiber switch (callee-saved registers + stack pointer).  ucontext's swapcontext
+// issues two sigprocmask syscalls per switch, which dominated the simulator's run time.
+typedef void* fctx_t;
+__attribute__((naked, noinline)) static void fiber_switch(fctx_t* from, fctx_t* to) {
+  asm volatile(
+      "pushq %rbp\n pushq %rbx\n pushq %r12\n pushq %r13\n pushq %r14\n pushq %r15\n"
+      "movq %rsp, (%rdi)\n"
+      "movq (%rsi), %rsp\n"
+      "popq %r15\n popq %r14\n popq %r13\n popq %r12\n popq %rbx\n popq %rbp\n"
+      "ret\n");
+}
+inline fctx_t fiber_make(char* stack, size_t size, void (*entry)()) {
+  uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+  void** sp = (void**)top;
+  *--sp = nullptr;        // fake return address of `entry` (it never returns)
+  *--sp = (void*)entry;   // popped by fiber_switch's ret
+  for (int i = 0; i < 6; ++i) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
+  return (fctx_t)sp;
+}
+
 struct Fiber {
-  ucontext_t ctx;
+  fctx_t ctx = nullptr;
   char* stack = nullptr;
   int state = READY;
   unsigned tid = 0;
@@ -55,7 +74,7 @@ struct BlockState {
   std::vector<Fiber> fibers;
   int n = 0, nwaves = 0;
   int cur = 0;
-  ucontext_t sched;
+  fctx_t sched = nullptr;
   int block_arrived = 0, done = 0;
   uint64_t block_gen = 1;
   std::vector<int> wave_arrived, wave_done;
@@ -80,7 +99,7 @@ inline void set_tid(unsigned tid) {
 inline void yield_to_sched() {
   BlockState* b = g_blk;
   Fiber& f = b->fibers[b->cur];
-  swapcontext(&f.ctx, &b->sched);
+  fiber_switch(&f.ctx, &b->sched);
 }
 
 inline int lane_id() { return g_blk->cur & 63; }
@@ -131,7 +150,8 @@ inline void trampoline() {
   f.state = DONE;
   b->done++;
   b->wave_done[b->cur >> 6]++;
-  swapcontext(&f.ctx, &b->sched);
+  fiber_switch(&f.ctx, &b->sched);
+  abort();  // a finished fiber is never resumed
 }
 
 inline void run_block(BlockState& b) {
@@ -143,11 +163,7 @@ inline void run_block(BlockState& b) {
   for (int i = 0; i < b.n; ++i) {
     Fiber& f = b.fibers[i];
     f.state = READY; f.tid = i; f.wait_gen = 0;
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack;
-    f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = nullptr;
-    makecontext(&f.ctx, (void (*)())trampoline, 0);
+    f.ctx = fiber_make(f.stack, kStack, trampoline);
   }
   while (b.done < b.n) {
     bool progressed = false;
@@ -170,7 +186,7 @@ inline void run_block(BlockState& b) {
       b.cur = i;
       set_tid(i);
       f.state = RUNNING;
-      swapcontext(&b.sched, &f.ctx);
+      fiber_switch(&b.sched, &f.ctx);
       progressed = true;
     }
     if (!progressed) {
