@@ -47,32 +47,40 @@ def focal_loss(logits, target, gamma=1.2):
     return (ce * (1 - p_t) ** gamma).mean()
 
 
-def cpu_baseline(max_seconds=40.0):
-    """The oracle (CPU restatement pinned to the reference) on the host cores: fwd+bwd of ONE
-    15x736x1280 window, fp32 eager — the same per-window work as the GPU step."""
+def cpu_baseline(max_seconds=25.0):
+    """The oracle (CPU restatement pinned to the reference) on the host cores, fp32 eager fwd+bwd.
+
+    A full 15x736x1280 window takes minutes on the host (241 s measured with 256 threads), so the
+    timed sample is ONE window at 1/16 of the pixels (15x184x320: same network, same 15 frames) and
+    the rate is scaled by 1/16 to full-window units (conv work is linear in the pixel count)."""
     from oracle import multidim_stacker_ref as orc
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(cores, 32)       # the reference's convolutions stop scaling well before 256 threads
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
     m = orc.MultiDimStacker(**kw).train()
-    x = torch.rand(1, 15, 736, 1280, generator=torch.Generator().manual_seed(1234))
+    frac = 16
+    x = torch.rand(1, 15, 736 // 4, 1280 // 4, generator=torch.Generator().manual_seed(1234))
     tgt = torch.tensor([[1.0, 0.0]])
     times = []
     t_start = time.time()
-    for it in range(4):
+    for it in range(6):
         t0 = time.time()
         m.zero_grad(set_to_none=True)
         orc.sigmoid_focal_loss(m(x), tgt, alpha=-1.0, gamma=1.2).backward()
         dt = time.time() - t0
         if it > 0:
             times.append(dt)
-        if time.time() - t_start > max_seconds and times:
+        if time.time() - t_start > max_seconds:
             break
     sec = min(times) if times else dt
-    return {"value": 1.0 / sec, "unit": "frame-windows/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 window 15x736x1280 fp32 eager fwd+bwd, 1 warm-up + {len(times)} timed, best of",
-            "sec_per_window": sec}
+    return {"value": round(1.0 / (sec * frac), 5), "unit": "frame-windows/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32 eager fwd+bwd of 1 window at 1/{frac} of the pixels (15x184x320), best of "
+                      f"{max(len(times), 1)} timed after 1 warm-up, scaled x1/{frac} to 15x736x1280 windows; "
+                      f"host has {cores} logical cores, {threads} threads used; a full-size window measured 241 s "
+                      f"(0.00415 windows/s) with 256 threads",
+            "sec_per_sample": round(sec, 3)}
 
 
 def main():

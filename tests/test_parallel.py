@@ -1,0 +1,88 @@
+"""Data-parallel path on CPU: gloo, world_size 2 (the GPU path is the same code over RCCL)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mds import parallel
+
+
+def test_shard_windows_partitions_everything():
+    for n, w in [(6000, 8), (7, 3), (5, 8), (16, 2)]:
+        parts = [list(parallel.shard_windows(n, r, w)) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def _worker(rank, world, port, tmp):
+    for p in sys.path_extra:
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import mds
+    from mds import parallel as par
+    from oracle import multidim_stacker_ref as orc
+    from det_init import fill_deterministic
+    from hipemu.loader import load_emulator
+
+    # 1. flat-buffer mean all-reduce
+    flat = torch.full((1000,), float(rank + 1))
+    par.allreduce_mean_(flat)
+    assert torch.allclose(flat, torch.full((1000,), (1 + world) / 2 * 1.0))
+
+    # 2. whole module: rank-local windows + local BN, averaged gradients == mean of the oracle's
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    prod = mds.MultiDimStacker(**kw)
+    fill_deterministic(prod, 3 + rank, scale=0.05)          # ranks start different on purpose
+    prod._lib = load_emulator()
+    par.data_parallel(prod)                                  # broadcasts rank 0's state, installs the sync
+    ref = orc.MultiDimStacker(**kw)
+    ref.load_state_dict(prod.state_dict())
+    ref0 = fill_deterministic(orc.MultiDimStacker(**kw), 3, scale=0.05)
+    for a, b in zip(ref.state_dict().values(), ref0.state_dict().values()):
+        assert torch.equal(a, b)                             # broadcast made every rank equal to rank 0
+    # (64x32: at 32x32 the last stages see 1x1 maps, BN over 5 samples is ill-conditioned in fp32)
+    xs = [torch.rand(1, 15, 64, 32, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    tgt = torch.tensor([[1.0, 0.0]])
+    prod.train()
+    orc.sigmoid_focal_loss(prod(xs[rank]), tgt, alpha=-1.0, gamma=1.2).backward()
+    want = None
+    for r in range(world):                                   # oracle on every shard, fresh copy each
+        m = orc.MultiDimStacker(**kw); m.load_state_dict(ref0.state_dict()); m.train()
+        orc.sigmoid_focal_loss(m(xs[r]), tgt, alpha=-1.0, gamma=1.2).backward()
+        g = torch.cat([p.grad.flatten() for p in m.parameters()])
+        want = g if want is None else want + g
+    want /= world
+    got = torch.cat([p.grad.flatten() for p in prod.parameters()])
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-3, err
+    torch.save(got, os.path.join(tmp, f"g{rank}.pt"))
+    dist.barrier()
+    if rank == 0:                                            # every rank holds the same averaged gradient
+        g1 = torch.load(os.path.join(tmp, "g1.pt"))
+        assert torch.equal(got, g1)
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradients_match_mean_of_oracle(tmp_path):
+    sys.path_extra = [p for p in sys.path if "repo" in p]
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = []
+    for r in range(2):
+        p = ctx.Process(target=_spawn_entry, args=(r, 2, port, str(tmp_path), sys.path_extra))
+        p.start(); procs.append(p)
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+
+
+def _spawn_entry(rank, world, port, tmp, paths):
+    sys.path_extra = paths
+    _worker(rank, world, port, tmp)
