@@ -28,6 +28,49 @@ MDS_DEV int reduce_scatter32(float (&vals)[32], int i) {
 }
 
 
+// reduce-scatter of 16 per-lane partials over the 16 lanes sharing q; returns the entry index
+MDS_DEV int reduce_scatter16(float (&vals)[16], int i) {
+  int e0 = 0;
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int half = 8 >> step, mask = 8 >> step;
+    const bool bit = (i & mask) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      float lo = vals[k], hi = vals[k + half];
+      float send = bit ? lo : hi;
+      float keep = bit ? hi : lo;
+      vals[k] = keep + __shfl_xor(send, mask);
+    }
+    if (bit) e0 += half;
+  }
+  return e0;
+}
+
+template <typename T> struct RawV8;   // 8 consecutive elements as loaded (no conversion yet)
+template <> struct RawV8<bf16_t> {
+  u16x8 v;
+  MDS_DEV void ld(const bf16_t* p) { v = *(const u16x8*)p; }
+  MDS_DEV void zero() { v = (u16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
+  MDS_DEV void get(float (&o)[8]) const {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bf2f(v[j]);
+  }
+  MDS_DEV void st(bf16_t* p) const { *(u16x8*)p = v; }
+};
+template <> struct RawV8<float> {
+  f32x4 a, b;
+  MDS_DEV void ld(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+  MDS_DEV void zero() { a = (f32x4){0, 0, 0, 0}; b = a; }
+  MDS_DEV void get(float (&o)[8]) const {
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  }
+  MDS_DEV void st(float* p) const { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
+};
+
+// exact a / b for 0 <= a < 2^22 with rb = 1.0f / b (cheap replacement for integer division)
+MDS_DEV int fdiv(int a, float rb) { return (int)(((float)a + 0.5f) * rb); }
+
 // 16-byte aligned fragment loads from LDS (8 consecutive k of one row)
 MDS_DEV u16x8 ld_frag(const bf16_t* p) { return *(const u16x8*)p; }
 MDS_DEV f32x8 ld_frag(const float* p) {

@@ -1,115 +1,174 @@
 // k_conv.hip — dense 3x3 convolutions (EfficientNetV2 stages 0-2) as MFMA implicit GEMMs.
 //
 // One kernel, parameterised by a tap list, serves the stride-1 'same' conv, the TF-SAME stride-2
-// conv, and both data gradients (see mds_conv_fwd_args).  A block owns an 8x16 patch of output
-// sub-grid points; the matching input patch (with halo) is staged in LDS once per 32-channel
-// chunk — with the producer's BN+SiLU applied on the way in and zero padding applied after it —
-// and re-read from LDS by all taps, so HBM sees each input pixel once per block.
+// conv, and both data gradients (see mds_conv_fwd_args).  A block owns a 16x16 (stride 1) or 8x16
+// (stride 2) patch of output sub-grid points and 64 output channels.  Per 32-channel input chunk
+// the input patch (+halo) is staged in LDS once — with the producer's BN+SiLU applied on the way in
+// and zero padding applied after it — together with the weights of ALL taps, so the 9-tap MFMA
+// loop runs without a barrier: 2 barriers per chunk, 0.5 LDS fragment reads per MFMA.
 // Arithmetic intensity 100-600 FLOP/B: MFMA-bound layers.
 #include "gemm.h"
 
-#define CV_TA 8
 #define CV_TB 16
-#define CV_BNT 128
+#define CV_BN 64
 
-template <typename T, int PRO>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW) {
+template <typename T> struct CvLd;   // LDS pitch of one staged pixel / weight row: 32 channels + 16 B
+template <> struct CvLd<bf16_t> { static const int v = 40; };
+template <> struct CvLd<float> { static const int v = 36; };
+
+template <typename T, int PRO, int IS>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW, int tg) {
   typedef typename Frag<T>::type frag_t;
-  const int LD = PwLd<T>::v;
+  constexpr int LD = CvLd<T>::v;
+  constexpr int MF = (IS == 1) ? 4 : 2;        // 16-pixel row fragments per wave
+  constexpr int TA = 4 * MF;                   // sub-grid rows per block
+  constexpr int MAXX = (IS == 1) ? 6 : 9;      // input-patch vectors per thread (18x18 | 17x33 pixels x 4)
+  constexpr int MAXW = MDS_MAX_TAPS * CV_BN * 4 / 256;
   MDS_DYN_SMEM(smem);
-  T* xs = (T*)smem;                          // [TH*TW][LD]
-  T* ws = xs + TH * TW * LD;                 // [CV_BNT][LD]
-  float* st_s = (float*)(ws + CV_BNT * LD);  // [CV_BNT]
-  float* st_ss = st_s + CV_BNT;
+  const int npix = TH * TW;
+  const float rTW = 1.0f / (float)TW;
+  T* xs = (T*)smem;                                    // [npix][LD]   32-channel chunk of the patch
+  T* ws = xs + npix * LD;                              // [tg taps][CV_BN][LD]
+  float* st_s = (float*)(ws + tg * CV_BN * LD);        // [CV_BN]
+  float* st_ss = st_s + CV_BN;
+  int* toff = (int*)(st_ss + CV_BN);                   // [ntaps] LDS element offset of each tap
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int b0 = blockIdx.x * CV_TB, a0 = blockIdx.y * CV_TA, img = blockIdx.z;
+  const int b0 = blockIdx.x * CV_TB, a0 = blockIdx.y * TA, img = blockIdx.z;
   const int Cin = a.Cin, Cout = a.Cout;
   const T* x = (const T*)a.x + (long)img * a.IH * a.IW * Cin;
   const T* w = (const T*)a.w;
   T* y = (T*)a.y;
-  const int schunk = tid & 3;
-  const int npix = TH * TW;
-
-  for (int n0 = 0; n0 < Cout; n0 += CV_BNT) {
-    const int nfr = (Cout - n0 >= CV_BNT) ? 8 : ((Cout - n0) >> 4);
-    f32x4 acc[2][8];
+  if (tid < a.ntaps) toff[tid] = ((a.dy[tid] - dymin) * TW + (a.dx[tid] - dxmin)) * LD;
+  int xbase[MF];
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-      for (int nf = 0; nf < 8; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.stats && tid < CV_BNT) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
+  for (int mf = 0; mf < MF; ++mf) xbase[mf] = ((MF * wave + mf) * IS * TW + i * IS) * LD + 8 * q;
+  const int wbase = i * LD + 8 * q;
+  const int nx = npix * 4;
 
-    for (int kc = 0; kc < Cin; kc += PW_KC) {
-      const int kk = kc + 8 * schunk;
+  for (int n0 = 0; n0 < Cout; n0 += CV_BN) {
+    const int nfr = (Cout - n0 >= CV_BN) ? 4 : ((Cout - n0) >> 4);
+    const int wrows = nfr * 16;
+    f32x4 acc[MF][4];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.stats && tid < CV_BN) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
+
+    for (int kc = 0; kc < Cin; kc += 32) {
+      // ---- issue every global load of this (n-tile, k-chunk) first: input patch, then the weights of
+      //      the first tap group.  Addresses are clamped (always legal); masks are applied afterwards.
+      const int ch = tid & 3, kk = kc + 8 * ch;   // this thread's 8-channel slice of the chunk (256 % 4 == 0)
       float sc[8], sh[8];
-      if (PRO != MDS_PRO_NONE && kk < Cin) { load8f(a.pro.scale + kk, sc); load8f(a.pro.shift + kk, sh); }
-      __syncthreads();
-      for (int it = tid; it < npix * 4; it += 256) {
-        const int pix = it >> 2;
-        const int ty = pix / TW, tx = pix - ty * TW;
-        const int iy = a0 * a.is + dymin + ty, ix = b0 * a.is + dxmin + tx;
-        float v[8];
-        if (kk < Cin && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
-          load8(x + ((long)iy * a.IW + ix) * Cin + kk, v);
-          if (PRO != MDS_PRO_NONE) {
+      if (PRO != MDS_PRO_NONE) {
+        load8f(a.pro.scale + (kk < Cin ? kk : 0), sc);
+        load8f(a.pro.shift + (kk < Cin ? kk : 0), sh);
+      }
+      RawV8<T> rx[MAXX];
+      unsigned okx = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float z = v[j] * sc[j] + sh[j];
-              v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+      for (int l = 0; l < MAXX; ++l) {
+        const int it = tid + 256 * l;
+        if (it < nx) {
+          const int pix = it >> 2;
+          const int ty = fdiv(pix, rTW), tx = pix - ty * TW;
+          const int iy = a0 * IS + dymin + ty, ix = b0 * IS + dxmin + tx;
+          const bool ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && kk < Cin;
+          okx |= (ok ? 1u : 0u) << l;
+          const int cy = iy < 0 ? 0 : (iy >= a.IH ? a.IH - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.IW ? a.IW - 1 : ix);
+          rx[l].ld(x + ((long)cy * a.IW + cx) * Cin + (kk < Cin ? kk : 0));
+        }
+      }
+      RawV8<T> rw[MAXW];
+      unsigned okw = 0;
+      auto issue_w = [&](int t0) {   // all weight loads of one tap group
+        const int tn = a.ntaps - t0 < tg ? a.ntaps - t0 : tg;
+        okw = 0;
+#pragma unroll
+        for (int l = 0; l < MAXW; ++l) {
+          const int it = tid + 256 * l;
+          if (it < tn * CV_BN * 4) {
+            const int rr = it >> 2;                       // rr = tl * CV_BN + r
+            const int t = t0 + (rr >> 6), r = rr & (CV_BN - 1);
+            okw |= ((r < wrows && kk < Cin) ? 1u : 0u) << l;
+            if (r < wrows) rw[l].ld(w + ((long)(n0 + r) * a.wtaps + a.wi[t]) * Cin + (kk < Cin ? kk : 0));
+          }
+        }
+      };
+      issue_w(0);
+      for (int t0 = 0; t0 < a.ntaps; t0 += tg) {
+        const int tn = a.ntaps - t0 < tg ? a.ntaps - t0 : tg;
+        __syncthreads();  // previous fragment reads are done
+        if (t0 == 0) {
+#pragma unroll
+          for (int l = 0; l < MAXX; ++l) {
+            const int it = tid + 256 * l;
+            if (it < nx) {
+              const int pix = it >> 2;
+              const bool ok = (okx >> l) & 1u;
+              if (PRO == MDS_PRO_NONE) {
+                if (!ok) rx[l].zero();
+                rx[l].st(xs + pix * LD + 8 * ch);
+              } else {
+                float v[8];
+                rx[l].get(v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  float z = v[j] * sc[j] + sh[j];
+                  z = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+                  v[j] = ok ? z : 0.f;  // zero padding AFTER the activation
+                }
+                store8(xs + pix * LD + 8 * ch, v);
+                MDS_SCHED_FENCE();  // keep one vector's exp/rcp temporaries live at a time (register budget)
+              }
             }
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = 0.f;
         }
-        store8(xs + pix * LD + 8 * schunk, v);
-      }
-      for (int t = 0; t < a.ntaps; ++t) {
-        if (t > 0) __syncthreads();
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const int r = (tid >> 2) + 64 * p;
-          const int n = n0 + r;
-          float v[8];
-          if (n < Cout && kk < Cin) {
-            load8(w + ((long)n * a.wtaps + a.wi[t]) * Cin + kk, v);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        for (int l = 0; l < MAXW; ++l) {
+          const int it = tid + 256 * l;
+          if (it < tn * CV_BN * 4) {
+            const int rr = it >> 2;
+            if ((rr & (CV_BN - 1)) < wrows) {
+              if (!((okw >> l) & 1u)) rw[l].zero();
+              rw[l].st(ws + rr * LD + 8 * ch);
+            }
           }
-          store8(ws + r * LD + 8 * schunk, v);
         }
         __syncthreads();
-        frag_t xf[2];
+        if (t0 + tg < a.ntaps) issue_w(t0 + tg);   // next group's weights fly under this group's MFMAs
+        for (int tl = 0; tl < tn; ++tl) {
+          const int xo = toff[t0 + tl];
+          const T* wt = ws + tl * CV_BN * LD + wbase;
+          frag_t xf[MF], wf[4];
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
-          const int al = 2 * wave + mf;
-          const int pix = (al * a.is + a.dy[t] - dymin) * TW + (i * a.is + a.dx[t] - dxmin);
-          xf[mf] = ld_frag(xs + pix * LD + 8 * q);
-        }
+          for (int mf = 0; mf < MF; ++mf) xf[mf] = ld_frag(xs + xbase[mf] + xo);
 #pragma unroll
-        for (int nf = 0; nf < 8; ++nf) {
-          if (nf < nfr) {
-            frag_t wf = ld_frag(ws + (16 * nf + i) * LD + 8 * q);
-            mma16(wf, xf[0], acc[0][nf]);
-            mma16(wf, xf[1], acc[1][nf]);
+          for (int nf = 0; nf < 4; ++nf)
+            if (nf < nfr) wf[nf] = ld_frag(wt + 16 * nf * LD);
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) {
+            if (nf < nfr) {
+#pragma unroll
+              for (int mf = 0; mf < MF; ++mf) mma16(wf[nf], xf[mf], acc[mf][nf]);
+            }
           }
         }
       }
     }
 
-    float part_s[32], part_ss[32];
+    float ps[16], pss[16];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) { part_s[e] = 0.f; part_ss[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-      const int aa = a0 + 2 * wave + mf, bb = b0 + i;
+    for (int mf = 0; mf < MF; ++mf) {
+      const int aa = a0 + MF * wave + mf, bb = b0 + i;
       const bool valid = aa < a.A && bb < a.B;
       const long row = ((long)img * a.OH + (a.oy0 + aa * a.os)) * a.OW + (a.ox0 + bb * a.os);
 #pragma unroll
-      for (int nf = 0; nf < 8; ++nf) {
+      for (int nf = 0; nf < 4; ++nf) {
         if (nf < nfr && valid) {
           const int n = n0 + 16 * nf + 4 * q;
           float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
@@ -121,25 +180,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(mds_conv_fwd_args a, int 
           }
           store4(y + row * Cout + n, v);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            part_s[nf * 4 + r] += v[r];
-            part_ss[nf * 4 + r] += v[r] * v[r];
-          }
+          for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[r]; pss[nf * 4 + r] += v[r] * v[r]; }
         }
       }
     }
     if (a.stats) {
-      int e0 = reduce_scatter32(part_s, i);
-      reduce_scatter32(part_ss, i);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int e = e0 + t;
-        const int nl = 16 * (e >> 2) + 4 * q + (e & 3);
-        atomicAdd(&st_s[nl], part_s[t]);
-        atomicAdd(&st_ss[nl], part_ss[t]);
-      }
+      const int e = reduce_scatter16(ps, i);
+      reduce_scatter16(pss, i);
+      const int nl = 16 * (e >> 2) + 4 * q + (e & 3);
+      atomicAdd(&st_s[nl], ps[0]);
+      atomicAdd(&st_ss[nl], pss[0]);
       __syncthreads();
-      if (tid < CV_BNT && n0 + tid < Cout) {
+      if (tid < CV_BN && n0 + tid < Cout) {
         const int slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7) % MDS_STAT_SLOTS;
         float* st = a.stats + (long)slot * 2 * Cout;
         atomicAdd(st + n0 + tid, st_s[tid]);
@@ -160,18 +212,25 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->N > 0 && a->A > 0 && a->B > 0, "conv_fwd: bad dims");
   MDS_REQUIRE(a->Cin % 8 == 0 && a->Cout % 16 == 0, "conv_fwd: Cin=%d %% 8, Cout=%d %% 16", a->Cin, a->Cout);
   MDS_REQUIRE(a->ntaps >= 1 && a->ntaps <= MDS_MAX_TAPS && a->wtaps >= 1, "conv_fwd: ntaps");
-  MDS_REQUIRE(a->is >= 1 && a->os >= 1, "conv_fwd: strides");
+  MDS_REQUIRE((a->is == 1 || a->is == 2) && a->os >= 1, "conv_fwd: strides");
   MDS_REQUIRE(a->x && a->w && a->y, "conv_fwd: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_AFFINE || a->pro.mode == MDS_PRO_BN_SILU, "conv_fwd: prologue mode");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "conv_fwd: prologue needs scale/shift");
   MDS_REQUIRE(a->oy0 + (a->A - 1) * a->os < a->OH && a->ox0 + (a->B - 1) * a->os < a->OW, "conv_fwd: sub-grid exceeds output");
   int dymin, dxmin;
   const int eh = tap_extent(a->dy, a->ntaps, &dymin), ew = tap_extent(a->dx, a->ntaps, &dxmin);
-  const int TH = (CV_TA - 1) * a->is + eh + 1, TW = (CV_TB - 1) * a->is + ew + 1;
-  dim3 grid(cdiv(a->B, CV_TB), cdiv(a->A, CV_TA), a->N), block(256);
-#define CV_GO(T, PRO)                                                                             \
-  MDS_LAUNCH((conv_fwd_kernel<T, PRO>), grid, block,                                              \
-             (size_t)(TH * TW + CV_BNT) * PwLd<T>::v * sizeof(T) + 2 * CV_BNT * sizeof(float), stream, *a, dymin, dxmin, TH, TW)
+  const int TA = a->is == 1 ? 16 : 8;
+  const int TH = (TA - 1) * a->is + eh + 1, TW = (CV_TB - 1) * a->is + ew + 1;
+  dim3 grid(cdiv(a->B, CV_TB), cdiv(a->A, TA), a->N), block(256);
+#define CV_GO(T, PRO)                                                                                   \
+  do {                                                                                                  \
+    const int LD = CvLd<T>::v;                                                                          \
+    int tg = a->ntaps;  /* taps staged per barrier group: all of them unless LDS (160 KiB) says no */   \
+    while (tg > 1 && (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) > 76 * 1024) tg = (tg > 3 ? 3 : tg - 1);     \
+    const size_t smem = (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) + 2 * CV_BN * sizeof(float) + 64; \
+    if (a->is == 1) MDS_LAUNCH((conv_fwd_kernel<T, PRO, 1>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
+    else MDS_LAUNCH((conv_fwd_kernel<T, PRO, 2>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
+  } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: CV_GO(T, MDS_PRO_NONE); break;
@@ -183,6 +242,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
   return mds_check_launch("conv_fwd");
 }
 
+#define CV_TA 8   // spatial tile of the weight-gradient kernel below
 // ------------------------------------------------------------------------------------ wgrad
 // dw[co][ci][tap] += sum over output points of dy[p][co] * pro(x)[p*is + tap][ci].
 // The MFMA reduction index is the output point; a block walks `tiles_per_block` 8x16 patches and

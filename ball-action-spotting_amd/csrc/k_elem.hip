@@ -4,7 +4,7 @@
 
 // ------------------------------------------------------------------ bn_res
 template <typename T>
-__global__ void bn_res_kernel(mds_bn_res_args a) {
+__global__ __launch_bounds__(256) void bn_res_kernel(mds_bn_res_args a) {
   const RowMap m = rowmap(a.C);
   if (!m.valid) return;
   const int c0 = m.chunk * 8;
@@ -44,7 +44,7 @@ extern "C" int mds_bn_res(const mds_bn_res_args* a, mds_stream_t stream) {
 // ------------------------------------------------------------------ grouped reductions
 // grid = (blocks_per_group, groups); block walks rows of its group.
 template <typename T>
-__global__ void se_pool_kernel(mds_se_pool_args a) {
+__global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
   __shared__ float red[256 * 8];
   const RowMap m = rowmap(a.C);
   const int c0 = m.chunk * 8;
@@ -81,15 +81,23 @@ extern "C" int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream) {
 }
 
 template <typename T>
-__global__ void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
+__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
   __shared__ float red[256 * 8];
+  __shared__ float red2[256 * 8 * 2];
   const RowMap m = rowmap(a.C);
   const int c0 = m.chunk * 8;
   float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
+  float bs[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[k][j] = 0.f;
+  const bool fuse_bn = a.bnsums != 0;
   if (m.valid) {
-    float sc[8], sh[8];
+    float sc[8], sh[8], mu[8], rs[8];
     const bool raw = a.scale != 0;  // raw conv output: re-apply BN+SiLU; else y IS the activation
     if (raw) { load8f(a.scale + c0, sc); load8f(a.shift + c0, sh); }
+    if (fuse_bn) { load8f(a.mean + c0, mu); load8f(a.rstd + c0, rs); }
     const long base = (long)blockIdx.y * a.rows_per_group * a.C;
     const T* y = (const T*)a.y + base;
     const T* u = (const T*)a.u + base;
@@ -97,12 +105,25 @@ __global__ void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
       float v[8], uu[8];
       load8(y + r * a.C + c0, v);
       load8(u + r * a.C + c0, uu);
-      if (raw) {
+      if (fuse_bn) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = siluf_(v[j] * sc[j] + sh[j]);
+        for (int j = 0; j < 8; ++j) {
+          const float z = v[j] * sc[j] + sh[j];
+          const float sg = sigmoidf_(z);
+          const float sp = sg * (1.0f + z * (1.0f - sg));     // silu'(z)
+          const float xh = (v[j] - mu[j]) * rs[j];
+          acc[0][j] += uu[j] * (z * sg);
+          const float us = uu[j] * sp;
+          bs[0][j] += us; bs[1][j] += us * xh; bs[2][j] += sp; bs[3][j] += sp * xh;
+        }
+      } else {
+        if (raw) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = siluf_(v[j] * sc[j] + sh[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[0][j] += uu[j] * v[j];
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[0][j] += uu[j] * v[j];
     }
   }
   block_reduce_rows<1>(acc, m, red);
@@ -110,16 +131,32 @@ __global__ void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) atomicAdd(a.dgate + (long)blockIdx.y * a.C + c0 + j, acc[0][j]);
   }
+  if (fuse_bn) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float part[2][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { part[0][j] = bs[2 * h][j]; part[1][j] = bs[2 * h + 1][j]; }
+      block_reduce_rows<2>(part, m, red2);
+      if (m.valid && m.rsub == 0) {
+        float* dst = a.bnsums + (((long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2 * h) * a.C + c0;
+        store8(dst, part[0]);
+        store8(dst + a.C, part[1]);
+      }
+    }
+  }
 }
+extern "C" int mds_se_bwd_reduce_blocks(long rows_per_group, int C) { return group_blocks(rows_per_group, C); }
 extern "C" int mds_se_bwd_reduce(const mds_se_bwd_reduce_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "se_bwd_reduce: bad dims");
+  MDS_REQUIRE(!a->bnsums || (a->scale && a->shift && a->mean && a->rstd), "se_bwd_reduce: BN fusion needs raw y + scale/shift/mean/rstd");
   MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(se_bwd_reduce_kernel<T>, dim3(group_blocks(a->rows_per_group, a->C), a->groups), dim3(256), 0, stream, *a));
   return mds_check_launch("se_bwd_reduce");
 }
 
 // ------------------------------------------------------------------ BN backward reduce / apply
 template <typename T>
-__global__ void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_args a) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_args a) {
   __shared__ float red[256 * 8 * 2];
   const RowMap m = rowmap(a.C);
   const int c0 = m.chunk * 8;
@@ -165,7 +202,7 @@ extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t s
 }
 
 template <typename T>
-__global__ void bn_bwd_apply_kernel(mds_bn_bwd_apply_args a) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(mds_bn_bwd_apply_args a) {
   const RowMap m = rowmap(a.C);
   if (!m.valid) return;
   const int c0 = m.chunk * 8;
@@ -200,7 +237,7 @@ extern "C" int mds_bn_bwd_apply(const mds_bn_bwd_apply_args* a, mds_stream_t str
 // ------------------------------------------------------------------ GeM (fp32 math)
 // one block per (b,t) group.
 template <typename T>
-__global__ void gem_fwd_kernel(mds_gem_fwd_args a) {
+__global__ __launch_bounds__(256) void gem_fwd_kernel(mds_gem_fwd_args a) {
   __shared__ float red[256 * 8];
   const RowMap m = rowmap(a.C);
   const int c0 = m.chunk * 8;
@@ -235,7 +272,7 @@ extern "C" int mds_gem_fwd(const mds_gem_fwd_args* a, mds_stream_t stream) {
 }
 
 template <typename T>
-__global__ void gem_bwd_kernel(mds_gem_bwd_args a) {
+__global__ __launch_bounds__(256) void gem_bwd_kernel(mds_gem_bwd_args a) {
   __shared__ float red[256 * 8];
   const RowMap m = rowmap(a.C);
   const int c0 = m.chunk * 8;

@@ -202,12 +202,31 @@ __global__ void se_bwd3_kernel(mds_se_fc_bwd_args a) {
   a.dw1[(long)r * C + c] += s1;
   if (r == 0) a.db2[c] += db2;
 }
+// BatchNorm-backward sums of g = (u*gate + dpooled)*silu'(z) from the per-group partials of
+// mds_se_bwd_reduce:  sum g = sum_grp gate*A1 + dpooled*A3 ;  sum g*xh = sum_grp gate*A2 + dpooled*A4
+__global__ void se_bwd4_kernel(mds_se_fc_bwd_args a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (group, channel)
+  if (e >= a.groups * a.C) return;
+  const int g = e / a.C, c = e % a.C;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* b = a.bnsums + (long)g * a.bn_nblk * 4 * a.C + c;
+  for (int k = 0; k < a.bn_nblk; ++k, b += 4 * a.C) {
+    s[0] += b[0]; s[1] += b[a.C]; s[2] += b[2 * a.C]; s[3] += b[3 * a.C];
+  }
+  const float gt = a.gate[e], dp = a.dpooled[e];
+  atomicAdd(a.bn_stats + c, gt * s[0] + dp * s[2]);
+  atomicAdd(a.bn_stats + a.C + c, gt * s[1] + dp * s[3]);
+}
 extern "C" int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->R > 0 && a->rows_per_group > 0, "se_fc_bwd: bad dims");
   MDS_REQUIRE(a->scratch && a->dgate && a->gate && a->hidden && a->pooled && a->dpooled, "se_fc_bwd: null pointer");
   MDS_LAUNCH(se_bwd1_kernel, dim3(cdiv(a->groups * a->R, 4)), dim3(256), 0, stream, *a);
   MDS_LAUNCH(se_bwd2_kernel, dim3(cdiv((long)a->groups * a->C, 256)), dim3(256), 0, stream, *a);
   MDS_LAUNCH(se_bwd3_kernel, dim3(cdiv((long)a->R * a->C, 256)), dim3(256), 0, stream, *a);
+  if (a->bnsums && a->bn_stats) {
+    MDS_REQUIRE(a->bn_nblk > 0, "se_fc_bwd: bn_nblk");
+    MDS_LAUNCH(se_bwd4_kernel, dim3(cdiv((long)a->groups * a->C, 256)), dim3(256), 0, stream, *a);
+  }
   return mds_check_launch("se_fc_bwd");
 }
 

@@ -108,6 +108,7 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
 }
+#define MDS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 // gfx950 has 160 KiB of LDS per CU; launches above the 64 KiB default opt in once per kernel.
 #define MDS_LAUNCH(kernel, grid, block, smem, stream, ...)                                          \
@@ -152,6 +153,7 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
   for (int j = 0; j < 8; ++j) { fa[j] = a[j]; fb[j] = b[j]; }
   mma16_emu(fa, fb, c, false);
 }
+#define MDS_SCHED_FENCE() ((void)0)
 #define MDS_DYN_SMEM(name) char* name = hipemu::dyn_smem()
 #define MDS_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipemu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })

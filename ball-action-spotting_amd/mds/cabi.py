@@ -102,6 +102,8 @@ class Lib:
             st = STRUCTS.get(f"mds_{op}_args")
             if st is not None:
                 self.fn[op].argtypes = [C.POINTER(st), C.c_void_p]
+        if "se_bwd_reduce_blocks" in self.fn:
+            self.fn["se_bwd_reduce_blocks"].argtypes = [C.c_long, C.c_int]
         if "pack_weights" in self.fn:
             self.fn["pack_weights"].argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 

@@ -352,8 +352,10 @@ class Plan:
             bn3.backward(self, seg, g3, y3, dy3, frozen=frozen)
             u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen)
             dgate, dpool = self.zero_bwd(groups * mid), self.f32(groups * mid)
-            self.op(seg, "se_bwd_reduce", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, u=u2, y=a2,
-                    scale=None, shift=None, dgate=dgate)
+            nblk = self.lib.fn["se_bwd_reduce_blocks"](rpg, mid)
+            bnsums = self.f32(groups * nblk * 4 * mid)
+            self.op(seg, "se_bwd_reduce", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, u=u2, y=y2,
+                    scale=bn2.scale, shift=bn2.shift, dgate=dgate, mean=bn2.mean, rstd=bn2.rstd, bnsums=bnsums)
             if frozen:
                 sg = [self.f32(se.conv_reduce.weight.numel()), self.f32(R), self.f32(se.conv_expand.weight.numel()), self.f32(mid)]
             else:
@@ -361,9 +363,10 @@ class Plan:
                       self.grad(se.conv_expand.bias)]
             self.op(seg, "se_fc_bwd", groups=groups, C=mid, R=R, rows_per_group=rpg, dgate=dgate, gate=gate, hidden=hidden,
                     pooled=pooled, w1=P(se.conv_reduce.weight), w2=P(se.conv_expand.weight), dpooled=dpool,
-                    scratch=self.f32(groups * R), dw1=sg[0], db1=sg[1], dw2=sg[2], db2=sg[3])
+                    scratch=self.f32(groups * R), dw1=sg[0], db1=sg[1], dw2=sg[2], db2=sg[3],
+                    bnsums=bnsums, bn_nblk=nblk, bn_stats=bn2.bstats)
             dy2 = self.act(Mout, mid)
-            bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, frozen=frozen)
+            bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, reduce=False, frozen=frozen)
             g1 = self.act(Min, mid)
             self.op(seg, "dw_bwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
                     pad_l=pl, kt=kt, x=y1, dy=dy2, w=wdw, g=g1, dw=self.f32(mid * kt * 9) if frozen else self.grad(blk.conv_dw.weight),

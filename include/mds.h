@@ -263,7 +263,17 @@ typedef struct {
   const float* scale;
   const float* shift;
   float* dgate; /* [groups][C] caller-zeroed */
+  /* optional fusion of the following BatchNorm-backward reduction (needs raw y + scale/shift):
+   * with s' = silu'(z), xh = (y-mean)*rstd, per (group, channel) partial sums
+   *   bnsums[g][blk][0..3][c] = sum u*s', sum u*s'*xh, sum s', sum s'*xh   over block blk's rows
+   * (plain stores, no atomics: contended fp32 atomics were slower than the pass they replaced),
+   * blk < mds_se_bwd_reduce_blocks(rows_per_group, C).  mds_se_fc_bwd forms sum g and sum g*xh of
+   * g = (u*gate + dpooled)*s' from them without another pass over the two mid-width tensors.    */
+  const float* mean;
+  const float* rstd;
+  float* bnsums; /* [groups][blocks][4][C] */
 } mds_se_bwd_reduce_args;
+int mds_se_bwd_reduce_blocks(long rows_per_group, int C);
 int mds_se_bwd_reduce(const mds_se_bwd_reduce_args* a, mds_stream_t stream);
 
 /* backward of the two SE FCs: in dgate_raw, gate, hidden, pooled; out dpooled[g][c] (grad wrt the
@@ -283,6 +293,9 @@ typedef struct {
   float* db1;
   float* dw2;     /* [C][R] */
   float* db2;
+  const float* bnsums; /* optional [groups][bn_nblk][4][C] from mds_se_bwd_reduce                  */
+  int bn_nblk;         /* = mds_se_bwd_reduce_blocks(rows_per_group, C)                            */
+  float* bn_stats;     /* optional [SLOTS][2][C] (zeroed): slot 0 receives sum g, sum g*xhat       */
 } mds_se_fc_bwd_args;
 int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream);
 

@@ -112,6 +112,27 @@ def bench_conv(which):
             timeit(f"conv_wgrad {tag}", lambda: lib.call("conv_wgrad", a, stream()), (x.numel() + dyt.numel()) * 2, flops)
 
 
+def bench_se():
+    G, R, C = 20, 3680, 672
+    M = G * R
+    u = rnd(M, C); y = rnd(M, C)
+    sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev) * 0.1
+    mean = torch.randn(C, device=dev) * 0.1; rstd = torch.rand(C, device=dev) + 0.5
+    dgate = torch.zeros(G, C, device=dev); bns = torch.zeros(G, 64, 4, C, device=dev)
+    a = cabi.make("mds_se_bwd_reduce_args", dtype=1, groups=G, rows_per_group=R, C=C, u=u, y=y, scale=sc, shift=sh,
+                  dgate=dgate, mean=mean, rstd=rstd, bnsums=bns)
+    timeit("se_bwd_reduce fused-bn 20x3680x672", lambda: lib.call("se_bwd_reduce", a, stream()), 2 * M * C * 2, 0)
+    b = cabi.make("mds_se_bwd_reduce_args", dtype=1, groups=G, rows_per_group=R, C=C, u=u, y=y, scale=sc, shift=sh,
+                  dgate=dgate)
+    timeit("se_bwd_reduce plain     20x3680x672", lambda: lib.call("se_bwd_reduce", b, stream()), 2 * M * C * 2, 0)
+    pooled = torch.zeros(G, C, device=dev); act = torch.empty_like(y)
+    c = cabi.make("mds_se_pool_args", dtype=1, groups=G, rows_per_group=R, C=C, y=y, scale=sc, shift=sh, pooled=pooled, act=act)
+    timeit("se_pool (+act)          20x3680x672", lambda: lib.call("se_pool", c, stream()), 2 * M * C * 2, 0)
+    st = torch.zeros(SLOTS, 2, C, device=dev); bn = torch.stack([sc, sh, mean, rstd]).contiguous()
+    d = cabi.make("mds_bn_bwd_reduce_args", dtype=1, M=M, C=C, g=cabi.gsrc(1, u), y=y, bn=bn, stats=st)
+    timeit("bn_bwd_reduce silu      20x3680x672", lambda: lib.call("bn_bwd_reduce", d, stream()), 2 * M * C * 2, 0)
+
+
 def bench_copy():
     n = 256 * 1024 * 1024
     a = torch.empty(n, device=dev, dtype=torch.uint8); b = torch.empty_like(a)
@@ -123,6 +144,8 @@ if __name__ == "__main__":
     for t in todo:
         if t == "copy":
             bench_copy()
+        elif t == "se":
+            bench_se()
         elif t.startswith("dw"):
             bench_dw(t)
         elif t.startswith("pw"):
