@@ -11,6 +11,7 @@
 //   * every global load of a K-chunk is issued at once into raw registers, and the NEXT chunk's
 //     loads are in flight while the current chunk's MFMAs run (register software pipeline);
 //   * LDS row pitch 272 B: the 16 rows of a fragment read land on 16 distinct 16-byte bank groups.
+#include <stdlib.h>
 #include "gemm.h"
 
 #define PW_BM 128
@@ -196,18 +197,33 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------ wgrad
+// dw[n][k] += sum_m dy[m][n] * pro(x)[m][k]: the MFMA reduction index is the row m, so both operands
+// are needed "transposed" (8 consecutive m per lane).  The staging pass transposes while writing to
+// LDS: element (channel c, row m) lives at c*LDT + 8*((m>>3) ^ ((c>>3)&7)) + (m&7) — bf16 rows are
+// written as (m, m+1) pairs in one dword, the XOR spreads the 8 channel-chunks of a wave over
+// distinct banks, and every fragment is ONE aligned 16-byte LDS read (was 8 two-byte reads, which
+// made this kernel LDS-issue bound).
 #define WG_ROWS 64  // rows staged per step (2 MFMA k-steps of 32 rows)
 #define WG_NT 128   // output-channel tile
 #define WG_KT 64    // input-channel tile
-#define WG_LDX (WG_KT + 2)   // pitch = 2 (mod 8): transposed fragment reads are bank-conflict free
-#define WG_LDY (WG_NT + 2)
+template <typename T> struct WgCfg;
+template <> struct WgCfg<bf16_t> { static const int MW = 2, LDT = WG_ROWS + 8; };
+template <> struct WgCfg<float> { static const int MW = 1, LDT = WG_ROWS + 4; };
+template <int LDT> MDS_DEV int wg_off(int c, int m) { return c * LDT + 8 * ((m >> 3) ^ ((c >> 3) & 7)) + (m & 7); }
+MDS_DEV void wg_put(bf16_t* base, int off, float v0, float v1) {
+  *(uint32_t*)(base + off) = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+}
+MDS_DEV void wg_put(float* base, int off, float v0, float) { base[off] = v0; }
 
 template <typename T, int PRO>
-__global__ __launch_bounds__(256) void pw_wgrad_kernel(mds_pw_wgrad_args a, int rows_per_block) {
+__global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, int rows_per_block) {
   typedef typename Frag<T>::type frag_t;
+  constexpr int MW = WgCfg<T>::MW, LDT = WgCfg<T>::LDT;
+  constexpr int XI = (WG_ROWS / MW) * (WG_KT / 8) / 256;   // x items per thread (1 bf16, 2 fp32)
+  constexpr int YI = (WG_ROWS / MW) * (WG_NT / 8) / 256;   // dy items per thread (2 bf16, 4 fp32)
   MDS_DYN_SMEM(smem);
-  T* xs = (T*)smem;               // [WG_ROWS][WG_LDX]
-  T* ds = xs + WG_ROWS * WG_LDX;  // [WG_ROWS][WG_LDY]
+  T* xsT = (T*)smem;               // [WG_KT][LDT]  channel-major
+  T* dsT = xsT + WG_KT * LDT;      // [WG_NT][LDT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int K = a.K, N = a.N;
@@ -219,11 +235,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(mds_pw_wgrad_args a, int 
   const T* x = (const T*)a.x;
   const T* dy = (const T*)a.dy;
 
-  // x staging: 8 chunks/row, 32 rows/pass, 2 passes ; dy staging: 16 chunks/row, 16 rows/pass, 4 passes
-  const int xc = tid & 7, xr = tid >> 3;
-  const int yc = tid & 15, yr = tid >> 4;
-  float sc[8], sh[8];
+  const int xc = tid & 7;           // x: 8 channel chunks per row(-pair); chunk fixed per thread
   const int kx = kt0 + 8 * xc;
+  float sc[8], sh[8];
   if (PRO != MDS_PRO_NONE && PRO != MDS_PRO_GATE && kx < K) { load8f(a.pro.scale + kx, sc); load8f(a.pro.shift + kx, sh); }
 
   f32x4 acc[2][4];  // wave owns n-fragments {2*wave, 2*wave+1} x 4 k-fragments
@@ -232,63 +246,81 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(mds_pw_wgrad_args a, int 
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (long mb = mbeg; mb < mend; mb += WG_ROWS) {
-    __syncthreads();
+  RawV8<T> rx[XI][MW], ry[YI][MW];
+  auto issue = [&](long mb) {   // every global load of one 64-row step
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int r = xr + 32 * p;
-      const long m = mb + r;
-      float v[8];
-      if (m < mend && kx < K) {
-        load8(x + m * K + kx, v);
-        if (PRO != MDS_PRO_NONE) {
+    for (int p = 0; p < XI; ++p)
+#pragma unroll
+      for (int h = 0; h < MW; ++h) {
+        const long m = mb + ((tid >> 3) + 32 * p) * MW + h;
+        if (m < mend && kx < K) rx[p][h].ld(x + m * K + kx); else rx[p][h].zero();
+      }
+#pragma unroll
+    for (int p = 0; p < YI; ++p)
+#pragma unroll
+      for (int h = 0; h < MW; ++h) {
+        const int it = tid + 256 * p;
+        const long m = mb + (it >> 4) * MW + h;
+        const int n = n0 + 8 * (it & 15);
+        if (m < mend && n < N) ry[p][h].ld(dy + m * N + n); else ry[p][h].zero();
+      }
+  };
+  issue(mbeg);
+  for (long mb = mbeg; mb < mend; mb += WG_ROWS) {
+    __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+    for (int p = 0; p < XI; ++p) {
+      float v[MW][8];
+#pragma unroll
+      for (int h = 0; h < MW; ++h) {
+        const long m = mb + ((tid >> 3) + 32 * p) * MW + h;
+        rx[p][h].get(v[h]);
+        if (PRO != MDS_PRO_NONE && m < mend && kx < K) {
           if (PRO != MDS_PRO_GATE) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              float z = v[j] * sc[j] + sh[j];
-              v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+              float z = v[h][j] * sc[j] + sh[j];
+              v[h][j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
             }
           }
           if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
             float g[8];
             load8f(a.pro.gate + (long)((unsigned)m / (unsigned)a.pro.rows_per_group) * K + kx, g);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= g[j];
+            for (int j = 0; j < 8; ++j) v[h][j] *= g[j];
           }
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
       }
-      lds_store8_u32(xs + r * WG_LDX + 8 * xc, v);
+      const int ml = ((tid >> 3) + 32 * p) * MW;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wg_put(xsT, wg_off<LDT>(8 * xc + j, ml), v[0][j], v[MW - 1][j]);
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = yr + 16 * p;
-      const long m = mb + r;
-      const int n = n0 + 8 * yc;
-      float v[8];
-      if (m < mend && n < N) {
-        load8(dy + m * N + n, v);
-      } else {
+    for (int p = 0; p < YI; ++p) {
+      const int it = tid + 256 * p;
+      float v[MW][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      }
-      lds_store8_u32(ds + r * WG_LDY + 8 * yc, v);
+      for (int h = 0; h < MW; ++h) ry[p][h].get(v[h]);
+      const int ml = (it >> 4) * MW, yc = it & 15;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wg_put(dsT, wg_off<LDT>(8 * yc + j, ml), v[0][j], v[MW - 1][j]);
     }
     __syncthreads();
+    if (mb + WG_ROWS < mend) issue(mb + WG_ROWS);   // next step's loads fly under this step's MFMAs
 #pragma unroll
     for (int ks = 0; ks < WG_ROWS / 32; ++ks) {
-      const int rb = 32 * ks + 8 * q;  // this lane's 8 rows (the MFMA k index)
+      const int g = 4 * ks + q;  // this lane's group of 8 rows (the MFMA k index)
       frag_t xf[4], yf[2];
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
+      for (int v = 0; v < 4; ++v) {
+        const int c = 16 * v + i;
+        xf[v] = ld_frag(xsT + c * LDT + 8 * (g ^ ((c >> 3) & 7)));
+      }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xf[v][j] = xs[(rb + j) * WG_LDX + 16 * v + i];
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) yf[u][j] = ds[(rb + j) * WG_LDY + 16 * (2 * wave + u) + i];
+      for (int u = 0; u < 2; ++u) {
+        const int c = 16 * (2 * wave + u) + i;
+        yf[u] = ld_frag(dsT + c * LDT + 8 * (g ^ ((c >> 3) & 7)));
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -316,13 +348,13 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   MDS_REQUIRE((a->pro.mode != MDS_PRO_BN_SILU_GATE && a->pro.mode != MDS_PRO_GATE) || (a->pro.gate && a->pro.rows_per_group > 0), "pw_wgrad: gate prologue");
   MDS_REQUIRE(a->M < 2147483647L, "pw_wgrad: M too large");
   const int tiles = cdiv(a->N, WG_NT) * cdiv(a->K, WG_KT);
-  long want_blocks = 1024 / tiles;
+  long want_blocks = (getenv("MDS_WG_BLOCKS") ? atoi(getenv("MDS_WG_BLOCKS")) : 1024) / tiles;
   if (want_blocks < 1) want_blocks = 1;
   long rpb = (a->M + want_blocks - 1) / want_blocks;
   rpb = ((rpb + WG_ROWS - 1) / WG_ROWS) * WG_ROWS;
   if (rpb < 4 * WG_ROWS) rpb = 4 * WG_ROWS;
   dim3 grid(cdiv(a->M, rpb), tiles), block(256);
-#define WG_GO(T, PRO) MDS_LAUNCH((pw_wgrad_kernel<T, PRO>), grid, block, (size_t)WG_ROWS * (WG_LDX + WG_LDY) * sizeof(T), stream, *a, (int)rpb)
+#define WG_GO(T, PRO) MDS_LAUNCH((pw_wgrad_kernel<T, PRO>), grid, block, (size_t)(WG_KT + WG_NT) * WgCfg<T>::LDT * sizeof(T), stream, *a, (int)rpb)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: WG_GO(T, MDS_PRO_NONE); break;
