@@ -41,14 +41,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(mds_stem_fwd_args a) {
     const int n = (int)(r / a.OH);
     const int ox = gx * 16 + i;
     frag_t xf;
+    float xv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int iy = oy * 2 + tky[j] - a.pad_t, ix = ox * 2 + tkx[j] - a.pad_l;
-      float v = 0.f;
+      xv[j] = 0.f;
       if (tp[j] >= 0 && ox < a.OW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-        v = a.x[(((long)n * 3 + tp[j]) * a.H + iy) * a.W + ix];
-      frag_set(xf, j, v);
+        xv[j] = a.x[(((long)n * 3 + tp[j]) * a.H + iy) * a.W + ix];
     }
+    frag_from8(xf, xv);
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     mma16(wf[0], xf, acc[0]);  // acc[r] = y[pixel i][oc = 4q + r]
     mma16(wf[1], xf, acc[1]);
@@ -121,24 +122,27 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(mds_stem_wgrad_args a) 
     const long rowb = ((long)n * a.OH + oy) * a.OW;
     frag_t yf[2], xf[2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < 2; ++f) {
+      float yv[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ox = oxb + j, oc = 16 * f + i;
-        float v = (ox < a.OW && oc < a.Cout) ? Elem<T>::ld(dy + (rowb + ox) * a.Cout + oc) : 0.f;
-        frag_set(yf[f], j, v);
+        yv[j] = (ox < a.OW && oc < a.Cout) ? Elem<T>::ld(dy + (rowb + ox) * a.Cout + oc) : 0.f;
       }
+      frag_from8(yf[f], yv);
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const int iy = oy * 2 + tky[g] - a.pad_t;
+      float xv[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ox = oxb + j, ix = ox * 2 + tkx[g] - a.pad_l;
-        float v = 0.f;
+        xv[j] = 0.f;
         if (tp[g] >= 0 && ox < a.OW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-          v = a.x[(((long)n * 3 + tp[g]) * a.H + iy) * a.W + ix];
-        frag_set(xf[g], j, v);
+          xv[j] = a.x[(((long)n * 3 + tp[g]) * a.H + iy) * a.W + ix];
       }
+      frag_from8(xf[g], xv);
     }
 #pragma unroll
     for (int f = 0; f < 2; ++f)

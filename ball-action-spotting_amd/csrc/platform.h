@@ -77,16 +77,23 @@ MDS_DEV void store8(float* p, const float (&v)[8]) {
   f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
   *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
 }
-MDS_DEV void store8(bf16_t* p, const float (&v)[8]) {
-  u16x8 a;
+// 8 floats -> 8 packed bf16: built as 4 dwords so each pair is ONE v_cvt_pk_bf16_f32
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+MDS_DEV u16x8 pack8(const float (&v)[8]) {
+  u32x4 w;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = f2bf(v[i]);
-  *(u16x8*)p = a;
+  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+  return __builtin_bit_cast(u16x8, w);
 }
+MDS_DEV void store8(bf16_t* p, const float (&v)[8]) { *(u16x8*)p = pack8(v); }
 MDS_DEV void load4(const float* p, float (&v)[4]) { f32x4 a = *(const f32x4*)p; v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
 MDS_DEV void load4(const bf16_t* p, float (&v)[4]) { u16x4 a = *(const u16x4*)p; for (int i = 0; i < 4; ++i) v[i] = bf2f(a[i]); }
 MDS_DEV void store4(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = a; }
-MDS_DEV void store4(bf16_t* p, const float (&v)[4]) { u16x4 a; for (int i = 0; i < 4; ++i) a[i] = f2bf(v[i]); *(u16x4*)p = a; }
+MDS_DEV void store4(bf16_t* p, const float (&v)[4]) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 w = {(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+  *(u32x2*)p = w;
+}
 
 // ------------------------------------------------------------------ MFMA tile op
 // One wave computes C[16x16] += A[16x32] * B[32x16].  Lane l = (i = l & 15, q = l >> 4) holds
@@ -159,8 +166,8 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
   hipemu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
 #endif
 
-MDS_DEV void frag_set(u16x8& f, int j, float v) { f[j] = f2bf(v); }
-MDS_DEV void frag_set(f32x8& f, int j, float v) { f[j] = v; }
+MDS_DEV void frag_from8(u16x8& f, const float (&v)[8]) { f = pack8(v); }
+MDS_DEV void frag_from8(f32x8& f, const float (&v)[8]) { f = (f32x8){v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}; }
 MDS_DEV void frag_zero(u16x8& f) { f = (u16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
 MDS_DEV void frag_zero(f32x8& f) { f = (f32x8){0, 0, 0, 0, 0, 0, 0, 0}; }
 
