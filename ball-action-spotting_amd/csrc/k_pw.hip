@@ -204,8 +204,8 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
 // distinct banks, and every fragment is ONE aligned 16-byte LDS read (was 8 two-byte reads, which
 // made this kernel LDS-issue bound).
 #define WG_ROWS 64  // rows staged per step (2 MFMA k-steps of 32 rows)
-#define WG_NT 128   // output-channel tile
-#define WG_KT 64    // input-channel tile
+// Output tile = (64*NF output channels) x (16*KF input channels); wave w owns n-fragments
+// {NF*w .. NF*w+NF-1} x all KF k-fragments (see the launcher for the measured choice of NF, KF).
 template <typename T> struct WgCfg;
 template <> struct WgCfg<bf16_t> { static const int MW = 2, LDT = WG_ROWS + 8; };
 template <> struct WgCfg<float> { static const int MW = 1, LDT = WG_ROWS + 4; };
@@ -215,126 +215,141 @@ MDS_DEV void wg_put(bf16_t* base, int off, float v0, float v1) {
 }
 MDS_DEV void wg_put(float* base, int off, float v0, float) { base[off] = v0; }
 
-template <typename T, int PRO>
+template <typename T, int PRO, int NF, int KF>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, int rows_per_block) {
   typedef typename Frag<T>::type frag_t;
   constexpr int MW = WgCfg<T>::MW, LDT = WgCfg<T>::LDT;
-  constexpr int XI = (WG_ROWS / MW) * (WG_KT / 8) / 256;   // x items per thread (1 bf16, 2 fp32)
-  constexpr int YI = (WG_ROWS / MW) * (WG_NT / 8) / 256;   // dy items per thread (2 bf16, 4 fp32)
+  constexpr int NT = 64 * NF, KT = 16 * KF, XCH = KT / 8, YCH = NT / 8;
+  constexpr int XN = (WG_ROWS / MW) * XCH, YN = (WG_ROWS / MW) * YCH;   // staging items (row-words x chunks)
+  constexpr int XI = (XN + 255) / 256, YI = (YN + 255) / 256;
   MDS_DYN_SMEM(smem);
-  T* xsT = (T*)smem;               // [WG_KT][LDT]  channel-major
-  T* dsT = xsT + WG_KT * LDT;      // [WG_NT][LDT]
+  T* xsT = (T*)smem;          // [KT][LDT]  channel-major
+  T* dsT = xsT + KT * LDT;    // [NT][LDT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int K = a.K, N = a.N;
-  const int ntiles_k = (K + WG_KT - 1) / WG_KT;
-  const int n0 = (blockIdx.y / ntiles_k) * WG_NT, kt0 = (blockIdx.y % ntiles_k) * WG_KT;
+  const int ntiles_k = (K + KT - 1) / KT;
+  const int n0 = (blockIdx.y / ntiles_k) * NT, kt0 = (blockIdx.y % ntiles_k) * KT;
   const long mbeg = (long)blockIdx.x * rows_per_block;
   long mend = mbeg + rows_per_block;
   if (mend > a.M) mend = a.M;
   const T* x = (const T*)a.x;
   const T* dy = (const T*)a.dy;
+  const int kfr = (K - kt0 >= KT) ? KF : ((K - kt0 + 15) >> 4);
 
-  const int xc = tid & 7;           // x: 8 channel chunks per row(-pair); chunk fixed per thread
-  const int kx = kt0 + 8 * xc;
+  // when 256 % XCH == 0 a thread keeps the same 8-channel slice for every staged item: its BN
+  // scale/shift live in registers for the whole kernel
+  constexpr bool FIXED_CH = (256 % XCH) == 0;
   float sc[8], sh[8];
-  if (PRO != MDS_PRO_NONE && PRO != MDS_PRO_GATE && kx < K) { load8f(a.pro.scale + kx, sc); load8f(a.pro.shift + kx, sh); }
+  if (FIXED_CH && PRO != MDS_PRO_NONE && PRO != MDS_PRO_GATE) {
+    const int kx = kt0 + 8 * (tid % XCH);
+    if (kx < K) { load8f(a.pro.scale + kx, sc); load8f(a.pro.shift + kx, sh); }
+  }
 
-  f32x4 acc[2][4];  // wave owns n-fragments {2*wave, 2*wave+1} x 4 k-fragments
+  f32x4 acc[NF][KF];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < NF; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < KF; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   RawV8<T> rx[XI][MW], ry[YI][MW];
   auto issue = [&](long mb) {   // every global load of one 64-row step
 #pragma unroll
-    for (int p = 0; p < XI; ++p)
+    for (int p = 0; p < XI; ++p) {
+      const int it = tid + 256 * p, kx = kt0 + 8 * (it % XCH);
 #pragma unroll
       for (int h = 0; h < MW; ++h) {
-        const long m = mb + ((tid >> 3) + 32 * p) * MW + h;
-        if (m < mend && kx < K) rx[p][h].ld(x + m * K + kx); else rx[p][h].zero();
+        const long m = mb + (it / XCH) * MW + h;
+        if (it < XN && m < mend && kx < K) rx[p][h].ld(x + m * K + kx); else rx[p][h].zero();
       }
+    }
 #pragma unroll
-    for (int p = 0; p < YI; ++p)
+    for (int p = 0; p < YI; ++p) {
+      const int it = tid + 256 * p, n = n0 + 8 * (it % YCH);
 #pragma unroll
       for (int h = 0; h < MW; ++h) {
-        const int it = tid + 256 * p;
-        const long m = mb + (it >> 4) * MW + h;
-        const int n = n0 + 8 * (it & 15);
-        if (m < mend && n < N) ry[p][h].ld(dy + m * N + n); else ry[p][h].zero();
+        const long m = mb + (it / YCH) * MW + h;
+        if (it < YN && m < mend && n < N) ry[p][h].ld(dy + m * N + n); else ry[p][h].zero();
       }
+    }
   };
   issue(mbeg);
   for (long mb = mbeg; mb < mend; mb += WG_ROWS) {
     __syncthreads();  // previous step's fragment reads are done
 #pragma unroll
     for (int p = 0; p < XI; ++p) {
-      float v[MW][8];
+      const int it = tid + 256 * p, xc = it % XCH, kx = kt0 + 8 * xc;
+      if (it < XN) {
+        float v[MW][8];
 #pragma unroll
-      for (int h = 0; h < MW; ++h) {
-        const long m = mb + ((tid >> 3) + 32 * p) * MW + h;
-        rx[p][h].get(v[h]);
-        if (PRO != MDS_PRO_NONE && m < mend && kx < K) {
-          if (PRO != MDS_PRO_GATE) {
+        for (int h = 0; h < MW; ++h) {
+          const long m = mb + (it / XCH) * MW + h;
+          rx[p][h].get(v[h]);
+          if (PRO != MDS_PRO_NONE && m < mend && kx < K) {
+            if (PRO != MDS_PRO_GATE) {
+              float scl[8], shl[8];
+              if (!FIXED_CH) { load8f(a.pro.scale + kx, scl); load8f(a.pro.shift + kx, shl); }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float z = v[h][j] * sc[j] + sh[j];
-              v[h][j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+              for (int j = 0; j < 8; ++j) {
+                float z = v[h][j] * (FIXED_CH ? sc[j] : scl[j]) + (FIXED_CH ? sh[j] : shl[j]);
+                v[h][j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+              }
+            }
+            if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
+              float g[8];
+              load8f(a.pro.gate + (long)((unsigned)m / (unsigned)a.pro.rows_per_group) * K + kx, g);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[h][j] *= g[j];
             }
           }
-          if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
-            float g[8];
-            load8f(a.pro.gate + (long)((unsigned)m / (unsigned)a.pro.rows_per_group) * K + kx, g);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[h][j] *= g[j];
-          }
         }
-      }
-      const int ml = ((tid >> 3) + 32 * p) * MW;
+        const int ml = (it / XCH) * MW;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wg_put(xsT, wg_off<LDT>(8 * xc + j, ml), v[0][j], v[MW - 1][j]);
+        for (int j = 0; j < 8; ++j) wg_put(xsT, wg_off<LDT>(8 * xc + j, ml), v[0][j], v[MW - 1][j]);
+      }
     }
 #pragma unroll
     for (int p = 0; p < YI; ++p) {
       const int it = tid + 256 * p;
-      float v[MW][8];
+      if (it < YN) {
+        float v[MW][8];
 #pragma unroll
-      for (int h = 0; h < MW; ++h) ry[p][h].get(v[h]);
-      const int ml = (it >> 4) * MW, yc = it & 15;
+        for (int h = 0; h < MW; ++h) ry[p][h].get(v[h]);
+        const int ml = (it / YCH) * MW, yc = it % YCH;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wg_put(dsT, wg_off<LDT>(8 * yc + j, ml), v[0][j], v[MW - 1][j]);
+        for (int j = 0; j < 8; ++j) wg_put(dsT, wg_off<LDT>(8 * yc + j, ml), v[0][j], v[MW - 1][j]);
+      }
     }
     __syncthreads();
     if (mb + WG_ROWS < mend) issue(mb + WG_ROWS);   // next step's loads fly under this step's MFMAs
 #pragma unroll
     for (int ks = 0; ks < WG_ROWS / 32; ++ks) {
       const int g = 4 * ks + q;  // this lane's group of 8 rows (the MFMA k index)
-      frag_t xf[4], yf[2];
+      frag_t yf[NF];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int c = 16 * v + i;
-        xf[v] = ld_frag(xsT + c * LDT + 8 * (g ^ ((c >> 3) & 7)));
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = 16 * (2 * wave + u) + i;
+      for (int u = 0; u < NF; ++u) {
+        const int c = 16 * (NF * wave + u) + i;
         yf[u] = ld_frag(dsT + c * LDT + 8 * (g ^ ((c >> 3) & 7)));
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int v = 0; v < KF; ++v) {
+        if (v < kfr) {   // k-fragments past K hold zeros: skip them (uniform)
+          const int c = 16 * v + i;
+          const frag_t xf = ld_frag(xsT + c * LDT + 8 * (g ^ ((c >> 3) & 7)));
 #pragma unroll
-        for (int v = 0; v < 4; ++v) mma16(yf[u], xf[v], acc[u][v]);  // acc[r] = dw[n = 4q + r][k = i]
+          for (int u = 0; u < NF; ++u) mma16(yf[u], xf, acc[u][v]);  // acc[r] = dw[n = 4q + r][k = i]
+        }
+      }
     }
   }
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < NF; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < KF; ++v) {
       const int k = kt0 + 16 * v + i;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 16 * (2 * wave + u) + 4 * q + r;
+        const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
         if (n < N && k < K) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r]);
       }
     }
@@ -347,14 +362,19 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || (a->pro.scale && a->pro.shift), "pw_wgrad: prologue needs scale/shift");
   MDS_REQUIRE((a->pro.mode != MDS_PRO_BN_SILU_GATE && a->pro.mode != MDS_PRO_GATE) || (a->pro.gate && a->pro.rows_per_group > 0), "pw_wgrad: gate prologue");
   MDS_REQUIRE(a->M < 2147483647L, "pw_wgrad: M too large");
-  const int tiles = cdiv(a->N, WG_NT) * cdiv(a->K, WG_KT);
-  long want_blocks = (getenv("MDS_WG_BLOCKS") ? atoi(getenv("MDS_WG_BLOCKS")) : 1024) / tiles;
+  // Tile shape (NF, KF) = (2, 4): 128 x 64.  Wider tiles — (2,12) full-K, (2,8), (3,8) — cut the PMC
+  // fetch from 2.6x to 1.5x of the algorithmic bytes but measured 15-80 % SLOWER (fewer blocks,
+  // 2 instead of 3-4 waves/SIMD): the re-reads are L2/Infinity-Cache hits and occupancy matters more.
+  const int NT = 128, KT = 64;
+  const int tiles = cdiv(a->N, NT) * cdiv(a->K, KT);
+  long want_blocks = 1024 / tiles;
   if (want_blocks < 1) want_blocks = 1;
   long rpb = (a->M + want_blocks - 1) / want_blocks;
   rpb = ((rpb + WG_ROWS - 1) / WG_ROWS) * WG_ROWS;
   if (rpb < 4 * WG_ROWS) rpb = 4 * WG_ROWS;
   dim3 grid(cdiv(a->M, rpb), tiles), block(256);
-#define WG_GO(T, PRO) MDS_LAUNCH((pw_wgrad_kernel<T, PRO>), grid, block, (size_t)(WG_KT + WG_NT) * WgCfg<T>::LDT * sizeof(T), stream, *a, (int)rpb)
+#define WG_GO(T, PRO) \
+  MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4>), grid, block, (size_t)(KT + NT) * WgCfg<T>::LDT * sizeof(T), stream, *a, (int)rpb)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: WG_GO(T, MDS_PRO_NONE); break;

@@ -83,6 +83,25 @@ def cpu_baseline(max_seconds=25.0):
             "sec_per_sample": round(sec, 3)}
 
 
+def pmc_traffic(kernel_key, dtype):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    very command, KiB units, FETCH_SIZE x2 on gfx950 — MI355X_MICROARCH.md §HBM).  PMC collection
+    cannot run inside the timed process, so the newest committed summary is reported; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    if not files or dtype != "bf16":
+        return None
+    ks = json.load(open(files[-1]))["kernels"]
+    base = kernel_key.split(".")[0] + "_kernel<unsigned short"
+    tot = calls = 0.0
+    for name, v in ks.items():
+        if base in name:
+            tot += v["hbm_bytes_per_launch"] * v["calls"]
+            calls += v["calls"]
+    return int(tot / calls) if calls else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,10 +194,11 @@ def main():
         avg_ms, avg_bytes, avg_flops = a[0] / a[1], a[2] / a[1], a[3] / a[1]
         gbs, tfl = avg_bytes / avg_ms / 1e6, avg_flops / avg_ms / 1e9
         hbm_bound = (avg_bytes / (HBM_PEAK_GBS * 1e9)) >= (avg_flops / (MFMA_PEAK_TFLOPS * 1e12))
+        traffic = pmc_traffic(dom, args.dtype)
         roofline = {"kernel": dom, "bound": "hbm" if hbm_bound else "mfma",
                     "achieved": round(gbs if hbm_bound else tfl, 2), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS,
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfl / MFMA_PEAK_TFLOPS), 4), "traffic": None,
+                    "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfl / MFMA_PEAK_TFLOPS), 4), "traffic": traffic,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a[1] // args.profile_steps,
                     "alg_bytes_per_launch": int(avg_bytes), "alg_flops_per_launch": int(avg_flops),
                     "share_of_kernel_time": round(a[0] / tot, 3),
