@@ -214,6 +214,279 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(mds_dw_fwd_args a, int nchu
   }
 }
 
+// ------------------------------------------------------------------------------------ 2D stride 1
+// The 3x3 stride-1 layers (all but two of the 2D depthwise convolutions) use a register
+// sliding-window formulation instead of LDS tiles: a lane owns a PAIR of channels (one dword of
+// bf16), a half-wave owns 64 consecutive channels (one 128-byte line per pixel), and a thread
+// walks a strip of R rows x L columns left to right keeping the (R+2) x 3 activated window in
+// registers.  Per column it issues R+2 loads (next column prefetched before the current one is
+// consumed), applies the producer's BN+SiLU once per element ((R+2)/R re-activation at the band
+// seams — same overhead as a tile halo) and does 9R packed FMAs.  ~100 VGPRs -> 4 waves/SIMD, no
+// __syncthreads in the main loop.  A block is 8 strips x 32 channel pairs; BN sums and filter
+// gradients are reduced over the 8 strips in LDS and flushed with coalesced atomics.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Pair;
+template <> struct Pair<bf16_t> {
+  typedef uint32_t raw_t;
+  static MDS_DEV raw_t ld(const bf16_t* p) { return *(const uint32_t*)p; }
+  static MDS_DEV f32x2 up(raw_t u) { return (f32x2){bits2f(u << 16), bits2f(u & 0xffff0000u)}; }
+  static MDS_DEV void st(bf16_t* p, f32x2 v) { *(uint32_t*)p = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); }
+};
+template <> struct Pair<float> {
+  typedef f32x2 raw_t;
+  static MDS_DEV raw_t ld(const float* p) { return *(const f32x2*)p; }
+  static MDS_DEV f32x2 up(raw_t u) { return u; }
+  static MDS_DEV void st(float* p, f32x2 v) { *(f32x2*)p = v; }
+};
+MDS_DEV f32x2 splat2(float v) { return (f32x2){v, v}; }
+MDS_DEV f32x2 sigmoid2(f32x2 z) {
+  f32x2 t = z * splat2(-1.4426950408889634f);
+#ifndef MDS_EMU
+  f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + splat2(1.0f);
+#else
+  f32x2 d = (f32x2){exp2f(t[0]), exp2f(t[1])} + splat2(1.0f);
+#endif
+  return (f32x2){fast_rcp(d[0]), fast_rcp(d[1])};
+}
+
+struct DwStrips { int nchunks, nseg, L, nbands, spt; long nstrips; };
+
+template <typename T, int R>
+__global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
+  constexpr int NR = R + 2;
+  typedef Pair<T> P;
+  typedef typename P::raw_t raw_t;
+  __shared__ float red[8][4][32];
+  const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
+  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const bool cvalid = c0 < C;
+  const int mode = a.pro.mode;
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
+  f32x2 w[3][3], sc = splat2(1.f), sh = splat2(0.f);
+  if (cvalid) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t / 3][t % 3] = (f32x2){a.w[(long)c0 * 9 + t], a.w[(long)(c0 + 1) * 9 + t]};
+    if (mode != MDS_PRO_NONE) { sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0); }
+  }
+  for (int k = 0; k < g.spt; ++k) {
+    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    if (!cvalid || strip >= g.nstrips) continue;
+    const int seg = (int)(strip % g.nseg);
+    const long bt = strip / g.nseg;
+    const int band = (int)(bt % g.nbands), img = (int)(bt / g.nbands);
+    const int oy0 = band * R, ox0 = seg * g.L;
+    const int nout = (a.OW - ox0 < g.L) ? a.OW - ox0 : g.L;
+    const T* xim = (const T*)a.x + (long)img * a.IH * a.IW * C + c0;
+    T* yim = (T*)a.y + ((long)img * a.OH + oy0) * a.OW * C + c0;
+    int roff[NR], rok = 0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int iy = oy0 - 1 + j;
+      rok |= (iy >= 0 && iy < a.IH) ? (1 << j) : 0;
+      roff[j] = clampi(iy, 0, a.IH - 1) * a.IW * C;
+    }
+    auto ldcol = [&](int ix, raw_t (&raw)[NR]) {
+      const int xo = clampi(ix, 0, a.IW - 1) * C;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) raw[j] = P::ld(xim + roff[j] + xo);
+    };
+    f32x2 win[NR][3];
+    auto push = [&](int ix, const raw_t (&raw)[NR]) {  // slide the window one column to the right
+      const bool cok = ix >= 0 && ix < a.IW;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        f32x2 v = P::up(raw[j]);
+        if (mode != MDS_PRO_NONE) {
+          v = v * sc + sh;
+          if (mode != MDS_PRO_AFFINE) v = v * sigmoid2(v);
+        }
+        const bool ok = cok && ((rok >> j) & 1);
+        win[j][0] = win[j][1]; win[j][1] = win[j][2];
+        win[j][2] = ok ? v : splat2(0.f);  // zero padding AFTER the activation
+      }
+    };
+    raw_t raw[NR], cur[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { win[j][1] = splat2(0.f); win[j][2] = splat2(0.f); }
+    ldcol(ox0 - 1, raw); push(ox0 - 1, raw);
+    ldcol(ox0, raw); push(ox0, raw);
+    ldcol(ox0 + 1, raw);
+#pragma unroll 3
+    for (int o = 0; o < nout; ++o) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) cur[j] = raw[j];
+      ldcol(ox0 + o + 2, raw);  // prefetch (clamped: always a legal address)
+      push(ox0 + o + 1, cur);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        f32x2 acc = splat2(0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc += win[r + ky][kx] * w[ky][kx];
+        if (oy0 + r < a.OH) {
+          P::st(yim + ((long)r * a.OW + ox0 + o) * C, acc);
+          s1 += acc; s2 += acc * acc;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    red[sl][0][cp] = s1[0]; red[sl][1][cp] = s1[1]; red[sl][2][cp] = s2[0]; red[sl][3][cp] = s2[1];
+    __syncthreads();
+    if (tid < 128) {
+      const int kk = tid >> 6, c = tid & 63;
+      float t = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+    }
+  }
+}
+
+// backward, same decomposition over INPUT pixels: window = dy rows iy-1..iy+R, cols ix-1..ix+1.
+//   da[iy][ix]   = sum_{ky,kx} dy[iy+1-ky][ix+1-kx] * w[ky][kx]
+//   dw[ky][kx]  += act[iy][ix] * dy[iy+1-ky][ix+1-kx]           (each input pixel owned by one thread)
+template <typename T, int R>
+__global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwStrips g) {
+  constexpr int NR = R + 2;
+  typedef Pair<T> P;
+  typedef typename P::raw_t raw_t;
+  __shared__ float dwl[8][9][64];
+  __shared__ float red[8][4][32];
+  const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
+  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const bool cvalid = c0 < C;
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
+  f32x2 w[3][3], dwacc[3][3], sc = splat2(0.f), sh = splat2(0.f), mu = splat2(0.f), rs = splat2(0.f);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) dwacc[t / 3][t % 3] = splat2(0.f);
+  if (cvalid) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t / 3][t % 3] = (f32x2){a.w[(long)c0 * 9 + t], a.w[(long)(c0 + 1) * 9 + t]};
+    sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0);
+    mu = *(const f32x2*)(a.mean + c0); rs = *(const f32x2*)(a.rstd + c0);
+  }
+  for (int k = 0; k < g.spt; ++k) {
+    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    if (!cvalid || strip >= g.nstrips) continue;
+    const int seg = (int)(strip % g.nseg);
+    const long bt = strip / g.nseg;
+    const int band = (int)(bt % g.nbands), img = (int)(bt / g.nbands);
+    const int iy0 = band * R, ix0 = seg * g.L;
+    const int ncol = (a.IW - ix0 < g.L) ? a.IW - ix0 : g.L;
+    const long ibase = (long)img * a.IH * a.IW * C + c0;  // OH == IH, OW == IW
+    const T* xim = (const T*)a.x + ibase;
+    const T* dyim = (const T*)a.dy + ibase;
+    T* gim = (T*)a.g + ibase;
+    int xoff[R], doff[NR], dok = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) xoff[r] = clampi(iy0 + r, 0, a.IH - 1) * a.IW * C;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int oy = iy0 - 1 + j;
+      dok |= (oy >= 0 && oy < a.OH) ? (1 << j) : 0;
+      doff[j] = clampi(oy, 0, a.OH - 1) * a.OW * C;
+    }
+    auto lddy = [&](int ox, raw_t (&raw)[NR]) {
+      const int xo = clampi(ox, 0, a.OW - 1) * C;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) raw[j] = P::ld(dyim + doff[j] + xo);
+    };
+    auto ldx = [&](int ix, raw_t (&raw)[R]) {
+      const int xo = clampi(ix, 0, a.IW - 1) * C;
+#pragma unroll
+      for (int r = 0; r < R; ++r) raw[r] = P::ld(xim + xoff[r] + xo);
+    };
+    f32x2 dyw[NR][3];
+    auto push = [&](int ox, const raw_t (&raw)[NR]) {
+      const bool cok = ox >= 0 && ox < a.OW;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const bool ok = cok && ((dok >> j) & 1);
+        dyw[j][0] = dyw[j][1]; dyw[j][1] = dyw[j][2];
+        dyw[j][2] = ok ? P::up(raw[j]) : splat2(0.f);
+      }
+    };
+    raw_t rdy[NR], cdy[NR], rx[R], cx[R];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { dyw[j][1] = splat2(0.f); dyw[j][2] = splat2(0.f); }
+    lddy(ix0 - 1, rdy); push(ix0 - 1, rdy);
+    lddy(ix0, rdy); push(ix0, rdy);
+    lddy(ix0 + 1, rdy); ldx(ix0, rx);
+#pragma unroll 3
+    for (int i = 0; i < ncol; ++i) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) cdy[j] = rdy[j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) cx[r] = rx[r];
+      lddy(ix0 + i + 2, rdy); ldx(ix0 + i + 1, rx);  // prefetch (clamped)
+      push(ix0 + i + 1, cdy);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool rok = iy0 + r < a.IH;
+        const f32x2 xv = P::up(cx[r]);
+        const f32x2 z = xv * sc + sh;
+        const f32x2 sg = sigmoid2(z);
+        const f32x2 act = rok ? z * sg : splat2(0.f);
+        f32x2 da = splat2(0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const f32x2 d = dyw[r + 2 - ky][2 - kx];
+            da += d * w[ky][kx];
+            dwacc[ky][kx] += d * act;
+          }
+        if (rok) {
+          const f32x2 gv = da * (sg * (splat2(1.0f) + z * (splat2(1.0f) - sg)));
+          P::st(gim + xoff[r] + (long)(ix0 + i) * C, gv);
+          s1 += gv; s2 += gv * (xv - mu);
+        }
+      }
+    }
+  }
+  s2 *= rs;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    *(f32x2*)&dwl[sl][t][2 * cp] = dwacc[t / 3][t % 3];
+  }
+  red[sl][0][cp] = s1[0]; red[sl][1][cp] = s1[1]; red[sl][2][cp] = s2[0]; red[sl][3][cp] = s2[1];
+  __syncthreads();
+  for (int e = tid; e < 64 * 9; e += 256) {
+    const int c = e / 9, t = e - c * 9;
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v += dwl[s][t][c];
+    if (cbeg + c < C) atomicAdd(a.dw + (long)cbeg * 9 + e, v);
+  }
+  if (tid < 128) {
+    const int kk = tid >> 6, c = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
+    if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+  }
+}
+
+// strips per launch: aim at >= one full round of the chip (256 CUs x 16 waves) before lengthening strips
+static DwStrips dw_strips(int images, int H, int W, int C, int R) {
+  DwStrips g;
+  g.nchunks = cdiv(C, 64);
+  g.nbands = cdiv(H, R);
+  int L = 16;
+  if (getenv("MDS_DW_L")) L = atoi(getenv("MDS_DW_L"));
+  else if ((long)images * g.nbands * cdiv(W, 16) * g.nchunks < 8192) L = 8;
+  g.nseg = cdiv(W, L);
+  g.L = cdiv(W, g.nseg);
+  g.nseg = cdiv(W, g.L);
+  g.nstrips = (long)images * g.nbands * g.nseg;
+  g.spt = 1;
+  if (getenv("MDS_DW_SPT")) g.spt = atoi(getenv("MDS_DW_SPT"));
+  return g;
+}
+
 extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->N > 0 && a->T > 0 && a->C % 8 == 0, "dw_fwd: bad dims");
   MDS_REQUIRE(a->kt == 1 || a->kt == 3, "dw_fwd: kt must be 1 or 3");
@@ -224,6 +497,13 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "dw_fwd: prologue");
   MDS_REQUIRE(a->pro.mode != MDS_PRO_BN_SILU_GATE, "dw_fwd: gate prologue unsupported");
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_fwd: grid.z");
+  if (a->kt == 1 && a->stride == 1 && !getenv("MDS_DW_OLD")) {
+    MDS_REQUIRE(a->pad_t == 1 && a->pad_l == 1 && a->OH == a->IH && a->OW == a->IW, "dw_fwd: stride-1 geometry");
+    const DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6);
+    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
+    return mds_check_launch("dw_fwd");
+  }
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     const int CC = DwCfg<T>::CC;
     const int nchunks = cdiv(a->C, CC);
@@ -459,6 +739,13 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_BN_SILU && a->pro.scale && a->pro.shift, "dw_bwd: needs the BN+SiLU prologue of the forward");
   MDS_REQUIRE(a->stride == 2 ? (a->pad_l == 0 || a->pad_l == 1) : (a->pad_l == 1 && a->pad_t == 1), "dw_bwd: pad=(%d,%d) unsupported for stride %d", a->pad_t, a->pad_l, a->stride);
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_bwd: grid.z");
+  if (a->kt == 1 && a->stride == 1 && !getenv("MDS_DW_OLD")) {
+    MDS_REQUIRE(a->OH == a->IH && a->OW == a->IW, "dw_bwd: stride-1 geometry");
+    const DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4);
+    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_bwd_kernel<T, 4>), grid, block, 0, stream, *a, g));
+    return mds_check_launch("dw_bwd");
+  }
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     const int CC = DwCfg<T>::CC;
     const int nchunks = cdiv(a->C, CC);

@@ -18,6 +18,7 @@ Reference mapping: forward_2d / forward_3d / forward_head of
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Dict, List, Optional
 
@@ -597,14 +598,50 @@ class Plan:
     def _stream(self):
         return torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
 
+    SIDE_OPS = ("pw_wgrad", "conv_wgrad", "stem_wgrad")
+
     def run(self, seg):
         if self.profile is not None:
             return self._run_profiled(seg)
         stream = self._stream()
+        side = self._side_stream() if seg[0] == "b" else None
+        if side is None:
+            for name, fn, st, ref in self.bound[seg]:
+                rc = fn(ref, stream)
+                if rc:
+                    self.lib.check(rc, name)
+            return
+        # Backward: the weight-gradient GEMMs are leaves of the dependency graph (they only add
+        # into the gradient arena), so they go to a second HIP stream and fill the CUs that the
+        # short dgrad / BN-backward launches of the critical path leave idle.
+        main = torch.cuda.current_stream()
+        side_h = side.cuda_stream
+        evs, n = self._side_events, 0
         for name, fn, st, ref in self.bound[seg]:
-            rc = fn(ref, stream)
+            if name in self.SIDE_OPS:
+                if n == len(evs):
+                    evs.append(torch.cuda.Event())
+                ev = evs[n]; n += 1
+                ev.record(main)
+                side.wait_event(ev)
+                rc = fn(ref, side_h)
+            else:
+                rc = fn(ref, stream)
             if rc:
                 self.lib.check(rc, name)
+
+    def join_backward(self):
+        """the gradient arena is complete once the side stream has drained"""
+        if getattr(self, "_side", None) is not None and self.profile is None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    def _side_stream(self):
+        if self.device.type != "cuda" or os.environ.get("MDS_SIDE_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._side_events = []
+        return self._side
 
     def _run_profiled(self, seg):
         """bench.py's per-kernel pass: a HIP event pair (on the launch stream) around every launch."""

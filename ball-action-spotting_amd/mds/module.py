@@ -60,6 +60,7 @@ class _MDSFunction(torch.autograd.Function):
         plan.dlogits.tensor.copy_(dlogits.reshape(-1).float())
         plan.begin_backward()
         plan.run("bhead"); plan.run("b3d"); plan.run("b2d")
+        plan.join_backward()
         flat = plan.grad_arena.tensor.clone()      # one launch; the arena is reused next step
         sync = getattr(ctx.module, "_grad_sync", None)
         if sync is not None:

@@ -27,6 +27,8 @@ def dw_ref(a, w, stride, kt, pads):
 
 DW_CASES = [  # N,T,H,W,C,stride,kt
     (2, 1, 9, 13, 48, 1, 1),
+    (1, 1, 14, 37, 72, 1, 1),     # several bands/segments, half-filled channel chunk
+    (3, 1, 5, 8, 136, 1, 1),
     (1, 1, 12, 18, 16, 2, 1),     # even: pad 0/1
     (2, 1, 11, 15, 24, 2, 1),     # odd: pad 1/1
     (2, 3, 5, 7, 24, 1, 3),
