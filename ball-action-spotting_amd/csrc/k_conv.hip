@@ -248,65 +248,109 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
 // The MFMA reduction index is the output point; a block walks `tiles_per_block` 8x16 patches and
 // keeps all 9 x Cin x 64 accumulators in registers (wave w owns taps w, w+4, w+8).
 #define CW_COT 64
-template <typename T, int PRO>
+// LDS images are [pixel][channel].  bf16 fragments (8 pixels of one channel per lane) come from two
+// transposing reads; a 32-lane LDS cycle touches 8 consecutive pixels x 32 bytes, conflict-free when
+// the pixel pitch is an odd multiple of 32 bytes.  fp32 has no transposing read: scalar gathers,
+// odd dword pitch.
+template <typename T> struct CwCfg;
+template <> struct CwCfg<float> {
+  static constexpr int LDY = CW_COT + 2;
+  static MDS_DEV int ldx(int Cin) { return Cin + 2; }
+  static MDS_DEV f32x8 frag(const float* base, int pitch, int pix_a, int pix_b, int pstep, int c0, int i) {
+    f32x8 f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[j] = base[(pix_a + j * pstep) * pitch + c0 + i];
+      f[4 + j] = base[(pix_b + j * pstep) * pitch + c0 + i];
+    }
+    return f;
+  }
+  static MDS_DEV void put8(float* dst, const float (&v)[8]) { lds_store8_u32(dst, v); }
+  static MDS_DEV void putraw(float* dst, const RawV8<float>& r) { float v[8]; r.get(v); lds_store8_u32(dst, v); }
+};
+template <> struct CwCfg<bf16_t> {
+  static constexpr int LDY = CW_COT + 16;
+  static MDS_DEV int ldx(int Cin) { return Cin == 32 ? 48 : Cin; }
+  static MDS_DEV u16x8 frag(const bf16_t* base, int pitch, int pix_a, int pix_b, int pstep, int c0, int i) {
+    const int off = (i >> 2) * pstep * pitch + c0 + 4 * (i & 3);
+    const u16x4 lo = lds_tr4(base + pix_a * pitch + off), hi = lds_tr4(base + pix_b * pitch + off);
+    return (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+  static MDS_DEV void put8(bf16_t* dst, const float (&v)[8]) { store8(dst, v); }
+  static MDS_DEV void putraw(bf16_t* dst, const RawV8<bf16_t>& r) { r.st(dst); }
+};
+static inline int cw_ldx(int dtype, int Cin) { return dtype == MDS_BF16 ? (Cin == 32 ? 48 : Cin) : Cin + 2; }
+static inline int cw_ldy(int dtype) { return dtype == MDS_BF16 ? CW_COT + 16 : CW_COT + 2; }
+
+template <typename T, int PRO, int CIFR, int COFR>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, int dymin, int dxmin, int TH, int TW,
                                                          int tiles_a, int tiles_b, int tiles_per_block) {
   typedef typename Frag<T>::type frag_t;
+  constexpr int NU = (9 * CIFR + 3) / 4;  // (tap, 16-input-channel fragment) units owned by a wave
   MDS_DYN_SMEM(smem);
   const int Cin = a.Cin, Cout = a.Cout;
-  const int LDX = Cin + 2, LDY = CW_COT + 2;
+  const int LDX = CwCfg<T>::ldx(Cin);
+  constexpr int LDY = CwCfg<T>::LDY;
   T* xs = (T*)smem;            // [TH*TW][LDX]
   T* dys = xs + TH * TW * LDX;  // [128][LDY]
   float* flush = (float*)(dys + 128 * LDY);  // [16][Cin*wtaps] filter-gradient staging
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int co0 = blockIdx.y * CW_COT;
-  const int cofr = (Cout - co0 >= CW_COT) ? 4 : ((Cout - co0) >> 4);
-  const int cifr = Cin >> 4;
+  const int cofr = (Cout - co0 >= 16 * COFR) ? COFR : ((Cout - co0) >> 4);
   const int cpp = Cin >> 3;  // 8-channel chunks per pixel
   const int npix = TH * TW;
   const long total_tiles = (long)a.N * tiles_a * tiles_b;
   long tl = (long)blockIdx.x * tiles_per_block;
   long tl_end = tl + tiles_per_block;
   if (tl_end > total_tiles) tl_end = total_tiles;
+  // unit u = wave + 4k -> (tap u / CIFR, fragment u % CIFR); tap offsets are wave-uniform scalars
+  // read ONCE (a per-lane index into the kernel-argument arrays inside the loop compiles to a
+  // dependent global load per tap — that alone was 2/3 of this kernel's time)
+  int utoff[NU], ukc[NU], uwi[NU];
+  bool uok[NU];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int u = wave + 4 * k;
+    uok[k] = u < a.ntaps * CIFR;
+    const int t = uok[k] ? u / CIFR : 0;
+    ukc[k] = 16 * (u % CIFR);
+    utoff[k] = (a.dy[t] - dymin) * TW + a.dx[t] - dxmin;
+    uwi[k] = a.wi[t];
+  }
 
-  f32x4 acc[3][3][4];
+  f32x4 acc[NU][COFR];
 #pragma unroll
-  for (int tt = 0; tt < 3; ++tt)
+  for (int k = 0; k < NU; ++k)
 #pragma unroll
-    for (int kf = 0; kf < 3; ++kf)
-#pragma unroll
-      for (int cf = 0; cf < 4; ++cf) acc[tt][kf][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cf = 0; cf < COFR; ++cf) acc[k][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (; tl < tl_end; ++tl) {
-    const int img = (int)(tl / (tiles_a * tiles_b));
-    const int rem = (int)(tl - (long)img * tiles_a * tiles_b);
-    const int a0 = (rem / tiles_b) * CV_TA, b0 = (rem % tiles_b) * CV_TB;
+  // Register software pipeline: the global loads of tile t+1 are in flight while tile t's MFMAs
+  // run (the kernel used to wait out a full memory latency per tile — it is latency-, not
+  // bandwidth-bound at these thin channel counts).
+  constexpr int XL = 9;  // staging items per thread: stride 2 -> 17x33 pixels x Cin/8 chunks / 256
+  RawV8<T> rx[XL], ry[4];
+  const int nitems = npix * cpp;
+  auto tile_origin = [&](long t, int& img, int& a0, int& b0) {
+    img = (int)(t / (tiles_a * tiles_b));
+    const int rem = (int)(t - (long)img * tiles_a * tiles_b);
+    a0 = (rem / tiles_b) * CV_TA; b0 = (rem % tiles_b) * CV_TB;
+  };
+  auto issue = [&](long t) {
+    int img, a0, b0;
+    tile_origin(t, img, a0, b0);
     const T* x = (const T*)a.x + (long)img * a.IH * a.IW * Cin;
     const T* dy = (const T*)a.dyt + (long)img * a.OH * a.OW * Cout;
-    __syncthreads();
-    for (int it = tid; it < npix * cpp; it += 256) {
-      const int pix = it / cpp, ch = it - pix * cpp;
-      const int ty = pix / TW, tx = pix - ty * TW;
-      const int iy = a0 * a.is + dymin + ty, ix = b0 * a.is + dxmin + tx;
-      float v[8];
-      if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
-        load8(x + ((long)iy * a.IW + ix) * Cin + 8 * ch, v);
-        if (PRO != MDS_PRO_NONE) {
-          float sc[8], sh[8];
-          load8f(a.pro.scale + 8 * ch, sc);
-          load8f(a.pro.shift + 8 * ch, sh);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float z = v[j] * sc[j] + sh[j];
-            v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int l = 0; l < XL; ++l) {
+      const int it = tid + 256 * l;
+      if (it < nitems) {
+        const int pix = it / cpp, ch = it - pix * cpp;
+        const int ty = pix / TW, tx = pix - ty * TW;
+        const int iy = a0 * a.is + dymin + ty, ix = b0 * a.is + dxmin + tx;
+        if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) rx[l].ld(x + ((long)iy * a.IW + ix) * Cin + 8 * ch);
+        else rx[l].zero();
       }
-      lds_store8_u32(xs + pix * LDX + 8 * ch, v);
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -314,43 +358,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
       const int pt = it >> 3, ch = it & 7;
       const int aa = a0 + (pt >> 4), bb = b0 + (pt & 15);
       const int co = co0 + 8 * ch;
-      float v[8];
-      if (aa < a.OH && bb < a.OW && co < Cout) {
-        load8(dy + ((long)aa * a.OW + bb) * Cout + co, v);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      }
-      lds_store8_u32(dys + pt * LDY + 8 * ch, v);
+      if (aa < a.OH && bb < a.OW && co < Cout) ry[p].ld(dy + ((long)aa * a.OW + bb) * Cout + co);
+      else ry[p].zero();
     }
+  };
+  if (tl < tl_end) issue(tl);
+  for (; tl < tl_end; ++tl) {
+    int img, a0, b0;
+    tile_origin(tl, img, a0, b0);
     __syncthreads();
-#pragma unroll 1
-    for (int s = 0; s < 4; ++s) {
-      const int al = 2 * s + (q >> 1), blb = 8 * (q & 1);
-      frag_t yf[4];
 #pragma unroll
-      for (int cf = 0; cf < 4; ++cf) {
-        if (cf < cofr) {
+    for (int l = 0; l < XL; ++l) {
+      const int it = tid + 256 * l;
+      if (it < nitems) {
+        const int pix = it / cpp, ch = it - pix * cpp;
+        if (PRO == MDS_PRO_NONE) {
+          CwCfg<T>::putraw(xs + pix * LDX + 8 * ch, rx[l]);
+        } else {
+          const int ty = pix / TW, tx = pix - ty * TW;
+          const int iy = a0 * a.is + dymin + ty, ix = b0 * a.is + dxmin + tx;
+          float v[8];
+          rx[l].get(v);
+          if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {  // zero padding stays zero
+            float sc[8], sh[8];
+            load8f(a.pro.scale + 8 * ch, sc);
+            load8f(a.pro.shift + 8 * ch, sh);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) yf[cf][j] = dys[(al * 16 + blb + j) * LDY + 16 * cf + i];
-        }
-      }
-#pragma unroll
-      for (int tt = 0; tt < 3; ++tt) {
-        const int t = wave + 4 * tt;
-        if (t < a.ntaps) {
-          const int pbase = (al * a.is + a.dy[t] - dymin) * TW + (blb * a.is + a.dx[t] - dxmin);
-#pragma unroll
-          for (int kf = 0; kf < 3; ++kf) {
-            if (kf < cifr) {
-              frag_t xf;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) xf[j] = xs[(pbase + j * a.is) * LDX + 16 * kf + i];
-#pragma unroll
-              for (int cf = 0; cf < 4; ++cf)
-                if (cf < cofr) mma16(yf[cf], xf, acc[tt][kf][cf]);  // acc[r] = dw[co = 4q + r][ci = i]
+            for (int j = 0; j < 8; ++j) {
+              float z = v[j] * sc[j] + sh[j];
+              v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
             }
           }
+          CwCfg<T>::put8(xs + pix * LDX + 8 * ch, v);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int it = tid + 256 * p;
+      CwCfg<T>::putraw(dys + (it >> 3) * LDY + 8 * (it & 7), ry[p]);
+    }
+    __syncthreads();
+    if (tl + 1 < tl_end) issue(tl + 1);
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+      // this 16-lane group's 8 output points: row al, columns ca..ca+3 and cb..cb+3
+      const int al = 2 * s + (q >> 1), ca = 4 * (q & 1), cb = 8 + ca;
+      frag_t yf[COFR];
+#pragma unroll
+      for (int cf = 0; cf < COFR; ++cf) yf[cf] = CwCfg<T>::frag(dys, LDY, al * 16 + ca, al * 16 + cb, 1, 16 * cf, i);
+      const int prow = al * a.is * TW;
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        if (uok[k]) {
+          const int pb = prow + utoff[k];
+          const frag_t xf = CwCfg<T>::frag(xs, LDX, pb + ca * a.is, pb + cb * a.is, a.is, ukc[k], i);
+#pragma unroll
+          for (int cf = 0; cf < COFR; ++cf) mma16(yf[cf], xf, acc[k][cf]);  // acc[r] = dw[co = 4q + r][ci = i]
         }
       }
     }
@@ -358,25 +422,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
   // flush: per 16-output-channel slab, transpose the accumulators through LDS into the parameter's
   // OIHW order and add them with coalesced atomics (one L2 transaction per 16 lanes, not per lane)
   const int slab = Cin * a.wtaps;  // floats per output channel
-  for (int cf = 0; cf < cofr; ++cf) {
+#pragma unroll
+  for (int cf = 0; cf < COFR; ++cf) {
+    if (cf >= cofr) break;
     __syncthreads();
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt) {
-      const int t = wave + 4 * tt;
-      if (t < a.ntaps) {
+    for (int k = 0; k < NU; ++k) {
+      if (uok[k]) {
 #pragma unroll
-        for (int kf = 0; kf < 3; ++kf) {
-          if (kf < cifr) {
-#pragma unroll
-            for (int cfi = 0; cfi < 4; ++cfi) {
-              if (cfi == cf) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  flush[(4 * q + r) * slab + (16 * kf + i) * a.wtaps + a.wi[t]] = acc[tt][kf][cfi][r];
-              }
-            }
-          }
-        }
+        for (int r = 0; r < 4; ++r) flush[(4 * q + r) * slab + (ukc[k] + i) * a.wtaps + uwi[k]] = acc[k][cf][r];
       }
     }
     __syncthreads();
@@ -396,6 +450,7 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
   const int eh = tap_extent(a->dy, a->ntaps, &dymin), ew = tap_extent(a->dx, a->ntaps, &dxmin);
   const int TH = (CV_TA - 1) * a->is + eh + 1, TW = (CV_TB - 1) * a->is + ew + 1;
   const int tiles_a = cdiv(a->OH, CV_TA), tiles_b = cdiv(a->OW, CV_TB);
+  MDS_REQUIRE(TH * TW * (a->Cin / 8) <= 9 * 256, "conv_wgrad: input patch %dx%dx%d exceeds the staging registers", TH, TW, a->Cin);
   const long total = (long)a->N * tiles_a * tiles_b;
   const int cot = cdiv(a->Cout, CW_COT);
   long want = 768 / cot;
@@ -403,11 +458,15 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
   int tpb = (int)((total + want - 1) / want);
   if (tpb < 1) tpb = 1;
   dim3 grid(cdiv(total, tpb), cot), block(256);
-#define CW_GO(T, PRO)                                                                                         \
-  MDS_LAUNCH((conv_wgrad_kernel<T, PRO>), grid, block,                                                        \
-             (size_t)(TH * TW * (a->Cin + 2) + 128 * (CW_COT + 2)) * sizeof(T) + (size_t)16 * a->Cin * a->wtaps * 4, \
-             stream, *a, dymin, dxmin, TH, TW, \
-             tiles_a, tiles_b, tpb)
+  MDS_REQUIRE(a->ntaps <= 9, "conv_wgrad: at most 9 taps");
+  const int cifr = a->Cin >> 4;
+  const size_t smem_elems = (size_t)TH * TW * cw_ldx(a->dtype, a->Cin) + 128 * cw_ldy(a->dtype);
+  const size_t smem_flush = (size_t)16 * a->Cin * a->wtaps * 4;
+#define CW_GO4(T, PRO, CI, CO)                                                                         \
+  MDS_LAUNCH((conv_wgrad_kernel<T, PRO, CI, CO>), grid, block, smem_elems * sizeof(T) + smem_flush, stream, *a, dymin, \
+             dxmin, TH, TW, tiles_a, tiles_b, tpb)
+#define CW_GO3(T, PRO, CI) do { if (a->Cout == 16) CW_GO4(T, PRO, CI, 1); else CW_GO4(T, PRO, CI, 4); } while (0)
+#define CW_GO(T, PRO) do { if (cifr == 1) CW_GO3(T, PRO, 1); else if (cifr == 2) CW_GO3(T, PRO, 2); else CW_GO3(T, PRO, 3); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: CW_GO(T, MDS_PRO_NONE); break;
@@ -415,6 +474,8 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
       default: CW_GO(T, MDS_PRO_BN_SILU); break;
     }
   });
+#undef CW_GO4
+#undef CW_GO3
 #undef CW_GO
   return mds_check_launch("conv_wgrad");
 }

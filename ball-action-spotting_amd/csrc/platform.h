@@ -116,6 +116,7 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
   for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
 }
 #define MDS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define MDS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  /* wave-uniform value -> scalar register */
 #define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 // gfx950 has 160 KiB of LDS per CU; launches above the 64 KiB default opt in once per kernel.
 #define MDS_LAUNCH(kernel, grid, block, smem, stream, ...)                                          \
@@ -161,9 +162,39 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
   mma16_emu(fa, fb, c, false);
 }
 #define MDS_SCHED_FENCE() ((void)0)
+#define MDS_UNIFORM(x) (x)
 #define MDS_DYN_SMEM(name) char* name = hipemu::dyn_smem()
 #define MDS_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipemu::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
+#endif
+
+// ------------------------------------------------------------------ transposing LDS read (gfx950)
+// ds_read_b64_tr_b16: every lane passes the (8-byte aligned) LDS address of 4 consecutive bf16;
+// within a 16-lane group, lane m's four values are row m>>2, columns 4(m&3)..4(m&3)+3 of a
+// [4][16] block, and lane i RECEIVES column i of that block (rows 0..3).  The rows may sit at
+// arbitrary addresses, so a [pixel][channel] image yields MFMA fragments whose reduction index is
+// the pixel — the weight-gradient GEMMs — in one instruction per 4 pixels (measured on hardware
+// with tmp probe; tests/test_k_conv.py covers it through conv_wgrad).
+#ifndef MDS_EMU
+MDS_DEV u16x4 lds_tr4(const bf16_t* p) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(u16x4, v);
+}
+#else
+MDS_DEV u16x4 lds_tr4(const bf16_t* p) {
+  const int lane = hipemu::lane_id();
+  hipemu::wave_scratch(lane)[0] = (uint64_t)(uintptr_t)p;
+  hipemu::wave_barrier();
+  const int i = lane & 15, g = lane & ~15;
+  u16x4 out;
+  for (int j = 0; j < 4; ++j) {
+    const bf16_t* src = (const bf16_t*)(uintptr_t)hipemu::wave_scratch(g + 4 * j + (i >> 2))[0];
+    out[j] = src[i & 3];
+  }
+  hipemu::wave_barrier();
+  return out;
+}
 #endif
 
 MDS_DEV void frag_from8(u16x8& f, const float (&v)[8]) { f = pack8(v); }

@@ -93,6 +93,8 @@ CONV_SHAPES = [(20, 368, 640, 32, 16, 1, 2, "b0.0 32->16"), (20, 368, 640, 16, 6
 
 def bench_conv(which):
     for (N, H, W, Cin, Cout, s, mode, tag) in CONV_SHAPES:
+        if os.environ.get("KB_MODE"):
+            mode = int(os.environ["KB_MODE"])
         OH, OW, pt, pl = geo.conv_geometry(H, W, s)
         dy_, dx_, wi = geo.taps_fwd(pt, pl)
         x = rnd(N * H * W, Cin); w = rnd(Cout * 9 * Cin)
