@@ -7,6 +7,7 @@
 // and zero padding applied after it — together with the weights of ALL taps, so the 9-tap MFMA
 // loop runs without a barrier: 2 barriers per chunk, 0.5 LDS fragment reads per MFMA.
 // Arithmetic intensity 100-600 FLOP/B: MFMA-bound layers.
+#include <stdlib.h>
 #include "gemm.h"
 
 #define CV_TB 16
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
   float* st_s = (float*)(ws + tg * CV_BN * LD);        // [CV_BN]
   float* st_ss = st_s + CV_BN;
   int* toff = (int*)(st_ss + CV_BN);                   // [ntaps] LDS element offset of each tap
+  int* twi = toff + MDS_MAX_TAPS;                      // [ntaps] weight slot of each tap
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -40,7 +42,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
   const T* x = (const T*)a.x + (long)img * a.IH * a.IW * Cin;
   const T* w = (const T*)a.w;
   T* y = (T*)a.y;
-  if (tid < a.ntaps) toff[tid] = ((a.dy[tid] - dymin) * TW + (a.dx[tid] - dxmin)) * LD;
+  if (tid < a.ntaps) {  // per-lane indices into the argument arrays are global loads: do them once
+    toff[tid] = ((a.dy[tid] - dymin) * TW + (a.dx[tid] - dxmin)) * LD;
+    twi[tid] = a.wi[tid];
+  }
+  __syncthreads();
   int xbase[MF];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) xbase[mf] = ((MF * wave + mf) * IS * TW + i * IS) * LD + 8 * q;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
             const int rr = it >> 2;                       // rr = tl * CV_BN + r
             const int t = t0 + (rr >> 6), r = rr & (CV_BN - 1);
             okw |= ((r < wrows && kk < Cin) ? 1u : 0u) << l;
-            if (r < wrows) rw[l].ld(w + ((long)(n0 + r) * a.wtaps + a.wi[t]) * Cin + (kk < Cin ? kk : 0));
+            if (r < wrows) rw[l].ld(w + ((long)(n0 + r) * a.wtaps + twi[t]) * Cin + (kk < Cin ? kk : 0));
           }
         }
       };
@@ -201,6 +207,188 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
   }
 }
 
+// ------------------------------------------------------------------------------------ persistent forward
+// Thin layers (K = ntaps*Cin <= 14 k-steps, the whole input patch of a tile in LDS) are latency-,
+// not bandwidth-bound with one tile per block: every block restaged the filter and waited out a
+// full memory latency.  Here a block keeps its 64-output-channel filter slab RESIDENT in LDS
+// ([n][k = tap*Cin + ch], one 16-byte fragment read per MFMA operand), walks a contiguous range of
+// tiles with the next tile's patch loads in flight under the current tile's MFMAs, and carries the
+// BatchNorm partial sums in registers until the end.  The k index is flattened over (tap, channel),
+// so Cin = 16 needs 5 k-steps for 9 taps instead of 9 half-empty ones.
+template <typename T, int PRO, int IS>
+__global__ __launch_bounds__(256, 2) void conv_fwd_p_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW,
+                                                            int tiles_a, int tiles_b, int tiles_per_block, int KS) {
+  typedef typename Frag<T>::type frag_t;
+  constexpr int MF = (IS == 1) ? 4 : 2, TA = 4 * MF, MAXX = 10;
+  MDS_DYN_SMEM(smem);
+  const int Cin = a.Cin, Cout = a.Cout, K = a.ntaps * Cin;
+  const int LDX = Cin + 8, LDW = KS * 32 + 8;
+  const int npix = TH * TW, cpp = Cin >> 3, nitems = npix * cpp;
+  T* xs = (T*)smem;                        // [npix][LDX]
+  T* ws = xs + npix * LDX;                 // [64][LDW]
+  float* st_s = (float*)(ws + CV_BN * LDW);  // [CV_BN]
+  float* st_ss = st_s + CV_BN;
+  int* ktab = (int*)(st_ss + CV_BN);       // [KS*4] LDS offset (tap shift + channel) of each 8-wide k chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * CV_BN;
+  const int nfr = (Cout - n0 >= CV_BN) ? 4 : ((Cout - n0) >> 4);
+  const T* w = (const T*)a.w;
+  T* y = (T*)a.y;
+  const float rTW = 1.0f / (float)TW, rcpp = 1.0f / (float)cpp;
+
+  for (int c = tid; c < KS * 4; c += 256) {
+    const int k = 8 * c;
+    int off = 0;
+    if (k < K) {
+      const int t = k / Cin, ch = k - t * Cin;
+      off = ((a.dy[t] - dymin) * TW + (a.dx[t] - dxmin)) * LDX + ch;
+    }
+    ktab[c] = off;
+  }
+  for (int e = tid; e < CV_BN * KS * 4; e += 256) {
+    const int n = e / (KS * 4), c = e - n * (KS * 4), k = 8 * c;
+    RawV8<T> r;
+    r.zero();
+    if (n < nfr * 16 && k < K) {
+      const int t = k / Cin, ch = k - t * Cin;
+      r.ld(w + ((long)(n0 + n) * a.wtaps + a.wi[t]) * Cin + ch);
+    }
+    r.st(ws + n * LDW + k);
+  }
+  if (tid < CV_BN) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
+
+  const long total_tiles = (long)a.N * tiles_a * tiles_b;
+  long tl = (long)blockIdx.x * tiles_per_block;
+  long tl_end = tl + tiles_per_block;
+  if (tl_end > total_tiles) tl_end = total_tiles;
+  int xbase[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) xbase[mf] = ((MF * wave + mf) * IS * TW + i * IS) * LDX;
+  const int wbase = i * LDW + 8 * q;
+
+  RawV8<T> rx[MAXX];
+  unsigned okx = 0;
+  auto origin = [&](long t, int& img, int& a0, int& b0) {
+    img = (int)(t / (tiles_a * tiles_b));
+    const int rem = (int)(t - (long)img * tiles_a * tiles_b);
+    a0 = (rem / tiles_b) * TA; b0 = (rem % tiles_b) * CV_TB;
+  };
+  auto issue = [&](long t) {
+    int img, a0, b0;
+    origin(t, img, a0, b0);
+    const T* x = (const T*)a.x + (long)img * a.IH * a.IW * Cin;
+    okx = 0;
+#pragma unroll
+    for (int l = 0; l < MAXX; ++l) {
+      const int it = tid + 256 * l;
+      if (it < nitems) {
+        const int pix = fdiv(it, rcpp), c8 = it - pix * cpp;
+        const int ty = fdiv(pix, rTW), tx = pix - ty * TW;
+        const int iy = a0 * IS + dymin + ty, ix = b0 * IS + dxmin + tx;
+        const bool ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+        okx |= (ok ? 1u : 0u) << l;
+        const int cy = iy < 0 ? 0 : (iy >= a.IH ? a.IH - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.IW ? a.IW - 1 : ix);
+        rx[l].ld(x + ((long)cy * a.IW + cx) * Cin + 8 * c8);
+      }
+    }
+  };
+  float ps[16], pss[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
+
+  if (tl < tl_end) issue(tl);
+  for (; tl < tl_end; ++tl) {
+    int img, a0, b0;
+    origin(tl, img, a0, b0);
+    __syncthreads();  // the previous tile's fragment reads are done (first pass: filter slab staged)
+#pragma unroll
+    for (int l = 0; l < MAXX; ++l) {
+      const int it = tid + 256 * l;
+      if (it < nitems) {
+        const int pix = fdiv(it, rcpp), c8 = it - pix * cpp;
+        const bool ok = (okx >> l) & 1u;
+        if (PRO == MDS_PRO_NONE) {
+          if (!ok) rx[l].zero();
+          rx[l].st(xs + pix * LDX + 8 * c8);
+        } else {
+          float v[8], sc[8], sh[8];
+          rx[l].get(v);
+          load8f(a.pro.scale + 8 * c8, sc);
+          load8f(a.pro.shift + 8 * c8, sh);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float z = v[j] * sc[j] + sh[j];
+            z = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+            v[j] = ok ? z : 0.f;  // zero padding AFTER the activation
+          }
+          store8(xs + pix * LDX + 8 * c8, v);
+          MDS_SCHED_FENCE();
+        }
+      }
+    }
+    __syncthreads();
+    if (tl + 1 < tl_end) issue(tl + 1);  // next patch flies under this tile's MFMAs
+
+    f32x4 acc[MF][4];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < KS; ++s) {
+      const int xo = ktab[4 * s + q];
+      frag_t xf[MF], wf[4];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) xf[mf] = ld_frag(xs + xbase[mf] + xo);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        if (nf < nfr) wf[nf] = ld_frag(ws + wbase + 16 * nf * LDW + 32 * s);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        if (nf < nfr) {
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) mma16(wf[nf], xf[mf], acc[mf][nf]);
+        }
+      }
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int aa = a0 + MF * wave + mf, bb = b0 + i;
+      const bool valid = aa < a.A && bb < a.B;
+      const long row = ((long)img * a.OH + (a.oy0 + aa * a.os)) * a.OW + (a.ox0 + bb * a.os);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        if (nf < nfr && valid) {
+          const int n = n0 + 16 * nf + 4 * q;
+          float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
+          if (a.residual) {
+            float rr[4];
+            load4((const T*)a.residual + row * Cout + n, rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+          }
+          store4(y + row * Cout + n, v);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[r]; pss[nf * 4 + r] += v[r] * v[r]; }
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    const int e = reduce_scatter16(ps, i);
+    reduce_scatter16(pss, i);
+    const int nl = 16 * (e >> 2) + 4 * q + (e & 3);
+    atomicAdd(&st_s[nl], ps[0]);
+    atomicAdd(&st_ss[nl], pss[0]);
+    __syncthreads();
+    if (tid < CV_BN && n0 + tid < Cout) {
+      float* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * Cout;
+      atomicAdd(st + n0 + tid, st_s[tid]);
+      atomicAdd(st + Cout + n0 + tid, st_ss[tid]);
+    }
+  }
+}
+
 static int tap_extent(const int* d, int n, int* dmin) {
   int lo = d[0], hi = d[0];
   for (int t = 1; t < n; ++t) { if (d[t] < lo) lo = d[t]; if (d[t] > hi) hi = d[t]; }
@@ -222,12 +410,40 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
   const int TA = a->is == 1 ? 16 : 8;
   const int TH = (TA - 1) * a->is + eh + 1, TW = (CV_TB - 1) * a->is + ew + 1;
   dim3 grid(cdiv(a->B, CV_TB), cdiv(a->A, TA), a->N), block(256);
+  {  // persistent variant when the filter slab + one whole-channel input patch fit in LDS
+    const int KS = cdiv(a->ntaps * a->Cin, 32);
+    const size_t esz = a->dtype == MDS_BF16 ? 2 : 4;
+    const size_t smem = ((size_t)TH * TW * (a->Cin + 8) + (size_t)CV_BN * (KS * 32 + 8)) * esz + 2 * CV_BN * sizeof(float) + (size_t)KS * 16;
+    if (TH * TW * (a->Cin / 8) <= 10 * 256 && smem <= 76 * 1024 && !getenv("MDS_CONV_OLD")) {  // two blocks per CU (measured: one resident block loses to the tile-per-block kernel)
+      const int tiles_a = cdiv(a->A, TA), tiles_b = cdiv(a->B, CV_TB);
+      const long total = (long)a->N * tiles_a * tiles_b;
+      const int nt = cdiv(a->Cout, CV_BN);
+      long want = (long)256 * 2 * 2 / nt;  // two balanced rounds of the chip at two blocks per CU
+      if (want < 1) want = 1;
+      const int tpb = (int)cdiv(total, want < total ? want : total);
+      dim3 pgrid(cdiv(total, tpb), nt);
+#define CVP_GO(T, PRO)                                                                                              \
+  do {                                                                                                              \
+    if (a->is == 1) MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 1>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
+    else MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 2>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
+  } while (0)
+      MDS_DISPATCH_DTYPE(a->dtype, T, {
+        switch (a->pro.mode) {
+          case MDS_PRO_NONE: CVP_GO(T, MDS_PRO_NONE); break;
+          case MDS_PRO_AFFINE: CVP_GO(T, MDS_PRO_AFFINE); break;
+          default: CVP_GO(T, MDS_PRO_BN_SILU); break;
+        }
+      });
+#undef CVP_GO
+      return mds_check_launch("conv_fwd");
+    }
+  }
 #define CV_GO(T, PRO)                                                                                   \
   do {                                                                                                  \
     const int LD = CvLd<T>::v;                                                                          \
     int tg = a->ntaps;  /* taps staged per barrier group: all of them unless LDS (160 KiB) says no */   \
     while (tg > 1 && (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) > 76 * 1024) tg = (tg > 3 ? 3 : tg - 1);     \
-    const size_t smem = (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) + 2 * CV_BN * sizeof(float) + 64; \
+    const size_t smem = (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) + 2 * CV_BN * sizeof(float) + 2 * MDS_MAX_TAPS * sizeof(int); \
     if (a->is == 1) MDS_LAUNCH((conv_fwd_kernel<T, PRO, 1>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
     else MDS_LAUNCH((conv_fwd_kernel<T, PRO, 2>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
   } while (0)
