@@ -355,6 +355,138 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
     }
 }
 
+// bf16 variant on the gfx950 transposing LDS read: the staged images stay in the natural
+// [row][channel] order (one 16-byte LDS store per loaded vector instead of eight transposing dword
+// stores, and no bf16->fp32->bf16 round trip without a prologue); a fragment — 8 rows of one
+// channel — is two ds_read_b64_tr_b16.  Row pitches are odd multiples of 32 bytes so the 8 rows a
+// 32-lane LDS cycle touches sit in distinct bank groups.
+template <int PRO, int NF, int KF>
+__global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a, int rows_per_block) {
+  typedef bf16_t T;
+  constexpr int NT = 64 * NF, KT = 16 * KF, XCH = KT / 8, YCH = NT / 8;
+  constexpr int LDX = KT + 16, LDY = NT + 16;           // elements; (KT+16)*2 B = odd * 32 B for KT % 32 == 0
+  constexpr int XN = WG_ROWS * XCH, YN = WG_ROWS * YCH;  // staging items (rows x 8-channel chunks)
+  constexpr int XI = (XN + 255) / 256, YI = (YN + 255) / 256;
+  MDS_DYN_SMEM(smem);
+  T* xs = (T*)smem;            // [WG_ROWS][LDX]
+  T* ds = xs + WG_ROWS * LDX;  // [WG_ROWS][LDY]
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int K = a.K, N = a.N;
+  const int ntiles_k = (K + KT - 1) / KT;
+  const int n0 = (blockIdx.y / ntiles_k) * NT, kt0 = (blockIdx.y % ntiles_k) * KT;
+  const long mbeg = (long)blockIdx.x * rows_per_block;
+  long mend = mbeg + rows_per_block;
+  if (mend > a.M) mend = a.M;
+  const T* x = (const T*)a.x;
+  const T* dy = (const T*)a.dy;
+  const int kfr = (K - kt0 >= KT) ? KF : ((K - kt0 + 15) >> 4);
+  constexpr bool FIXED_CH = (256 % XCH) == 0;
+  float sc[8], sh[8];
+  if (FIXED_CH && PRO != MDS_PRO_NONE && PRO != MDS_PRO_GATE) {
+    const int kx = kt0 + 8 * (tid % XCH);
+    if (kx < K) { load8f(a.pro.scale + kx, sc); load8f(a.pro.shift + kx, sh); }
+  }
+  f32x4 acc[NF][KF];
+#pragma unroll
+  for (int u = 0; u < NF; ++u)
+#pragma unroll
+    for (int v = 0; v < KF; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  RawV8<T> rx[XI], ry[YI];
+  auto issue = [&](long mb) {
+#pragma unroll
+    for (int p = 0; p < XI; ++p) {
+      const int it = tid + 256 * p, kx = kt0 + 8 * (it % XCH);
+      const long m = mb + it / XCH;
+      if (it < XN && m < mend && kx < K) rx[p].ld(x + m * K + kx); else rx[p].zero();
+    }
+#pragma unroll
+    for (int p = 0; p < YI; ++p) {
+      const int it = tid + 256 * p, n = n0 + 8 * (it % YCH);
+      const long m = mb + it / YCH;
+      if (it < YN && m < mend && n < N) ry[p].ld(dy + m * N + n); else ry[p].zero();
+    }
+  };
+  issue(mbeg);
+  // fragment rows of a 32-row k-step: 16-lane group q reads rows ra..ra+3 and ra+8..ra+11
+  const int ra = 16 * (q >> 1) + 4 * (q & 1);
+  const int lrow = (i >> 2), lcol = 4 * (i & 3);  // this lane's part of the 4x16 block it helps to gather
+  for (long mb = mbeg; mb < mend; mb += WG_ROWS) {
+    __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+    for (int p = 0; p < XI; ++p) {
+      const int it = tid + 256 * p, xc = it % XCH, kx = kt0 + 8 * xc, ml = it / XCH;
+      if (it < XN) {
+        if (PRO == MDS_PRO_NONE) {
+          rx[p].st(xs + ml * LDX + 8 * xc);
+        } else {
+          const long m = mb + ml;
+          float v[8];
+          rx[p].get(v);
+          if (m < mend && kx < K) {
+            if (PRO != MDS_PRO_GATE) {
+              float scl[8], shl[8];
+              if (!FIXED_CH) { load8f(a.pro.scale + kx, scl); load8f(a.pro.shift + kx, shl); }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                float z = v[j] * (FIXED_CH ? sc[j] : scl[j]) + (FIXED_CH ? sh[j] : shl[j]);
+                v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+              }
+            }
+            if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
+              float g[8];
+              load8f(a.pro.gate + (long)((unsigned)m / (unsigned)a.pro.rows_per_group) * K + kx, g);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] *= g[j];
+            }
+          }
+          store8(xs + ml * LDX + 8 * xc, v);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < YI; ++p) {
+      const int it = tid + 256 * p;
+      if (it < YN) ry[p].st(ds + (it / YCH) * LDY + 8 * (it % YCH));
+    }
+    __syncthreads();
+    if (mb + WG_ROWS < mend) issue(mb + WG_ROWS);   // next step's loads fly under this step's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < WG_ROWS / 32; ++ks) {
+      const int r0 = 32 * ks + ra + lrow;
+      u16x8 yf[NF];
+#pragma unroll
+      for (int u = 0; u < NF; ++u) {
+        const T* pcol = ds + 16 * (NF * wave + u) + lcol;
+        const u16x4 lo = lds_tr4(pcol + r0 * LDY), hi = lds_tr4(pcol + (r0 + 8) * LDY);
+        yf[u] = (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int v = 0; v < KF; ++v) {
+        if (v < kfr) {
+          const T* pcol = xs + 16 * v + lcol;
+          const u16x4 lo = lds_tr4(pcol + r0 * LDX), hi = lds_tr4(pcol + (r0 + 8) * LDX);
+          const u16x8 xf = (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int u = 0; u < NF; ++u) mma16(yf[u], xf, acc[u][v]);  // acc[r] = dw[n = 4q + r][k = i]
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NF; ++u)
+#pragma unroll
+    for (int v = 0; v < KF; ++v) {
+      const int k = kt0 + 16 * v + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
+        if (n < N && k < K) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r]);
+      }
+    }
+}
+
 extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_wgrad: bad dims");
   MDS_REQUIRE(a->K % 8 == 0 && a->N % 8 == 0, "pw_wgrad: K, N must be multiples of 8");
@@ -375,6 +507,20 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   dim3 grid(cdiv(a->M, rpb), tiles), block(256);
 #define WG_GO(T, PRO) \
   MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4>), grid, block, (size_t)(KT + NT) * WgCfg<T>::LDT * sizeof(T), stream, *a, (int)rpb)
+#define WGT_GO(PRO) \
+  MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4>), grid, block, (size_t)WG_ROWS * (KT + 16 + NT + 16) * sizeof(bf16_t), stream, *a, (int)rpb)
+  if (a->dtype == MDS_BF16 && !getenv("MDS_WG_OLD")) {
+    switch (a->pro.mode) {
+      case MDS_PRO_NONE: WGT_GO(MDS_PRO_NONE); break;
+      case MDS_PRO_AFFINE: WGT_GO(MDS_PRO_AFFINE); break;
+      case MDS_PRO_BN_SILU: WGT_GO(MDS_PRO_BN_SILU); break;
+      case MDS_PRO_BN_SILU_GATE: WGT_GO(MDS_PRO_BN_SILU_GATE); break;
+      case MDS_PRO_GATE: WGT_GO(MDS_PRO_GATE); break;
+      default: mds_set_error("pw_wgrad: prologue mode %d", a->pro.mode); return MDS_ERR_BAD_ARG;
+    }
+    return mds_check_launch("pw_wgrad");
+  }
+#undef WGT_GO
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: WG_GO(T, MDS_PRO_NONE); break;
