@@ -7,44 +7,31 @@ template <typename T> struct PwLd;           // LDS row pitch (elements): 16-byt
 template <> struct PwLd<bf16_t> { static const int v = PW_KC + 8; };
 template <> struct PwLd<float> { static const int v = PW_KC + 4; };
 
-// reduce-scatter of 32 per-lane partials over the 16 lanes sharing q: afterwards vals[0..1] hold
-// the 16-lane totals of entries e0, e0+1 with e0 = 16*b3 + 8*b2 + 4*b1 + 2*b0 (b = bits of i).
-MDS_DEV int reduce_scatter32(float (&vals)[32], int i) {
-  int e0 = 0;
+// reduce-scatter of N per-lane partials over the 16 lanes sharing q: afterwards vals[0..N/16-1] hold
+// the 16-lane totals of entries e0.. with e0 = (N/16) * (8*b3 + 4*b2 + 2*b1 + b0) (b = bits of i).
+template <int MASK, int HALF, int N>
+MDS_DEV void reduce_scatter_step(float (&vals)[N], bool bit) {
 #pragma unroll
-  for (int step = 0; step < 4; ++step) {
-    const int half = 16 >> step, mask = 8 >> step;
-    const bool bit = (i & mask) != 0;
-#pragma unroll
-    for (int k = 0; k < half; ++k) {
-      float lo = vals[k], hi = vals[k + half];
-      float send = bit ? lo : hi;
-      float keep = bit ? hi : lo;
-      vals[k] = keep + __shfl_xor(send, mask);
-    }
-    if (bit) e0 += half;
+  for (int k = 0; k < HALF; ++k) {
+    const float lo = vals[k], hi = vals[k + HALF];
+    const float send = bit ? lo : hi, keep = bit ? hi : lo;
+    vals[k] = keep + __shfl_xor(send, MASK);  // (the DPP row_xor<MASK> costs the MFMA kernels ~60 VGPRs here: spills)
   }
-  return e0;
 }
-
-
+MDS_DEV int reduce_scatter32(float (&vals)[32], int i) {
+  reduce_scatter_step<8, 16>(vals, (i & 8) != 0);
+  reduce_scatter_step<4, 8>(vals, (i & 4) != 0);
+  reduce_scatter_step<2, 4>(vals, (i & 2) != 0);
+  reduce_scatter_step<1, 2>(vals, (i & 1) != 0);
+  return ((i & 8) ? 16 : 0) + ((i & 4) ? 8 : 0) + ((i & 2) ? 4 : 0) + ((i & 1) ? 2 : 0);
+}
 // reduce-scatter of 16 per-lane partials over the 16 lanes sharing q; returns the entry index
 MDS_DEV int reduce_scatter16(float (&vals)[16], int i) {
-  int e0 = 0;
-#pragma unroll
-  for (int step = 0; step < 4; ++step) {
-    const int half = 8 >> step, mask = 8 >> step;
-    const bool bit = (i & mask) != 0;
-#pragma unroll
-    for (int k = 0; k < half; ++k) {
-      float lo = vals[k], hi = vals[k + half];
-      float send = bit ? lo : hi;
-      float keep = bit ? hi : lo;
-      vals[k] = keep + __shfl_xor(send, mask);
-    }
-    if (bit) e0 += half;
-  }
-  return e0;
+  reduce_scatter_step<8, 8>(vals, (i & 8) != 0);
+  reduce_scatter_step<4, 4>(vals, (i & 4) != 0);
+  reduce_scatter_step<2, 2>(vals, (i & 2) != 0);
+  reduce_scatter_step<1, 1>(vals, (i & 1) != 0);
+  return ((i & 8) ? 8 : 0) + ((i & 4) ? 4 : 0) + ((i & 2) ? 2 : 0) + ((i & 1) ? 1 : 0);
 }
 
 template <typename T> struct RawV8;   // 8 consecutive elements as loaded (no conversion yet)

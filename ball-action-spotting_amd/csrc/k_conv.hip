@@ -215,11 +215,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
 // tiles with the next tile's patch loads in flight under the current tile's MFMAs, and carries the
 // BatchNorm partial sums in registers until the end.  The k index is flattened over (tap, channel),
 // so Cin = 16 needs 5 k-steps for 9 taps instead of 9 half-empty ones.
-template <typename T, int PRO, int IS>
+template <typename T, int PRO, int IS, int MAXX>
 __global__ __launch_bounds__(256, 2) void conv_fwd_p_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW,
                                                             int tiles_a, int tiles_b, int tiles_per_block, int KS) {
   typedef typename Frag<T>::type frag_t;
-  constexpr int MF = (IS == 1) ? 4 : 2, TA = 4 * MF, MAXX = 10;
+  constexpr int MF = (IS == 1) ? 4 : 2, TA = 4 * MF;  // MAXX: patch vectors a thread keeps in flight
   MDS_DYN_SMEM(smem);
   const int Cin = a.Cin, Cout = a.Cout, K = a.ntaps * Cin;
   const int LDX = Cin + 8, LDW = KS * 32 + 8;
@@ -422,10 +422,12 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
       if (want < 1) want = 1;
       const int tpb = (int)cdiv(total, want < total ? want : total);
       dim3 pgrid(cdiv(total, tpb), nt);
+      const bool small = TH * TW * (a->Cin / 8) <= 6 * 256;
 #define CVP_GO(T, PRO)                                                                                              \
   do {                                                                                                              \
-    if (a->is == 1) MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 1>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
-    else MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 2>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
+    if (a->is == 1 && small) MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 1, 6>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
+    else if (a->is == 1) MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 1, 10>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
+    else MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 2, 10>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
   } while (0)
       MDS_DISPATCH_DTYPE(a->dtype, T, {
         switch (a->pro.mode) {

@@ -37,6 +37,11 @@ __global__ void pack_kernel(const mds_pack_job* jobs, int njobs) {
     return;
   }
   const int total = O * I * taps;
+  if (jb.kind == MDS_PACK_IO_F32) {
+    float* d32 = (float*)jb.dst;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < O * I; e += gridDim.x * blockDim.x) d32[e] = jb.src[(e % O) * I + e / O];
+    return;
+  }
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     // e indexes the destination
     if (jb.kind == MDS_PACK_OI) {
@@ -59,17 +64,38 @@ extern "C" int mds_pack_weights(const mds_pack_job* jobs_dev, int njobs, int max
 }
 
 // ------------------------------------------------------------------ BN finalize (fwd)
-__global__ void bn_finalize_kernel(mds_bn_finalize_args a) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && a.training && a.num_batches_tracked) *a.num_batches_tracked += 1;
-  if (c >= a.C) return;
+// 72 + 72 of these run per step between dependent kernels, so their latency is on the critical
+// path: a block handles 32 channels, 8 threads per channel each summing 4 of the 32 statistic slots
+// (all 8 loads independent and coalesced along c), then one LDS hop.
+#define FIN_CH 32
+static_assert(MDS_STAT_SLOTS == 32, "finalize kernels sum 8 groups of 4 slots");
+MDS_DEV void fin_slot_sums(const float* stats, int C, int c, int sg, double (&red)[2][8][FIN_CH], int cl) {
+  double s = 0.0, ss = 0.0;
+  if (c < C) {
+    float v[4], w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = stats[((sg * 4 + k) * 2 + 0) * C + c];
+      w[k] = stats[((sg * 4 + k) * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s += v[k]; ss += w[k]; }
+  }
+  red[0][sg][cl] = s; red[1][sg][cl] = ss;
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(mds_bn_finalize_args a) {
+  __shared__ double red[2][8][FIN_CH];
+  const int cl = threadIdx.x % FIN_CH, sg = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.training && a.num_batches_tracked) *a.num_batches_tracked += 1;
+  if (a.training) fin_slot_sums(a.stats, a.C, c, sg, red, cl);
+  __syncthreads();
+  if (sg != 0 || c >= a.C) return;
   float mean, var;
   if (a.training) {
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < MDS_STAT_SLOTS; ++k) {
-      s += a.stats[(k * 2 + 0) * a.C + c];
-      ss += a.stats[(k * 2 + 1) * a.C + c];
-    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
     double m = s / (double)a.count;
     double v = ss / (double)a.count - m * m;
     if (v < 0.0) v = 0.0;
@@ -95,90 +121,177 @@ extern "C" int mds_bn_finalize(const mds_bn_finalize_args* a, mds_stream_t strea
   MDS_REQUIRE(a && a->C > 0 && a->out && a->gamma && a->beta, "bn_finalize: bad args");
   MDS_REQUIRE(a->training ? (a->stats != 0 && a->count > 0) : (a->running_mean && a->running_var),
               "bn_finalize: missing stats / running buffers");
-  MDS_LAUNCH(bn_finalize_kernel, dim3(cdiv(a->C, 128)), dim3(128), 0, stream, *a);
+  MDS_LAUNCH(bn_finalize_kernel, dim3(cdiv(a->C, FIN_CH)), dim3(256), 0, stream, *a);
   return mds_check_launch("bn_finalize");
 }
 
 // ------------------------------------------------------------------ BN finalize (bwd)
-__global__ void bn_bwd_finalize_kernel(mds_bn_bwd_finalize_args a) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.C) return;
-  double sg = 0.0, sgx = 0.0;
-  for (int k = 0; k < MDS_STAT_SLOTS; ++k) {
-    sg += a.stats[(k * 2 + 0) * a.C + c];
-    sgx += a.stats[(k * 2 + 1) * a.C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mds_bn_bwd_finalize_args a) {
+  __shared__ double red[2][8][FIN_CH];
+  const int cl = threadIdx.x % FIN_CH, sg = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  fin_slot_sums(a.stats, a.C, c, sg, red, cl);
+  __syncthreads();
+  if (sg != 0 || c >= a.C) return;
+  double sg_ = 0.0, sgx = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sg_ += red[0][k][cl]; sgx += red[1][k][cl]; }
   if (a.dgamma) a.dgamma[c] += (float)sgx;
-  if (a.dbeta) a.dbeta[c] += (float)sg;
+  if (a.dbeta) a.dbeta[c] += (float)sg_;
   a.coef[0 * a.C + c] = a.gamma[c] * a.bn[3 * a.C + c];
-  a.coef[1 * a.C + c] = (float)(sg / (double)a.count);
+  a.coef[1 * a.C + c] = (float)(sg_ / (double)a.count);
   a.coef[2 * a.C + c] = (float)(sgx / (double)a.count);
 }
 extern "C" int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->C > 0 && a->stats && a->gamma && a->bn && a->coef && a->count > 0,
               "bn_bwd_finalize: bad args");
-  MDS_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(a->C, 128)), dim3(128), 0, stream, *a);
+  MDS_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(a->C, FIN_CH)), dim3(256), 0, stream, *a);
   return mds_check_launch("bn_bwd_finalize");
 }
 
 // ------------------------------------------------------------------ SE FCs
-// Latency-class: groups <= 44, C <= 1152, R <= 48.  One wave per (group, r) dot product for the
-// C-long reductions (coalesced, wave_sum); one thread per (group, c) / per c for the R-long ones.
-__global__ void se_fc1_kernel(mds_se_fc_fwd_args a) {
-  const int lane = threadIdx.x & 63;
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (e >= a.groups * a.R) return;
-  const int g = e / a.R, r = e % a.R;
-  const float* w = a.w1 + (long)r * a.C;
-  const float* p = a.pooled + (long)g * a.C;
-  float s = 0.f;
-  for (int c = lane; c < a.C; c += MDS_WAVE) s += w[c] * p[c];
-  s = wave_sum(s);
-  if (lane == 0) a.hidden[e] = s + a.b1[r];
+// Latency-class: groups <= 44, C <= 1152, R <= 64.  These used to be 2 + 4 dependent launches of
+// loops over R or over the groups, 6-22 us each (60 us of pure latency per SE block and step).
+// Now a block owns (group g, 256 channels); the R hidden values of its group are (re)computed by
+// the block itself in LDS — R dot products of length C, a few thousand MACs — which removes the
+// cross-block dependency, so the forward is ONE launch and the backward two.
+#define SE_RMAX 64
+#define SE_CCH 256
+
+// out[r] = sum_c w[r][c] * v[c] for all r < R at once: every thread walks its channels
+// (c = tid, tid + 256, ...) with R accumulators, so the R*C/256 loads of a thread are independent
+// and coalesced; then wave shuffles + one LDS hop.  (R dots done one after another by a wave cost
+// 40 us of dependent latency.)
+template <int RB>  // RB = R rounded up to 16: no per-r branches, so the loads stay back-to-back
+MDS_DEV void se_matvec_rc(const float* w, const float* v, int R, int C, float (&part)[4][SE_RMAX], float* out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float vc = v[c];
+    float wv[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) wv[r] = w[(long)(r < R ? r : R - 1) * C + c];  // rows past R: a legal dummy
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] += wv[r] * vc;
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const float s = wave_sum(acc[r]);
+    if (lane == 0) part[wave][r] = s;
+  }
+  __syncthreads();
+  if (tid < R) out[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  __syncthreads();
 }
-__global__ void se_fc2_kernel(mds_se_fc_fwd_args a) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= a.groups * a.C) return;
-  const int g = e / a.C, c = e % a.C;
-  const float* w = a.w2 + (long)c * a.R;
-  const float* h = a.hidden + (long)g * a.R;
+#define SE_DISPATCH_RB(R, ...)                                      \
+  do {                                                              \
+    if ((R) <= 16) { constexpr int RB = 16; __VA_ARGS__; }          \
+    else if ((R) <= 32) { constexpr int RB = 32; __VA_ARGS__; }     \
+    else if ((R) <= 48) { constexpr int RB = 48; __VA_ARGS__; }     \
+    else { constexpr int RB = 64; __VA_ARGS__; }                    \
+  } while (0)
+template <int RB>
+__global__ __launch_bounds__(256) void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
+  __shared__ float part[4][SE_RMAX], hid[SE_RMAX], act[SE_RMAX];
+  const int g = blockIdx.x, c = blockIdx.y * SE_CCH + threadIdx.x;
+  se_matvec_rc<RB>(a.w1, a.pooled + (long)g * a.C, a.R, a.C, part, hid);
+  if (threadIdx.x < a.R) {
+    const float h = hid[threadIdx.x] + a.b1[threadIdx.x];
+    act[threadIdx.x] = siluf_(h);
+    if (blockIdx.y == 0) a.hidden[g * a.R + threadIdx.x] = h;
+  }
+  __syncthreads();
+  if (c >= a.C) return;
   float s = a.b2[c];
-  for (int r = 0; r < a.R; ++r) s += w[r] * siluf_(h[r]);
-  a.gate[e] = sigmoidf_(s);
+  if (a.w2t) {
+#pragma unroll 12
+    for (int r = 0; r < a.R; ++r) s += a.w2t[(long)r * a.C + c] * act[r];
+  } else {
+    const float* w = a.w2 + (long)c * a.R;
+    for (int r = 0; r < a.R; ++r) s += w[r] * act[r];
+  }
+  a.gate[(long)g * a.C + c] = sigmoidf_(s);
 }
 extern "C" int mds_se_fc_fwd(const mds_se_fc_fwd_args* a, mds_stream_t stream) {
-  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->R > 0, "se_fc_fwd: bad dims");
+  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->R > 0 && a->R <= SE_RMAX, "se_fc_fwd: bad dims (R <= %d)", SE_RMAX);
   MDS_REQUIRE(a->pooled && a->w1 && a->b1 && a->w2 && a->b2 && a->hidden && a->gate, "se_fc_fwd: null pointer");
-  MDS_LAUNCH(se_fc1_kernel, dim3(cdiv(a->groups * a->R, 4)), dim3(256), 0, stream, *a);
-  MDS_LAUNCH(se_fc2_kernel, dim3(cdiv((long)a->groups * a->C, 256)), dim3(256), 0, stream, *a);
+  SE_DISPATCH_RB(a->R, MDS_LAUNCH(se_fc_fwd_kernel<RB>, dim3(a->groups, cdiv(a->C, SE_CCH)), dim3(256), 0, stream, *a));
   return mds_check_launch("se_fc_fwd");
 }
 
-// dhpre[g][r] = silu'(hidden) * sum_c de[g][c] * w2[c][r],  de = dgate * gate * (1 - gate)
-__global__ void se_bwd1_kernel(mds_se_fc_bwd_args a) {
-  const int lane = threadIdx.x & 63;
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (e >= a.groups * a.R) return;
-  const int g = e / a.R, r = e % a.R;
-  float s = 0.f;
-  for (int c = lane; c < a.C; c += MDS_WAVE) {
-    const float gt = a.gate[(long)g * a.C + c];
-    s += a.dgate[(long)g * a.C + c] * gt * (1.0f - gt) * a.w2[(long)c * a.R + r];
+// Backward, launch A — block (g, 256 channels):
+//   dhpre[g][r] = silu'(hidden[g][r]) * sum_c de[g][c] * w2[c][r],   de = dgate * gate * (1 - gate)
+//     (thread-per-channel partial sums over the contiguous w2 rows, reduced by wave shuffles + LDS)
+//   dpooled[g][c] = sum_r dhpre[g][r] * w1[r][c] / rows
+//   BatchNorm-backward sums of g = (u*gate + dpooled)*silu'(z) from the per-group partials of
+//   mds_se_bwd_reduce:  sum g = sum_grp gate*A1 + dpooled*A3 ;  sum g*xh = sum_grp gate*A2 + dpooled*A4
+template <int RB>
+__global__ __launch_bounds__(256) void se_bwd_a_kernel(mds_se_fc_bwd_args a) {
+  __shared__ float part[4][SE_RMAX], dh[SE_RMAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x, C = a.C, R = a.R;
+  if (a.w2t) {  // de[c] staged once, then the block-wide [R][C] mat-vec
+    __shared__ float de_s[2048];
+    for (int c = tid; c < C; c += 256) {
+      const float gt = a.gate[(long)g * C + c];
+      de_s[c] = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
+    }
+    __syncthreads();
+    se_matvec_rc<RB>(a.w2t, de_s, R, C, part, dh);
+    if (tid < R) {
+      const float v = dh[tid] * silu_gradf_(a.hidden[g * R + tid]);
+      dh[tid] = v;
+      if (blockIdx.y == 0) a.scratch[g * R + tid] = v;
+    }
+  } else {      // thread per channel over the contiguous w2 rows (strided across lanes: slow path)
+    float acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+    for (int c = tid; c < C; c += 256) {
+      const float gt = a.gate[(long)g * C + c];
+      const float de = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
+      const float* w = a.w2 + (long)c * R;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) acc[r] += de * w[r < R ? r : R - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const float s = wave_sum(acc[r]);
+      if (lane == 0) part[wave][r] = s;
+    }
+    __syncthreads();
+    if (tid < R) {
+      const float s = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+      const float v = s * silu_gradf_(a.hidden[g * R + tid]);
+      dh[tid] = v;
+      if (blockIdx.y == 0) a.scratch[g * R + tid] = v;
+    }
   }
-  s = wave_sum(s);
-  if (lane == 0) a.scratch[e] = s * silu_gradf_(a.hidden[e]);
-}
-// dpooled[g][c] = sum_r dhpre[g][r] * w1[r][c] / rows        (thread per (g, c))
-__global__ void se_bwd2_kernel(mds_se_fc_bwd_args a) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= a.groups * a.C) return;
-  const int g = e / a.C, c = e % a.C;
+  __syncthreads();
+  const int c = blockIdx.y * SE_CCH + tid;
+  if (c >= C) return;
   float dp = 0.f;
-  for (int r = 0; r < a.R; ++r) dp += a.scratch[g * a.R + r] * a.w1[(long)r * a.C + c];
-  a.dpooled[e] = dp / (float)a.rows_per_group;
+#pragma unroll 12
+  for (int r = 0; r < R; ++r) dp += dh[r] * a.w1[(long)r * C + c];
+  dp /= (float)a.rows_per_group;
+  a.dpooled[(long)g * C + c] = dp;
+  if (a.bnsums && a.bn_stats) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* b = a.bnsums + (long)g * a.bn_nblk * 4 * C + c;
+#pragma unroll 8
+    for (int k = 0; k < a.bn_nblk; ++k, b += 4 * C) {
+      s[0] += b[0]; s[1] += b[C]; s[2] += b[2 * C]; s[3] += b[3 * C];
+    }
+    const float gt = a.gate[(long)g * C + c];
+    atomicAdd(a.bn_stats + c, gt * s[0] + dp * s[2]);
+    atomicAdd(a.bn_stats + C + c, gt * s[1] + dp * s[3]);
+  }
 }
-// dw2[c][r], dw1[r][c] (thread per (r, c), c fastest); r == 0 threads also do db2[c]; block 0 db1
-__global__ void se_bwd3_kernel(mds_se_fc_bwd_args a) {
+// launch B — parameter gradients: dw2[c][r], dw1[r][c] (thread per (r, c), c fastest); r == 0
+// threads also do db2[c]; block 0 db1
+__global__ __launch_bounds__(256) void se_bwd_b_kernel(mds_se_fc_bwd_args a) {
   const int G = a.groups, C = a.C, R = a.R;
   if (blockIdx.x == 0) {
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
@@ -191,6 +304,7 @@ __global__ void se_bwd3_kernel(mds_se_fc_bwd_args a) {
   if (e >= R * C) return;
   const int r = e / C, c = e % C;
   float s2 = 0.f, s1 = 0.f, db2 = 0.f;
+#pragma unroll 4
   for (int g = 0; g < G; ++g) {
     const float gt = a.gate[(long)g * C + c];
     const float de = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
@@ -202,31 +316,12 @@ __global__ void se_bwd3_kernel(mds_se_fc_bwd_args a) {
   a.dw1[(long)r * C + c] += s1;
   if (r == 0) a.db2[c] += db2;
 }
-// BatchNorm-backward sums of g = (u*gate + dpooled)*silu'(z) from the per-group partials of
-// mds_se_bwd_reduce:  sum g = sum_grp gate*A1 + dpooled*A3 ;  sum g*xh = sum_grp gate*A2 + dpooled*A4
-__global__ void se_bwd4_kernel(mds_se_fc_bwd_args a) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (group, channel)
-  if (e >= a.groups * a.C) return;
-  const int g = e / a.C, c = e % a.C;
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* b = a.bnsums + (long)g * a.bn_nblk * 4 * a.C + c;
-  for (int k = 0; k < a.bn_nblk; ++k, b += 4 * a.C) {
-    s[0] += b[0]; s[1] += b[a.C]; s[2] += b[2 * a.C]; s[3] += b[3 * a.C];
-  }
-  const float gt = a.gate[e], dp = a.dpooled[e];
-  atomicAdd(a.bn_stats + c, gt * s[0] + dp * s[2]);
-  atomicAdd(a.bn_stats + a.C + c, gt * s[1] + dp * s[3]);
-}
 extern "C" int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
-  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->R > 0 && a->rows_per_group > 0, "se_fc_bwd: bad dims");
+  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->C <= 2048 && a->R > 0 && a->R <= SE_RMAX && a->rows_per_group > 0, "se_fc_bwd: bad dims (R <= %d, C <= 2048)", SE_RMAX);
   MDS_REQUIRE(a->scratch && a->dgate && a->gate && a->hidden && a->pooled && a->dpooled, "se_fc_bwd: null pointer");
-  MDS_LAUNCH(se_bwd1_kernel, dim3(cdiv(a->groups * a->R, 4)), dim3(256), 0, stream, *a);
-  MDS_LAUNCH(se_bwd2_kernel, dim3(cdiv((long)a->groups * a->C, 256)), dim3(256), 0, stream, *a);
-  MDS_LAUNCH(se_bwd3_kernel, dim3(cdiv((long)a->R * a->C, 256)), dim3(256), 0, stream, *a);
-  if (a->bnsums && a->bn_stats) {
-    MDS_REQUIRE(a->bn_nblk > 0, "se_fc_bwd: bn_nblk");
-    MDS_LAUNCH(se_bwd4_kernel, dim3(cdiv((long)a->groups * a->C, 256)), dim3(256), 0, stream, *a);
-  }
+  MDS_REQUIRE(!(a->bnsums && a->bn_stats) || a->bn_nblk > 0, "se_fc_bwd: bn_nblk");
+  SE_DISPATCH_RB(a->R, MDS_LAUNCH(se_bwd_a_kernel<RB>, dim3(a->groups, cdiv(a->C, SE_CCH)), dim3(256), 0, stream, *a));
+  MDS_LAUNCH(se_bwd_b_kernel, dim3(cdiv((long)a->R * a->C, 256)), dim3(256), 0, stream, *a);
   return mds_check_launch("se_fc_bwd");
 }
 

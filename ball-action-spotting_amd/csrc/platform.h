@@ -203,16 +203,45 @@ MDS_DEV void frag_zero(u16x8& f) { f = (u16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
 MDS_DEV void frag_zero(f32x8& f) { f = (f32x8){0, 0, 0, 0, 0, 0, 0, 0}; }
 
 // ------------------------------------------------------------------ wave / block reductions
+// Cross-lane exchange inside a 16-lane row runs on the VALU's DPP path (one 4-cycle op: quad_perm
+// for xor 1/2, two bank-masked row shifts for xor 4, row_ror:8 for xor 8) — __shfl_xor compiles to
+// ds_bpermute_b32, an LDS-crossbar instruction, and the statistic epilogues issued 30+ of them per
+// tile.  Semantics checked on hardware (row_shl:n -> lane i receives lane i+n).
+#ifndef MDS_EMU
+template <int CTRL, int BANK = 0xF>
+MDS_DEV float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xF, BANK, false));
+}
+template <int M> MDS_DEV float row_xor(float v);  // value of lane (i ^ M), M < 16
+template <> MDS_DEV float row_xor<1>(float v) { return dpp_f<0xB1>(v, v); }
+template <> MDS_DEV float row_xor<2>(float v) { return dpp_f<0x4E>(v, v); }
+template <> MDS_DEV float row_xor<4>(float v) { return dpp_f<0x114, 0xA>(dpp_f<0x104, 0x5>(v, v), v); }
+template <> MDS_DEV float row_xor<8>(float v) { return dpp_f<0x128>(v, v); }
+// sum over the 16 lanes that share q = lane >> 4 (i.e. over i = lane & 15); every lane gets it
+MDS_DEV float sum_over_i16(float v) {
+  v += dpp_f<0xB1>(v, v); v += dpp_f<0x4E>(v, v);
+  v += dpp_f<0x141>(v, v);  // row_half_mirror: pairs the two quads of each half row
+  v += dpp_f<0x140>(v, v);  // row_mirror: pairs the half rows
+  return v;
+}
+MDS_DEV float wave_sum(float v) {
+  v = sum_over_i16(v);
+  const int u = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48)));
+}
+#else
+template <int M> MDS_DEV float row_xor(float v) { return __shfl_xor(v, M); }
+MDS_DEV float sum_over_i16(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
 MDS_DEV float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
   return v;
 }
-// sum over the 16 lanes that share q = lane >> 4 (i.e. over i = lane & 15)
-MDS_DEV float sum_over_i16(float v) {
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-  return v;
-}
+#endif
 
 // ------------------------------------------------------------------ error plumbing (C ABI)
 void mds_set_error(const char* fmt, ...);

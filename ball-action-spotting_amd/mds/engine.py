@@ -218,7 +218,7 @@ class Plan:
 
     def pack(self, param, kind, O, I, taps):
         n = O * 32 if kind == cabi.MDS_PACK_STEM else O * I * taps
-        dst = self._own(n, self.tdt)
+        dst = self._own(n, torch.float32 if kind == cabi.MDS_PACK_IO_F32 else self.tdt)
         self.pack_jobs.append((param, dst, kind, O, I, taps))
         return dst
 
@@ -339,8 +339,10 @@ class Plan:
                 shift=bn2.shift, pooled=pooled, act=a2)
         gate_pro = dict(mode=PRO_GATE, scale=None, shift=None, gate=gate, rows_per_group=rpg)
         se = blk.se
+        w2t = self.pack(se.conv_expand.weight, cabi.MDS_PACK_IO_F32, mid, R, 1)    # [R][mid], fp32
         self.op(fseg, "se_fc_fwd", groups=groups, C=mid, R=R, pooled=pooled, w1=P(se.conv_reduce.weight),
-                b1=P(se.conv_reduce.bias), w2=P(se.conv_expand.weight), b2=P(se.conv_expand.bias), hidden=hidden, gate=gate)
+                b1=P(se.conv_reduce.bias), w2=P(se.conv_expand.weight), b2=P(se.conv_expand.bias), hidden=hidden, gate=gate,
+                w2t=w2t)
         y3 = self._pw(fseg, a2, Mout, mid, cout, blk.conv_pwl.weight, pro=gate_pro, stats_bn=bn3)
         mask = self.mask(groups, blk.dpr) if has_skip else None
         xout = self.act(Mout, cout)
@@ -365,7 +367,7 @@ class Plan:
             self.op(seg, "se_fc_bwd", groups=groups, C=mid, R=R, rows_per_group=rpg, dgate=dgate, gate=gate, hidden=hidden,
                     pooled=pooled, w1=P(se.conv_reduce.weight), w2=P(se.conv_expand.weight), dpooled=dpool,
                     scratch=self.f32(groups * R), dw1=sg[0], db1=sg[1], dw2=sg[2], db2=sg[3],
-                    bnsums=bnsums, bn_nblk=nblk, bn_stats=bn2.bstats)
+                    bnsums=bnsums, bn_nblk=nblk, bn_stats=bn2.bstats, w2t=w2t)
             dy2 = self.act(Mout, mid)
             bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, reduce=False, frozen=frozen)
             g1 = self.act(Min, mid)

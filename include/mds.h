@@ -249,6 +249,8 @@ typedef struct {
   const float* b2;      /* [C]    */
   float* hidden;        /* [groups][R] pre-activation */
   float* gate;          /* [groups][C] */
+  const float* w2t;     /* optional [R][C] copy of w2 (MDS_PACK_IO_F32): lets the C-long dimension be
+                           the coalesced one; without it the kernels walk w2 rows (slower)          */
 } mds_se_fc_fwd_args;
 int mds_se_fc_fwd(const mds_se_fc_fwd_args* a, mds_stream_t stream);
 
@@ -296,6 +298,7 @@ typedef struct {
   const float* bnsums; /* optional [groups][bn_nblk][4][C] from mds_se_bwd_reduce                  */
   int bn_nblk;         /* = mds_se_bwd_reduce_blocks(rows_per_group, C)                            */
   float* bn_stats;     /* optional [SLOTS][2][C] (zeroed): slot 0 receives sum g, sum g*xhat       */
+  const float* w2t;    /* optional [R][C] copy of w2, see mds_se_fc_fwd_args                       */
 } mds_se_fc_bwd_args;
 int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream);
 
@@ -415,6 +418,7 @@ int mds_head_bwd(const mds_head_bwd_args* a, mds_stream_t stream);
 #define MDS_PACK_OI 0      /* [O][I][taps] -> [O][taps][I]   (1x1: taps = 1; conv fwd)         */
 #define MDS_PACK_IO_FLIP 1 /* [O][I][taps] -> [I][taps-1-t][O] (data-gradient pack)            */
 #define MDS_PACK_STEM 2    /* [O][3][3][3] -> [O][32] zero padded                              */
+#define MDS_PACK_IO_F32 3  /* [O][I] -> [I][O], kept in fp32 whatever `dtype` (squeeze-excite w2) */
 typedef struct {
   const float* src;
   void* dst;

@@ -72,10 +72,12 @@ def test_bn_res(be, dt, M, C, act, use_mask, use_sc):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-def test_se_forward_backward(be, dt):
-    """se_pool + se_fc_fwd + (gated consumer) and the SE backward chain vs autograd."""
+@pytest.mark.parametrize("packed,C,RD", [(True, 48, 12), (False, 48, 12), (True, 328, 28)])
+def test_se_forward_backward(be, dt, packed, C, RD):
+    """se_pool + se_fc_fwd + (gated consumer) and the SE backward chain vs autograd; with and without
+    the packed [R][C] copy of w2 (made by pack_weights / MDS_PACK_IO_F32)."""
     code, tdt = DT[dt]
-    G, R_, C, RD = 3, 70, 48, 12
+    G, R_ = 3, 70
     M = G * R_
     g = gen(5)
     y = torch.randn(M, C, generator=g).to(tdt)
@@ -100,8 +102,16 @@ def test_se_forward_backward(be, dt):
                                  scale=scd, shift=shd, pooled=pooled))
     hidden = torch.empty(G, RD, device=be.device); gate = torch.empty(G, C, device=be.device)
     w1d, b1d, w2d, b2d = be.t(w1), be.t(b1), be.t(w2), be.t(b2)
+    w2t = None
+    if packed:
+        w2t = torch.full((RD, C), float("nan"), device=be.device)
+        job = cabi.make("mds_pack_job", src=w2d, dst=w2t, kind=cabi.MDS_PACK_IO_F32, O=C, I=RD, taps=1)
+        raw = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(be.device)
+        be.lib.check(be.lib.fn["pack_weights"](raw.data_ptr(), 1, C * RD, code, be.stream()), "pack_weights")
+        be.sync()
+        assert torch.equal(w2t.cpu(), w2.t().contiguous())
     be.call("se_fc_fwd", cabi.make("mds_se_fc_fwd_args", groups=G, C=C, R=RD, pooled=pooled, w1=w1d, b1=b1d,
-                                   w2=w2d, b2=b2d, hidden=hidden, gate=gate))
+                                   w2=w2d, b2=b2d, hidden=hidden, gate=gate, w2t=w2t))
     dgate = torch.zeros(G, C, device=be.device)
     be.call("se_bwd_reduce", cabi.make("mds_se_bwd_reduce_args", dtype=code, groups=G, rows_per_group=R_, C=C,
                                        u=ud, y=yd, scale=scd, shift=shd, dgate=dgate))
@@ -110,7 +120,8 @@ def test_se_forward_backward(be, dt):
     dw2 = torch.zeros(C, RD, device=be.device); db2 = torch.zeros(C, device=be.device)
     be.call("se_fc_bwd", cabi.make("mds_se_fc_bwd_args", groups=G, C=C, R=RD, rows_per_group=R_, dgate=dgate,
                                    gate=gate, hidden=hidden, pooled=pooled, w1=w1d, w2=w2d, dpooled=dpooled,
-                                   scratch=torch.empty(G, RD, device=be.device), dw1=dw1, db1=db1, dw2=dw2, db2=db2))
+                                   scratch=torch.empty(G, RD, device=be.device), dw1=dw1, db1=db1, dw2=dw2, db2=db2,
+                                   w2t=w2t))
     be.sync()
     assert_close(pooled, pooled_ref, dt, msg="pooled")
     assert_close(gate, gate_ref, dt, msg="gate")
