@@ -12,22 +12,27 @@
 // A 256-thread block walks a [rows][C] tensor 8 channels (16 B bf16 / 32 B fp32) per thread:
 // cpr = C/8 threads cover one row, rpb = 256/cpr rows per pass; a thread keeps its channel
 // chunk for the whole kernel so per-channel parameters live in registers.
+// Wide rows (C/8 > 128 chunks, i.e. C = 1152) would leave 112 of 256 threads idle with one row per
+// pass; the reduce kernels then split the channels into `nslices` column slices (blockIdx.z).
 struct RowMap {
-  int cpr, rpb, chunk, rsub;
+  int cpr, rpb, chunk, rsub;   // chunk: this thread's 8-channel chunk WITHIN its slice (LDS index)
+  int c0;                      // first channel of the thread (global)
   bool valid;
 };
-MDS_DEV RowMap rowmap(int C) {
+MDS_DEV RowMap rowmap(int C, int nslices = 1, int slice = 0) {
   RowMap m;
-  m.cpr = C >> 3;
+  m.cpr = (C >> 3) / nslices;
   m.rpb = 256 / m.cpr;
   if (m.rpb < 1) m.rpb = 1;
   m.chunk = threadIdx.x % m.cpr;
   m.rsub = threadIdx.x / m.cpr;
   m.valid = m.rsub < m.rpb;
+  m.c0 = (slice * m.cpr + m.chunk) * 8;
   return m;
 }
-// host: rows per block pass
-static inline int rows_per_pass(int C) { int cpr = C / 8; int r = 256 / cpr; return r < 1 ? 1 : r; }
+// host: column slices of a reduce kernel, and rows per block pass
+static inline int row_slices(int C) { return ((C / 8) > 128 && (C / 8) % 2 == 0) ? 2 : 1; }
+static inline int rows_per_pass(int C, int nslices = 1) { int cpr = C / 8 / nslices; int r = 256 / cpr; return r < 1 ? 1 : r; }
 // host: number of blocks for a row-streaming kernel over M rows (cap ~2048 blocks, grid-stride)
 static inline int stream_blocks(long M, int C) {
   long b = (M + rows_per_pass(C) - 1) / rows_per_pass(C);

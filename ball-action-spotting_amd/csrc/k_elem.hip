@@ -1,6 +1,6 @@
 // k_elem.hip — HBM-bound row-streaming kernels: 16-byte vector loads, per-channel parameters
 // in registers, LDS + wave reductions for the per-channel / per-group sums.
-#include "elem.h"
+#include "gemm.h"
 
 // ------------------------------------------------------------------ bn_res
 template <typename T>
@@ -46,8 +46,8 @@ extern "C" int mds_bn_res(const mds_bn_res_args* a, mds_stream_t stream) {
 template <typename T>
 __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
   __shared__ float red[256 * 8];
-  const RowMap m = rowmap(a.C);
-  const int c0 = m.chunk * 8;
+  const RowMap m = rowmap(a.C, gridDim.z, blockIdx.z);
+  const int c0 = m.c0;
   float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
   if (m.valid) {
     float sc[8], sh[8];
@@ -55,12 +55,27 @@ __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
     load8f(a.shift + c0, sh);
     const T* y = (const T*)a.y + (long)blockIdx.y * a.rows_per_group * a.C;
     T* act = a.act ? (T*)a.act + (long)blockIdx.y * a.rows_per_group * a.C : (T*)0;
-    for (long r = (long)blockIdx.x * m.rpb + m.rsub; r < a.rows_per_group; r += (long)gridDim.x * m.rpb) {
-      float v[8];
-      load8(y + r * a.C + c0, v);
+    // 4 rows per trip: the loads are issued together (a single 16-byte load in flight per thread
+    // leaves the kernel latency-bound at ~2 TB/s)
+    const long stride = (long)gridDim.x * m.rpb;
+    for (long r = (long)blockIdx.x * m.rpb + m.rsub; r < a.rows_per_group; r += 4 * stride) {
+      RawV8<T> raw[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { v[j] = siluf_(v[j] * sc[j] + sh[j]); acc[0][j] += v[j]; }
-      if (act) store8(act + r * a.C + c0, v);
+      for (int k = 0; k < 4; ++k) {
+        const long rr = r + k * stride;
+        raw[k].ld(y + (rr < a.rows_per_group ? rr : r) * a.C + c0);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long rr = r + k * stride;
+        if (rr < a.rows_per_group) {
+          float v[8];
+          raw[k].get(v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { v[j] = siluf_(v[j] * sc[j] + sh[j]); acc[0][j] += v[j]; }
+          if (act) store8(act + rr * a.C + c0, v);
+        }
+      }
     }
   }
   block_reduce_rows<1>(acc, m, red);
@@ -70,13 +85,17 @@ __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
     for (int j = 0; j < 8; ++j) atomicAdd(a.pooled + (long)blockIdx.y * a.C + c0 + j, acc[0][j] * inv);
   }
 }
+// blocks per group of a reduce kernel: every block ends with O(C) atomics / partial stores, so it
+// must own enough rows to amortise them (8 passes made the C = 1152 layers tail-bound: 1.2 TB/s)
+static int reduce_passes() { return 32; }   // measured 8 / 16 / 32 / 64 / 128 at the four layer shapes
 static inline int group_blocks(long rows, int C) {
-  long b = (rows + (long)rows_per_pass(C) * 8 - 1) / ((long)rows_per_pass(C) * 8);
+  const long per = (long)rows_per_pass(C, row_slices(C)) * reduce_passes();
+  const long b = (rows + per - 1) / per;
   return (int)(b > 64 ? 64 : (b < 1 ? 1 : b));
 }
 extern "C" int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "se_pool: bad dims");
-  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(se_pool_kernel<T>, dim3(group_blocks(a->rows_per_group, a->C), a->groups), dim3(256), 0, stream, *a));
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(se_pool_kernel<T>, dim3(group_blocks(a->rows_per_group, a->C), a->groups, row_slices(a->C)), dim3(256), 0, stream, *a));
   return mds_check_launch("se_pool");
 }
 
@@ -84,8 +103,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
   __shared__ float red[256 * 8];
   __shared__ float red2[256 * 8 * 2];
-  const RowMap m = rowmap(a.C);
-  const int c0 = m.chunk * 8;
+  const RowMap m = rowmap(a.C, gridDim.z, blockIdx.z);
+  const int c0 = m.c0;
   float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
   float bs[4][8];
 #pragma unroll
@@ -101,28 +120,40 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(mds_se_bwd_reduce_ar
     const long base = (long)blockIdx.y * a.rows_per_group * a.C;
     const T* y = (const T*)a.y + base;
     const T* u = (const T*)a.u + base;
-    for (long r = (long)blockIdx.x * m.rpb + m.rsub; r < a.rows_per_group; r += (long)gridDim.x * m.rpb) {
-      float v[8], uu[8];
-      load8(y + r * a.C + c0, v);
-      load8(u + r * a.C + c0, uu);
-      if (fuse_bn) {
+    const long stride = (long)gridDim.x * m.rpb;
+    for (long r0 = (long)blockIdx.x * m.rpb + m.rsub; r0 < a.rows_per_group; r0 += 2 * stride) {
+      RawV8<T> rv[2], ru[2];   // two rows per trip, loads issued together
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float z = v[j] * sc[j] + sh[j];
-          const float sg = sigmoidf_(z);
-          const float sp = sg * (1.0f + z * (1.0f - sg));     // silu'(z)
-          const float xh = (v[j] - mu[j]) * rs[j];
-          acc[0][j] += uu[j] * (z * sg);
-          const float us = uu[j] * sp;
-          bs[0][j] += us; bs[1][j] += us * xh; bs[2][j] += sp; bs[3][j] += sp * xh;
+      for (int k = 0; k < 2; ++k) {
+        const long rr = r0 + k * stride < a.rows_per_group ? r0 + k * stride : r0;
+        rv[k].ld(y + rr * a.C + c0);
+        ru[k].ld(u + rr * a.C + c0);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (r0 + k * stride >= a.rows_per_group) break;
+        float v[8], uu[8];
+        rv[k].get(v);
+        ru[k].get(uu);
+        if (fuse_bn) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float z = v[j] * sc[j] + sh[j];
+            const float sg = sigmoidf_(z);
+            const float sp = sg * (1.0f + z * (1.0f - sg));     // silu'(z)
+            const float xh = (v[j] - mu[j]) * rs[j];
+            acc[0][j] += uu[j] * (z * sg);
+            const float us = uu[j] * sp;
+            bs[0][j] += us; bs[1][j] += us * xh; bs[2][j] += sp; bs[3][j] += sp * xh;
+          }
+        } else {
+          if (raw) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = siluf_(v[j] * sc[j] + sh[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[0][j] += uu[j] * v[j];
         }
-      } else {
-        if (raw) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = siluf_(v[j] * sc[j] + sh[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[0][j] += uu[j] * v[j];
       }
     }
   }
@@ -150,7 +181,7 @@ extern "C" int mds_se_bwd_reduce_blocks(long rows_per_group, int C) { return gro
 extern "C" int mds_se_bwd_reduce(const mds_se_bwd_reduce_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "se_bwd_reduce: bad dims");
   MDS_REQUIRE(!a->bnsums || (a->scale && a->shift && a->mean && a->rstd), "se_bwd_reduce: BN fusion needs raw y + scale/shift/mean/rstd");
-  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(se_bwd_reduce_kernel<T>, dim3(group_blocks(a->rows_per_group, a->C), a->groups), dim3(256), 0, stream, *a));
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(se_bwd_reduce_kernel<T>, dim3(group_blocks(a->rows_per_group, a->C), a->groups, row_slices(a->C)), dim3(256), 0, stream, *a));
   return mds_check_launch("se_bwd_reduce");
 }
 
@@ -158,8 +189,8 @@ extern "C" int mds_se_bwd_reduce(const mds_se_bwd_reduce_args* a, mds_stream_t s
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_args a) {
   __shared__ float red[256 * 8 * 2];
-  const RowMap m = rowmap(a.C);
-  const int c0 = m.chunk * 8;
+  const RowMap m = rowmap(a.C, gridDim.y, blockIdx.y);
+  const int c0 = m.c0;
   float acc[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
   if (m.valid) {
     float sc[8], sh[8], mu[8], rs[8];
@@ -195,9 +226,10 @@ extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t s
   MDS_REQUIRE(a && a->M > 0 && a->C % 8 == 0 && a->C <= 2048, "bn_bwd_reduce: bad dims");
   MDS_REQUIRE(a->g.u && a->y && a->bn && a->stats, "bn_bwd_reduce: null pointer");
   MDS_REQUIRE(a->g.mode == MDS_G_PLAIN || a->g.mode == MDS_G_SILU || a->g.rows_per_group > 0, "bn_bwd_reduce: rows_per_group");
-  int nb = stream_blocks(a->M, a->C);
-  if (nb > 512) nb = 512;
-  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_reduce_kernel<T>, dim3(nb), dim3(256), 0, stream, *a));
+  const int ns = row_slices(a->C);
+  long nb = (a->M + rows_per_pass(a->C, ns) - 1) / rows_per_pass(a->C, ns);
+  if (nb > 512 / ns) nb = 512 / ns;   // 2C atomics per block into 32 slots: 512 blocks measured best (1024: +40 %)
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_reduce_kernel<T>, dim3((unsigned)nb, ns), dim3(256), 0, stream, *a));
   return mds_check_launch("bn_bwd_reduce");
 }
 
@@ -264,9 +296,59 @@ __global__ __launch_bounds__(256) void gem_fwd_kernel(mds_gem_fwd_args a) {
     }
   }
 }
+// row-split variant: grid (groups, splits); partial sums by atomics into the zeroed accumulator
+template <typename T, int BWD>
+__global__ __launch_bounds__(256) void gem_partial_kernel(int groups, long rows_per_group, int C, const void* yv, mds_pro_t pro,
+                                                          const float* pp, float eps, float* accum) {
+  __shared__ float red[256 * 8];
+  const RowMap m = rowmap(C);
+  const int c0 = m.chunk * 8;
+  const float p = pp[0];
+  float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
+  if (m.valid) {
+    float sc[8], sh[8];
+    if (pro.mode != MDS_PRO_NONE) { load8f(pro.scale + c0, sc); load8f(pro.shift + c0, sh); }
+    const T* y = (const T*)yv + (long)blockIdx.x * rows_per_group * C;
+    for (long r = (long)blockIdx.y * m.rpb + m.rsub; r < rows_per_group; r += (long)gridDim.y * m.rpb) {
+      float v[8];
+      load8(y + r * C + c0, v);
+      apply_pro8(pro.mode, v, sc, sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float lc = logf(fmaxf(v[j], eps));
+        acc[0][j] += BWD ? expf(p * lc) * lc : expf(p * lc);
+      }
+    }
+  }
+  block_reduce_rows<1>(acc, m, red);
+  if (m.valid && m.rsub == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(accum + (long)blockIdx.x * C + c0 + j, acc[0][j]);
+  }
+}
+__global__ void gem_finish_kernel(int n, float rows, const float* pp, const float* accum, float* pooled) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) pooled[e] = expf(logf(accum[e] / rows) / pp[0]);
+}
+static inline int gem_splits(int groups, long rows, int C) {
+  long per = (rows + rows_per_pass(C) - 1) / rows_per_pass(C);   // block passes per group
+  long want = 1024 / groups;
+  if (want < 1) want = 1;
+  long s = per / 4;                                              // >= 4 passes per block
+  if (s > want) s = want;
+  return (int)(s < 1 ? 1 : s);
+}
 extern "C" int mds_gem_fwd(const mds_gem_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "gem_fwd: bad dims");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_BN_SILU || a->pro.mode == MDS_PRO_AFFINE, "gem_fwd: prologue");
+  if (a->accum) {
+    const int sp = gem_splits(a->groups, a->rows_per_group, a->C);
+    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((gem_partial_kernel<T, 0>), dim3(a->groups, sp), dim3(256), 0, stream, a->groups,
+                                               a->rows_per_group, a->C, a->y, a->pro, a->p, a->eps, a->accum));
+    const int n = a->groups * a->C;
+    MDS_LAUNCH(gem_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, n, (float)a->rows_per_group, a->p, a->accum, a->pooled);
+    return mds_check_launch("gem_fwd");
+  }
   MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(gem_fwd_kernel<T>, dim3(a->groups), dim3(256), 0, stream, *a));
   return mds_check_launch("gem_fwd");
 }
@@ -339,8 +421,62 @@ __global__ __launch_bounds__(256) void gem_bwd_kernel(mds_gem_bwd_args a) {
     atomicAdd(a.dp, s);
   }
 }
+// row-split backward, second launch: u = coef * c^(p-1) * [a >= eps] with coef recomputed per block from
+// the finished accumulator; split 0 of each group also adds the exponent's gradient
+template <typename T>
+__global__ __launch_bounds__(256) void gem_apply_kernel(mds_gem_bwd_args a) {
+  __shared__ float red[256];
+  const RowMap m = rowmap(a.C);
+  const int c0 = m.chunk * 8;
+  const float p = a.p[0], R = (float)a.rows_per_group;
+  float dp_part = 0.f;
+  if (m.valid) {
+    float sc[8], sh[8], coef[8];
+    if (a.pro.mode != MDS_PRO_NONE) { load8f(a.pro.scale + c0, sc); load8f(a.pro.shift + c0, sh); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float out = a.pooled[(long)blockIdx.x * a.C + c0 + j];
+      const float dpo = a.dpooled[(long)blockIdx.x * a.C + c0 + j];
+      const float mean = expf(p * logf(out));  // out^p
+      coef[j] = dpo * out / (mean * R);
+      if (m.rsub == 0 && blockIdx.y == 0) {
+        const float S = a.accum[(long)blockIdx.x * a.C + c0 + j] / R;  // mean(c^p log c)
+        dp_part += dpo * out * (-logf(mean) / (p * p) + S / (p * mean));
+      }
+    }
+    const long gbase = (long)blockIdx.x * a.rows_per_group * a.C;
+    const T* y = (const T*)a.y + gbase;
+    T* u = (T*)a.u + gbase;
+    for (long r = (long)blockIdx.y * m.rpb + m.rsub; r < a.rows_per_group; r += (long)gridDim.y * m.rpb) {
+      float v[8];
+      load8(y + r * a.C + c0, v);
+      apply_pro8(a.pro.mode, v, sc, sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (v[j] >= a.eps) ? coef[j] * expf((p - 1.0f) * logf(v[j])) : 0.0f;
+      store8(u + r * a.C + c0, v);
+    }
+  }
+  if (blockIdx.y == 0) {
+    red[threadIdx.x] = dp_part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int i = 0; i < 256; ++i) s += red[i];
+      atomicAdd(a.dp, s);
+    }
+  }
+}
 extern "C" int mds_gem_bwd(const mds_gem_bwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "gem_bwd: bad dims");
+  if (a->accum) {
+    const int sp = gem_splits(a->groups, a->rows_per_group, a->C);
+    MDS_DISPATCH_DTYPE(a->dtype, T, {
+      MDS_LAUNCH((gem_partial_kernel<T, 1>), dim3(a->groups, sp), dim3(256), 0, stream, a->groups, a->rows_per_group, a->C, a->y,
+                 a->pro, a->p, a->eps, a->accum);
+      MDS_LAUNCH(gem_apply_kernel<T>, dim3(a->groups, sp), dim3(256), 0, stream, *a);
+    });
+    return mds_check_launch("gem_bwd");
+  }
   MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(gem_bwd_kernel<T>, dim3(a->groups), dim3(256), 0, stream, *a));
   return mds_check_launch("gem_bwd");
 }

@@ -518,7 +518,7 @@ class Plan:
         gp = m.global_pool
         pooled = self.f32(B * F_)
         self.op("fhead", "gem_fwd", dtype=self.code, groups=B * S, rows_per_group=h * w, C=cq, y=yq, pro=pro, p=P(gp.p),
-                eps=float(gp.eps), pooled=pooled)
+                eps=float(gp.eps), pooled=pooled, accum=self.zero_fwd(B * S * cq))
         dmask = self.mask(B * F_, m.drop_rate) if m.drop_rate > 0 else None
         ncls = m.classifier.out_features
         self.logits = self.f32(B * ncls)
@@ -532,7 +532,7 @@ class Plan:
                     dlogits=self.dlogits, dpooled=dpo, dw=self.grad(m.classifier.weight), db=self.grad(m.classifier.bias))
             uq = self.act(B * S * h * w, cq)
             self.op(seg, "gem_bwd", dtype=self.code, groups=B * S, rows_per_group=h * w, C=cq, y=yq, pro=pro, p=P(gp.p),
-                    eps=float(gp.eps), pooled=pooled, dpooled=dpo, u=uq, dp=self.grad(gp.p))
+                    eps=float(gp.eps), pooled=pooled, dpooled=dpo, u=uq, dp=self.grad(gp.p), accum=self.zero_bwd(B * S * cq))
             return uq
 
         self._recs["head"].append(bwd)

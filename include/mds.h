@@ -370,6 +370,9 @@ typedef struct {
   const float* p;       /* [1] learnable exponent */
   float eps;
   float* pooled;        /* [groups][C] == [b][t*C + c] */
+  float* accum;         /* optional caller-zeroed [groups][C]: the rows of a group are then split over
+                           several blocks (sum of clamp(a)^p by atomics + a finishing launch); without
+                           it one block walks a whole group                                         */
 } mds_gem_fwd_args;
 int mds_gem_fwd(const mds_gem_fwd_args* a, mds_stream_t stream);
 
@@ -387,6 +390,7 @@ typedef struct {
   const float* dpooled; /* [groups][C] */
   void* u;              /* [rows][C] */
   float* dp;            /* [1] += */
+  float* accum;         /* optional caller-zeroed [groups][C] (sum of c^p log c), as in mds_gem_fwd    */
 } mds_gem_bwd_args;
 int mds_gem_bwd(const mds_gem_bwd_args* a, mds_stream_t stream);
 

@@ -72,7 +72,7 @@ def test_bn_res(be, dt, M, C, act, use_mask, use_sc):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("packed,C,RD", [(True, 48, 12), (False, 48, 12), (True, 328, 28)])
+@pytest.mark.parametrize("packed,C,RD", [(True, 48, 12), (False, 48, 12), (True, 328, 28), (True, 1152, 48)])
 def test_se_forward_backward(be, dt, packed, C, RD):
     """se_pool + se_fc_fwd + (gated consumer) and the SE backward chain vs autograd; with and without
     the packed [R][C] copy of w2 (made by pack_weights / MDS_PACK_IO_F32)."""
@@ -134,11 +134,12 @@ def test_se_forward_backward(be, dt, packed, C, RD):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_bn_backward_chain(be, dt, mode):
-    """reduce -> finalize -> apply == autograd through act(batch_norm(y)) for every g-source."""
+@pytest.mark.parametrize("mode,C", [(0, 40), (1, 40), (2, 40), (3, 40), (1, 1152)])
+def test_bn_backward_chain(be, dt, mode, C):
+    """reduce -> finalize -> apply == autograd through act(batch_norm(y)) for every g-source
+    (C = 1152 takes the two-slice path of the reduce kernels)."""
     code, tdt = DT[dt]
-    M, C, rpg = 330, 40, 110
+    M, rpg = 330, 110
     G = M // rpg
     g = gen(11 + mode)
     y = (torch.randn(M, C, generator=g) * 1.5 + 0.3).to(tdt)
@@ -181,10 +182,11 @@ def test_bn_backward_chain(be, dt, mode):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("pro_mode", [0, 2])
-def test_gem_fwd_bwd(be, dt, pro_mode, golden):
+@pytest.mark.parametrize("pro_mode,split,R_,C", [(0, False, 35, 16), (2, False, 35, 16), (2, True, 35, 16), (2, True, 920, 64)])
+def test_gem_fwd_bwd(be, dt, pro_mode, split, R_, C, golden):
+    """single-block path and the row-split path (caller-zeroed accumulators)"""
     code, tdt = DT[dt]
-    G, R_, C = 4, 35, 16
+    G = 4
     g = gen(21)
     y = (torch.randn(G * R_, C, generator=g) * 1.5).to(tdt)
     scale = 1 + 0.2 * torch.randn(C, generator=g); shift = 0.2 * torch.randn(C, generator=g)
@@ -197,11 +199,13 @@ def test_gem_fwd_bwd(be, dt, pro_mode, golden):
     yd = be.t(y)
     pro = cabi.pro(pro_mode, be.t(scale), be.t(shift))
     pooled = torch.empty(G, C, device=be.device); pd = be.t(p)
+    acc1 = torch.zeros(G, C, device=be.device) if split else None
+    acc2 = torch.zeros(G, C, device=be.device) if split else None
     be.call("gem_fwd", cabi.make("mds_gem_fwd_args", dtype=code, groups=G, rows_per_group=R_, C=C, y=yd, pro=pro,
-                                 p=pd, eps=1e-6, pooled=pooled))
+                                 p=pd, eps=1e-6, pooled=pooled, accum=acc1))
     u = torch.empty(G * R_, C, dtype=tdt, device=be.device); dp = torch.zeros(1, device=be.device)
     be.call("gem_bwd", cabi.make("mds_gem_bwd_args", dtype=code, groups=G, rows_per_group=R_, C=C, y=yd, pro=pro,
-                                 p=pd, eps=1e-6, pooled=pooled, dpooled=be.t(dpo), u=u, dp=dp))
+                                 p=pd, eps=1e-6, pooled=pooled, dpooled=be.t(dpo), u=u, dp=dp, accum=acc2))
     be.sync()
     assert_close(pooled, pooled_ref, dt, msg="pooled")
     assert_close(u, a.grad, dt, msg="u")

@@ -115,7 +115,11 @@ def bench_conv(which):
 
 
 def bench_se():
-    G, R, C = 20, 3680, 672
+    for (G, R, C) in [(20, 3680, 672), (20, 920, 1152), (20, 3680, 384), (4, 4600, 576)]:
+        bench_se1(G, R, C)
+
+
+def bench_se1(G, R, C):
     M = G * R
     u = rnd(M, C); y = rnd(M, C)
     sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev) * 0.1
@@ -123,16 +127,19 @@ def bench_se():
     dgate = torch.zeros(G, C, device=dev); bns = torch.zeros(G, 64, 4, C, device=dev)
     a = cabi.make("mds_se_bwd_reduce_args", dtype=1, groups=G, rows_per_group=R, C=C, u=u, y=y, scale=sc, shift=sh,
                   dgate=dgate, mean=mean, rstd=rstd, bnsums=bns)
-    timeit("se_bwd_reduce fused-bn 20x3680x672", lambda: lib.call("se_bwd_reduce", a, stream()), 2 * M * C * 2, 0)
+    timeit(f"se_bwd_reduce fused-bn {G}x{R}x{C}", lambda: lib.call("se_bwd_reduce", a, stream()), 2 * M * C * 2, 0)
     b = cabi.make("mds_se_bwd_reduce_args", dtype=1, groups=G, rows_per_group=R, C=C, u=u, y=y, scale=sc, shift=sh,
                   dgate=dgate)
-    timeit("se_bwd_reduce plain     20x3680x672", lambda: lib.call("se_bwd_reduce", b, stream()), 2 * M * C * 2, 0)
+    timeit(f"se_bwd_reduce plain     {G}x{R}x{C}", lambda: lib.call("se_bwd_reduce", b, stream()), 2 * M * C * 2, 0)
     pooled = torch.zeros(G, C, device=dev); act = torch.empty_like(y)
     c = cabi.make("mds_se_pool_args", dtype=1, groups=G, rows_per_group=R, C=C, y=y, scale=sc, shift=sh, pooled=pooled, act=act)
-    timeit("se_pool (+act)          20x3680x672", lambda: lib.call("se_pool", c, stream()), 2 * M * C * 2, 0)
+    timeit(f"se_pool (+act)          {G}x{R}x{C}", lambda: lib.call("se_pool", c, stream()), 2 * M * C * 2, 0)
     st = torch.zeros(SLOTS, 2, C, device=dev); bn = torch.stack([sc, sh, mean, rstd]).contiguous()
     d = cabi.make("mds_bn_bwd_reduce_args", dtype=1, M=M, C=C, g=cabi.gsrc(1, u), y=y, bn=bn, stats=st)
-    timeit("bn_bwd_reduce silu      20x3680x672", lambda: lib.call("bn_bwd_reduce", d, stream()), 2 * M * C * 2, 0)
+    timeit(f"bn_bwd_reduce silu      {G}x{R}x{C}", lambda: lib.call("bn_bwd_reduce", d, stream()), 2 * M * C * 2, 0)
+    coef = torch.rand(3, C, device=dev); dyo = torch.empty_like(y)
+    e = cabi.make("mds_bn_bwd_apply_args", dtype=1, M=M, C=C, g=cabi.gsrc(1, u), y=y, bn=bn, coef=coef, dy=dyo)
+    timeit(f"bn_bwd_apply silu       {G}x{R}x{C}", lambda: lib.call("bn_bwd_apply", e, stream()), 3 * M * C * 2, 0)
 
 
 def bench_copy():
