@@ -14,8 +14,8 @@
 #define CV_BN 64
 
 template <typename T> struct CvLd;   // LDS pitch of one staged pixel / weight row: 32 channels + 16 B
-template <> struct CvLd<bf16_t> { static const int v = 40; };
-template <> struct CvLd<float> { static const int v = 36; };
+template <> struct CvLd<bf16_t> { static const int v = 48; };   // 96 B: 32 B x odd (see PwCfg)
+template <> struct CvLd<float> { static const int v = 40; };     // 160 B
 
 template <typename T, int PRO, int IS>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW, int tg) {
@@ -215,6 +215,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
 // tiles with the next tile's patch loads in flight under the current tile's MFMAs, and carries the
 // BatchNorm partial sums in registers until the end.  The k index is flattened over (tap, channel),
 // so Cin = 16 needs 5 k-steps for 9 taps instead of 9 half-empty ones.
+// LDS row pitch (elements): the next byte pitch that is 32 (mod 64) — conflict-free for ds_read_b128
+MDS_DEV int cvp_pitch(int elems, int esz) { const int b = elems * esz; return (b + ((96 - b % 64) % 64)) / esz; }
+static inline int cvp_pitch_h(int elems, int esz) { const int b = elems * esz; return (b + ((96 - b % 64) % 64)) / esz; }
+
 template <typename T, int PRO, int IS, int MAXX>
 __global__ __launch_bounds__(256, 2) void conv_fwd_p_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW,
                                                             int tiles_a, int tiles_b, int tiles_per_block, int KS) {
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_p_kernel(mds_conv_fwd_args a,
   constexpr int MF = (IS == 1) ? 4 : 2, TA = 4 * MF;  // MAXX: patch vectors a thread keeps in flight
   MDS_DYN_SMEM(smem);
   const int Cin = a.Cin, Cout = a.Cout, K = a.ntaps * Cin;
-  const int LDX = Cin + 8, LDW = KS * 32 + 8;
+  const int LDX = cvp_pitch(Cin, sizeof(T)), LDW = cvp_pitch(KS * 32, sizeof(T));
   const int npix = TH * TW, cpp = Cin >> 3, nitems = npix * cpp;
   T* xs = (T*)smem;                        // [npix][LDX]
   T* ws = xs + npix * LDX;                 // [64][LDW]
@@ -413,7 +417,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
   {  // persistent variant when the filter slab + one whole-channel input patch fit in LDS
     const int KS = cdiv(a->ntaps * a->Cin, 32);
     const size_t esz = a->dtype == MDS_BF16 ? 2 : 4;
-    const size_t smem = ((size_t)TH * TW * (a->Cin + 8) + (size_t)CV_BN * (KS * 32 + 8)) * esz + 2 * CV_BN * sizeof(float) + (size_t)KS * 16;
+    const size_t smem = ((size_t)TH * TW * cvp_pitch_h(a->Cin, (int)esz) + (size_t)CV_BN * cvp_pitch_h(KS * 32, (int)esz)) * esz + 2 * CV_BN * sizeof(float) + (size_t)KS * 16;
     if (TH * TW * (a->Cin / 8) <= 10 * 256 && smem <= 76 * 1024 && !getenv("MDS_CONV_OLD")) {  // two blocks per CU (measured: one resident block loses to the tile-per-block kernel)
       const int tiles_a = cdiv(a->A, TA), tiles_b = cdiv(a->B, CV_TB);
       const long total = (long)a->N * tiles_a * tiles_b;

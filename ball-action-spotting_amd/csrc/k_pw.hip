@@ -10,7 +10,7 @@
 //     16 MFMAs), K staged 256 bytes per row at a time (128 bf16 / 64 fp32) -> 4 k-steps per barrier;
 //   * every global load of a K-chunk is issued at once into raw registers, and the NEXT chunk's
 //     loads are in flight while the current chunk's MFMAs run (register software pipeline);
-//   * LDS row pitch 272 B: the 16 rows of a fragment read land on 16 distinct 16-byte bank groups.
+//   * LDS row pitch 160 B (32 B x odd): conflict-free for the lane groups of ds_read_b128.
 #include <stdlib.h>
 #include "gemm.h"
 
@@ -18,22 +18,27 @@
 #define PW_BN 128
 
 template <typename T> struct PwCfg;
-template <> struct PwCfg<bf16_t> { static const int KC = 64, LD = 72; };
-template <> struct PwCfg<float> { static const int KC = 32, LD = 36; };
+// LDS row pitch = 160 B: with ds_read_b128's real lane groups ({0-3,12-15,20-27}, ...) a pitch of
+// 32 B x odd is the conflict-free family; the former 144 B cost 28 of 64 lanes a replay.
+template <> struct PwCfg<bf16_t> { static const int KC = 64, LD = 80; };
+template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 
-template <typename T, int PRO>
-__global__ __launch_bounds__(256, 2) void pw_fwd_kernel(mds_pw_fwd_args a) {
+// WN = waves along N: 2 -> 128x128 tile (2x2 waves of 64x64), two blocks per CU;
+//                      1 -> 128x64 tile (4x1 waves of 32x64), ~160 VGPRs, three blocks per CU.
+template <typename T, int PRO, int WN>
+__global__ __launch_bounds__(256, WN == 2 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
   typedef typename Frag<T>::type frag_t;
   constexpr int KC = PwCfg<T>::KC, LD = PwCfg<T>::LD, VPR = KC / 8, RPP = 256 / VPR, NL = PW_BM / RPP;
+  constexpr int BN = 64 * WN, MFW = 2 * WN, NLW = BN / RPP;   // tile columns, m-fragments per wave, filter rows per thread
   MDS_DYN_SMEM(smem);
   T* xs = (T*)smem;                          // [PW_BM][LD]
-  T* ws = xs + PW_BM * LD;                   // [PW_BN][LD]
-  float* st_s = (float*)(ws + PW_BN * LD);   // [PW_BN]
-  float* st_ss = st_s + PW_BN;
+  T* ws = xs + PW_BM * LD;                   // [BN][LD]
+  float* st_s = (float*)(ws + BN * LD);      // [BN]
+  float* st_ss = st_s + BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const long m0 = (long)blockIdx.x * PW_BM;
   const int K = a.K, N = a.N;
   const T* x = (const T*)a.x;
@@ -49,17 +54,17 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_kernel(mds_pw_fwd_args a) {
     }
   }
 
-  for (int n0 = blockIdx.y * PW_BN; n0 < N; n0 += gridDim.y * PW_BN) {
+  for (int n0 = blockIdx.y * BN; n0 < N; n0 += gridDim.y * BN) {
     int nfr = (N - n0 - 64 * wn) >> 4;  // valid 16-column fragments of this wave
     nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
-    f32x4 acc[4][4];
+    f32x4 acc[MFW][4];
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf)
+    for (int mf = 0; mf < MFW; ++mf)
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.stats && tid < PW_BN) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
+    if (a.stats && tid < BN) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
 
-    RawV8<T> rx[NL], rw[NL];
+    RawV8<T> rx[NL], rw[NLW];
     auto issue = [&](int kc) {  // all global loads of one K-chunk
       const int kk = kc + 8 * svec;
 #pragma unroll
@@ -67,8 +72,10 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_kernel(mds_pw_fwd_args a) {
         const int r = srow + RPP * l;
         const long m = m0 + r;
         if (m < a.M && kk < K) rx[l].ld(x + m * K + kk); else rx[l].zero();
-        const int n = n0 + r;
-        if (n < N && kk < K) rw[l].ld(w + (long)n * K + kk); else rw[l].zero();
+        if (l < NLW) {
+          const int n = n0 + r;
+          if (n < N && kk < K) rw[l].ld(w + (long)n * K + kk); else rw[l].zero();
+        }
       }
     };
     issue(0);
@@ -106,22 +113,22 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_kernel(mds_pw_fwd_args a) {
         }
       }
 #pragma unroll
-      for (int l = 0; l < NL; ++l) rw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
+      for (int l = 0; l < NLW; ++l) rw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
       __syncthreads();
       if (kc + KC < K) issue(kc + KC);  // in flight while the MFMAs below run
       const int ksteps = (K - kc >= KC) ? KC / 32 : ((K - kc + 31) >> 5);
 #pragma unroll
       for (int ks = 0; ks < KC / 32; ++ks) {
         if (ks < ksteps) {
-          frag_t xf[4];
+          frag_t xf[MFW];
 #pragma unroll
-          for (int mf = 0; mf < 4; ++mf) xf[mf] = ld_frag(xs + (64 * wm + 16 * mf + i) * LD + 32 * ks + 8 * q);
+          for (int mf = 0; mf < MFW; ++mf) xf[mf] = ld_frag(xs + (16 * MFW * wm + 16 * mf + i) * LD + 32 * ks + 8 * q);
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) {
             if (nf < nfr) {
               frag_t wf = ld_frag(ws + (64 * wn + 16 * nf + i) * LD + 32 * ks + 8 * q);
 #pragma unroll
-              for (int mf = 0; mf < 4; ++mf) mma16(wf, xf[mf], acc[mf][nf]);  // acc[r] = y[m = i][n = 4q + r]
+              for (int mf = 0; mf < MFW; ++mf) mma16(wf, xf[mf], acc[mf][nf]);  // acc[r] = y[m = i][n = 4q + r]
             }
           }
         }
@@ -133,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_kernel(mds_pw_fwd_args a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-      const long m = m0 + 64 * wm + 16 * mf + i;
+    for (int mf = 0; mf < MFW; ++mf) {
+      const long m = m0 + 16 * MFW * wm + 16 * mf + i;
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) {
         if (nf < nfr) {
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_kernel(mds_pw_fwd_args a) {
       atomicAdd(&st_s[nl], ps[0]);
       atomicAdd(&st_ss[nl], pss[0]);
       __syncthreads();
-      if (tid < PW_BN && n0 + tid < N) {
+      if (tid < BN && n0 + tid < N) {
         float* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * N;
         atomicAdd(st + n0 + tid, st_s[tid]);
         atomicAdd(st + N + n0 + tid, st_ss[tid]);
@@ -176,12 +183,18 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->x && a->w && a->y, "pw_fwd: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || (a->pro.scale && a->pro.shift), "pw_fwd: prologue needs scale/shift");
   MDS_REQUIRE((a->pro.mode != MDS_PRO_BN_SILU_GATE && a->pro.mode != MDS_PRO_GATE) || (a->pro.gate && a->pro.rows_per_group > 0), "pw_fwd: gate prologue");
-  const int mt = cdiv(a->M, PW_BM), nt = cdiv(a->N, PW_BN);
+  // 128x64 tiles for the narrow projections (N <= 64: half of a 128-column tile would be padding;
+  // 154 -> 119 us at 1.18 M x 128 -> 32); wider N measured 5-20 % slower with them despite 3 blocks/CU
+  const int wn = a->N <= 64 ? 1 : 2;
+  const int BN = 64 * wn;
+  const int mt = cdiv(a->M, PW_BM), nt = cdiv(a->N, BN);
   int gy = 1;
   if (nt > 1) { gy = cdiv(1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
   dim3 grid(mt, gy), block(256);
 #define PW_GO(T, PRO) \
-  MDS_LAUNCH((pw_fwd_kernel<T, PRO>), grid, block, (size_t)(PW_BM + PW_BN) * PwCfg<T>::LD * sizeof(T) + 2 * PW_BN * sizeof(float), stream, *a)
+  do { const size_t smem = (size_t)(PW_BM + BN) * PwCfg<T>::LD * sizeof(T) + 2 * BN * sizeof(float); \
+       if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2>), grid, block, smem, stream, *a); \
+       else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1>), grid, block, smem, stream, *a); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: PW_GO(T, MDS_PRO_NONE); break;
