@@ -5,6 +5,7 @@
 // pure streaming pass: 226 MB of frames in, 301 MB of bf16 activations out per batch-4 step
 // (15 FLOP/B -> HBM-bound).  im2col fragments are gathered straight from global memory (the
 // planes are read with unit stride along W by neighbouring lanes), weights live in registers.
+#include <stdlib.h>
 #include "gemm.h"
 
 template <typename T>
@@ -162,10 +163,156 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(mds_stem_wgrad_args a) 
     }
 }
 
+// bf16 variant, tiled through LDS (the gather kernel above issues 32 scalar loads per MFMA group and
+// runs at 0.9 TB/s).  Tile = 8 output rows x 32 output columns; per (plane, input row) three arrays
+// A_kx[j] = x[2(ox0+j) + kx - pad_l] are staged (9 coalesced 8-byte loads -> three 16-byte LDS
+// stores per item), so a tap's fragment — 8 consecutive output columns of one (plane, ky, kx) — is ONE
+// aligned 16-byte LDS read; dy is staged as loaded ([pixel][oc]) and read with the transposing
+// ds_read_b64_tr_b16.  Persistent blocks, next tile's loads in flight under the MFMAs.
+#define SW_ROWS 8
+#define SW_COLS 32
+#define SW_PITCH 48   // elements: 96 B = 32 B x odd (conflict-free for ds_read_b128 and the tr reads)
+__global__ __launch_bounds__(256, 3) void stem_wgrad_tiled_kernel(mds_stem_wgrad_args a, int tiles_a, int tiles_b, int tiles_per_block) {
+  typedef bf16_t T;
+  constexpr int IR = 2 * SW_ROWS + 1;                  // input rows of a tile
+  constexpr int NX = IR * 3 * (SW_COLS / 8);           // x staging items: (input row, plane, 8-column group)
+  MDS_DYN_SMEM(smem);
+  T* xa = (T*)smem;                                    // [IR][3 planes][3 kx][SW_PITCH]
+  T* dys = xa + IR * 9 * SW_PITCH;                     // [SW_ROWS * SW_COLS][SW_PITCH]
+  T* zrow = dys + SW_ROWS * SW_COLS * SW_PITCH;        // [SW_PITCH] zeros (k = 27..31)
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const T* dy = (const T*)a.dy;
+  if (tid < SW_PITCH) zrow[tid] = 0;
+  // this lane's two taps n = 16g + i -> (plane, ky, kx): LDS element offset of its row within the tile image
+  int noff[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int n = 16 * g + i;
+    const int pl = n / 9, ky = (n % 9) / 3, kx = n % 3;
+    noff[g] = n < 27 ? ((ky * 3 + pl) * 3 + kx) * SW_PITCH : -1;   // + (2 r) * 9 * SW_PITCH per output row r
+  }
+  const long total = (long)a.N * tiles_a * tiles_b;
+  long tl = (long)blockIdx.x * tiles_per_block, tl_end = tl + tiles_per_block;
+  if (tl_end > total) tl_end = total;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) acc[f][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 rx[9];
+  RawV8<T> ry[4];
+  auto origin = [&](long t, int& img, int& oy0, int& ox0) {
+    img = (int)(t / (tiles_a * tiles_b));
+    const int rem = (int)(t - (long)img * tiles_a * tiles_b);
+    oy0 = (rem / tiles_b) * SW_ROWS; ox0 = (rem % tiles_b) * SW_COLS;
+  };
+  auto issue = [&](long t) {
+    int img, oy0, ox0;
+    origin(t, img, oy0, ox0);
+    if (tid < NX) {
+      const int grp = tid & 3, pl = (tid >> 2) % 3, ir = tid / 12;
+      const int iy = oy0 * 2 - a.pad_t + ir;
+      const int iyc = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+      const float* row = a.x + (((long)img * 3 + pl) * a.H + iyc) * a.W;
+      const int ix0 = 2 * (ox0 + 8 * grp) - a.pad_l;
+      if (iy >= 0 && iy < a.H && ix0 >= 0 && ix0 + 17 < a.W) {   // interior: nine 8-byte loads
+#pragma unroll
+        for (int j = 0; j < 9; ++j) rx[j] = *(const f32x2*)(row + ix0 + 2 * j);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          const int ix = ix0 + 2 * j;
+          const bool ok0 = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W, ok1 = iy >= 0 && iy < a.H && ix + 1 >= 0 && ix + 1 < a.W;
+          const int c0 = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix), c1 = ix + 1 < 0 ? 0 : (ix + 1 >= a.W ? a.W - 1 : ix + 1);
+          const float v0 = row[c0], v1 = row[c1];
+          rx[j] = (f32x2){ok0 ? v0 : 0.f, ok1 ? v1 : 0.f};
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int it = tid + 256 * p, px = it >> 2, ch = it & 3;
+      const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+      if (oy < a.OH && ox < a.OW && 8 * ch < a.Cout) ry[p].ld(dy + (((long)img * a.OH + oy) * a.OW + ox) * a.Cout + 8 * ch);
+      else ry[p].zero();
+    }
+  };
+  if (tl < tl_end) issue(tl);
+  for (; tl < tl_end; ++tl) {
+    __syncthreads();
+    if (tid < NX) {
+      const int grp = tid & 3, pl = (tid >> 2) % 3, ir = tid / 12;
+      T* base = xa + ((ir * 3 + pl) * 3) * SW_PITCH + 8 * grp;
+      float v0[8], v1[8], v2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v0[j] = rx[j][0]; v1[j] = rx[j][1]; v2[j] = rx[j + 1][0]; }
+      store8(base, v0); store8(base + SW_PITCH, v1); store8(base + 2 * SW_PITCH, v2);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int it = tid + 256 * p;
+      ry[p].st(dys + (it >> 2) * SW_PITCH + 8 * (it & 3));
+    }
+    __syncthreads();
+    if (tl + 1 < tl_end) issue(tl + 1);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = 2 * wave + rr;  // output row of the tile handled by this wave
+      // A: dy^T fragments (8 pixels of one oc): pixels r*32 + 16(q>>1) + 4(q&1) + {0..3, 8..11}
+      const int p0 = r * SW_COLS + 16 * (q >> 1) + 4 * (q & 1) + (i >> 2);
+      u16x8 yf[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const T* pc = dys + 16 * f + 4 * (i & 3);
+        const u16x4 lo = lds_tr4(pc + p0 * SW_PITCH), hi = lds_tr4(pc + (p0 + 8) * SW_PITCH);
+        yf[f] = (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      // B: x fragments: the same pixel permutation -> columns 16(q>>1) + 4(q&1) + {0..3} and +8
+      const int cb = 16 * (q >> 1) + 4 * (q & 1);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const T* rowp = noff[g] >= 0 ? xa + (2 * r) * 9 * SW_PITCH + noff[g] : zrow;
+        const int c = noff[g] >= 0 ? cb : 0;
+        const u16x4 lo = *(const u16x4*)(rowp + c), hi = *(const u16x4*)(rowp + c + (noff[g] >= 0 ? 8 : 4));
+        const u16x8 xf = (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int f = 0; f < 2; ++f) mma16(yf[f], xf, acc[f][g]);  // acc[r] = dw[oc = 16f + 4q + r][k = 16g + i]
+      }
+    }
+  }
+  // the 864 filter gradients are shared by every block: sum the four waves in LDS first, then one
+  // atomic per value and block (per-lane atomics from 1024 blocks = 4800 contended adds per address,
+  // which was most of this kernel's time)
+  __syncthreads();
+  float* red = (float*)smem;   // [4 waves][32 oc][32 k]
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 32 + 16 * f + 4 * q + r) * 32 + 16 * g + i] = acc[f][g][r];
+  __syncthreads();
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int oc = e >> 5, k = e & 31;
+    if (k < 27 && oc < a.Cout) atomicAdd(a.dw + oc * 27 + k, (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]));
+  }
+}
+
 extern "C" int mds_stem_wgrad(const mds_stem_wgrad_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0, "stem_wgrad: bad dims");
   MDS_REQUIRE(a->Cout % 16 == 0 && a->Cout <= 32, "stem_wgrad: Cout=%d must be 16 or 32", a->Cout);
   MDS_REQUIRE(a->x && a->dy && a->dw, "stem_wgrad: null pointer");
+  if (a->dtype == MDS_BF16 && !getenv("MDS_STEM_OLD")) {
+    const int tiles_a = cdiv(a->OH, SW_ROWS), tiles_b = cdiv(a->OW, SW_COLS);
+    const long total = (long)a->N * tiles_a * tiles_b;
+    const int tpb = (int)cdiv(total, total < 768 ? total : 768);   // three blocks per CU
+    const size_t smem = (size_t)((2 * SW_ROWS + 1) * 9 + SW_ROWS * SW_COLS + 1) * SW_PITCH * sizeof(bf16_t);
+    MDS_LAUNCH(stem_wgrad_tiled_kernel, dim3(cdiv(total, tpb)), dim3(256), smem, stream, *a, tiles_a, tiles_b, tpb);
+    return mds_check_launch("stem_wgrad");
+  }
   const long ngroups = (long)a->N * a->OH * ((a->OW + 31) / 32);
   long nb = (ngroups + 3) / 4;
   if (nb > 512) nb = 512;

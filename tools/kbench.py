@@ -142,6 +142,14 @@ def bench_se1(G, R, C):
     timeit(f"bn_bwd_apply silu       {G}x{R}x{C}", lambda: lib.call("bn_bwd_apply", e, stream()), 3 * M * C * 2, 0)
 
 
+def bench_stem():
+    N, H, W = 20, 736, 1280
+    OH, OW, pt, pl = geo.conv_geometry(H, W, 2)
+    x = torch.rand(N, 3, H, W, device=dev); dy = rnd(N * OH * OW, 32); dw = torch.zeros(32, 27, device=dev)
+    a = cabi.make("mds_stem_wgrad_args", dtype=1, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl, x=x, dy=dy, dw=dw)
+    timeit("stem_wgrad 20x3x736x1280", lambda: lib.call("stem_wgrad", a, stream()), x.numel() * 4 + dy.numel() * 2, 2 * N * OH * OW * 27 * 32)
+
+
 def bench_copy():
     n = 256 * 1024 * 1024
     a = torch.empty(n, device=dev, dtype=torch.uint8); b = torch.empty_like(a)
@@ -153,6 +161,8 @@ if __name__ == "__main__":
     for t in todo:
         if t == "copy":
             bench_copy()
+        elif t == "stem":
+            bench_stem()
         elif t == "se":
             bench_se()
         elif t.startswith("dw"):
