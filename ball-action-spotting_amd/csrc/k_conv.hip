@@ -675,7 +675,9 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
   MDS_REQUIRE(TH * TW * (a->Cin / 8) <= 9 * 256, "conv_wgrad: input patch %dx%dx%d exceeds the staging registers", TH, TW, a->Cin);
   const long total = (long)a->N * tiles_a * tiles_b;
   const int cot = cdiv(a->Cout, CW_COT);
-  long want = 768 / cot;
+  // one block per CU (the accumulators take the register file); every block ends with an atomic per
+  // filter value, so: two rounds of the chip for the big layers, one for the small (measured)
+  long want = (total >= 4096 ? 512 : 256) / cot;
   if (want < 1) want = 1;
   int tpb = (int)((total + want - 1) / want);
   if (tpb < 1) tpb = 1;
