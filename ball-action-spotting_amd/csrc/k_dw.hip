@@ -470,20 +470,282 @@ __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwSt
   }
 }
 
+// ------------------------------------------------------------------------------------ 3x3x3, T = 5
+// Same register sliding window for the 3D blocks of the headline configuration (5 slices per stack):
+// a thread owns one output ROW of all five slices of its channel pair and walks L columns; the
+// 5 x 3 x 3 activated window stays in registers (each input value is activated 3x, once per output
+// row that needs it), the 27 taps of the channel pair are read from LDS once per column.  The LDS-tiled
+// kernel above had 216-324 blocks of five barrier-separated slices each for the whole launch.
+#define DW3_T 5
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
+  constexpr int TT = DW3_T;
+  typedef Pair<T> P;
+  typedef typename P::raw_t raw_t;
+  __shared__ f32x2 wl[27][32];
+  __shared__ float red[8][4][32];
+  const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
+  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const bool cvalid = c0 < C;
+  const int mode = a.pro.mode;
+  for (int e = tid; e < 27 * 32; e += 256) {
+    const int t = e >> 5, c = cbeg + 2 * (e & 31);
+    wl[t][e & 31] = c < C ? (f32x2){a.w[(long)c * 27 + t], a.w[(long)(c + 1) * 27 + t]} : splat2(0.f);
+  }
+  __syncthreads();
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f), sc = splat2(1.f), sh = splat2(0.f);
+  if (cvalid && mode != MDS_PRO_NONE) { sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0); }
+  const int tstr = a.IH * a.IW * C;   // slice stride (elements)
+  for (int k = 0; k < g.spt; ++k) {
+    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    if (!cvalid || strip >= g.nstrips) continue;
+    const int seg = (int)(strip % g.nseg);
+    const long bt = strip / g.nseg;
+    const int oy = (int)(bt % g.nbands), n = (int)(bt / g.nbands);
+    const int ox0 = seg * g.L;
+    const int nout = (a.OW - ox0 < g.L) ? a.OW - ox0 : g.L;
+    const T* xim = (const T*)a.x + (long)n * TT * tstr + c0;
+    T* yim = (T*)a.y + (long)n * TT * tstr + (long)oy * a.OW * C + c0;
+    int roff[3], rok = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int iy = oy - 1 + j;
+      rok |= (iy >= 0 && iy < a.IH) ? (1 << j) : 0;
+      roff[j] = clampi(iy, 0, a.IH - 1) * a.IW * C;
+    }
+    auto ldcol = [&](int ix, raw_t (&raw)[TT][3]) {
+      const int xo = clampi(ix, 0, a.IW - 1) * C;
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) raw[t][j] = P::ld(xim + t * tstr + roff[j] + xo);
+    };
+    f32x2 win[TT][3][3];
+    auto push = [&](int ix, const raw_t (&raw)[TT][3]) {
+      const bool cok = ix >= 0 && ix < a.IW;
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          f32x2 v = P::up(raw[t][j]);
+          if (mode != MDS_PRO_NONE) {
+            v = v * sc + sh;
+            if (mode != MDS_PRO_AFFINE) v = v * sigmoid2(v);
+          }
+          const bool ok = cok && ((rok >> j) & 1);
+          win[t][j][0] = win[t][j][1]; win[t][j][1] = win[t][j][2];
+          win[t][j][2] = ok ? v : splat2(0.f);
+        }
+    };
+    raw_t raw[TT][3], cur[TT][3];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { win[t][j][1] = splat2(0.f); win[t][j][2] = splat2(0.f); }
+    ldcol(ox0 - 1, raw); push(ox0 - 1, raw);
+    ldcol(ox0, raw); push(ox0, raw);
+    ldcol(ox0 + 1, raw);
+#pragma unroll 1
+    for (int o = 0; o < nout; ++o) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cur[t][j] = raw[t][j];
+      ldcol(ox0 + o + 2, raw);
+      push(ox0 + o + 1, cur);
+      f32x2 acc[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) acc[t] = splat2(0.f);
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const f32x2 wv = wl[(dt * 3 + ky) * 3 + kx][cp];
+#pragma unroll
+            for (int ot = 0; ot < TT; ++ot) {
+              const int it = ot + dt - 1;
+              if (it >= 0 && it < TT) acc[ot] += win[it][ky][kx] * wv;
+            }
+          }
+#pragma unroll
+      for (int ot = 0; ot < TT; ++ot) {
+        P::st(yim + (long)ot * tstr + (long)(ox0 + o) * C, acc[ot]);
+        s1 += acc[ot]; s2 += acc[ot] * acc[ot];
+      }
+    }
+  }
+  if (a.stats) {
+    red[sl][0][cp] = s1[0]; red[sl][1][cp] = s1[1]; red[sl][2][cp] = s2[0]; red[sl][3][cp] = s2[1];
+    __syncthreads();
+    if (tid < 128) {
+      const int kk = tid >> 6, c = tid & 63;
+      float t = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+    }
+  }
+}
+
+// backward: window of dy [5 slices][3 rows][3 cols] around the thread's input row; per input pixel
+//   da[it] = sum_{dt,ky,kx} dy[it+1-dt][iy+1-ky][ix+1-kx] * w[dt][ky][kx],   dw[tap] += act[it] * (same dy)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dw3_bwd_kernel(mds_dw_bwd_args a, DwStrips g) {
+  constexpr int TT = DW3_T;
+  typedef Pair<T> P;
+  typedef typename P::raw_t raw_t;
+  __shared__ f32x2 wl[27][32];
+  __shared__ float dwl[8][27][64];
+  __shared__ float red[8][4][32];
+  const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
+  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const bool cvalid = c0 < C;
+  for (int e = tid; e < 27 * 32; e += 256) {
+    const int t = e >> 5, c = cbeg + 2 * (e & 31);
+    wl[t][e & 31] = c < C ? (f32x2){a.w[(long)c * 27 + t], a.w[(long)(c + 1) * 27 + t]} : splat2(0.f);
+  }
+  __syncthreads();
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f), sc = splat2(0.f), sh = splat2(0.f), mu = splat2(0.f), rs = splat2(0.f);
+  f32x2 dwacc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) dwacc[t] = splat2(0.f);
+  if (cvalid) {
+    sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0);
+    mu = *(const f32x2*)(a.mean + c0); rs = *(const f32x2*)(a.rstd + c0);
+  }
+  const int tstr = a.IH * a.IW * C;
+  for (int k = 0; k < g.spt; ++k) {
+    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    if (!cvalid || strip >= g.nstrips) continue;
+    const int seg = (int)(strip % g.nseg);
+    const long bt = strip / g.nseg;
+    const int iy = (int)(bt % g.nbands), n = (int)(bt / g.nbands);
+    const int ix0 = seg * g.L;
+    const int ncol = (a.IW - ix0 < g.L) ? a.IW - ix0 : g.L;
+    const long nbase = (long)n * TT * tstr + c0;
+    const T* xim = (const T*)a.x + nbase + (long)iy * a.IW * C;
+    const T* dyim = (const T*)a.dy + nbase;
+    T* gim = (T*)a.g + nbase + (long)iy * a.IW * C;
+    int doff[3], dok = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int oy = iy - 1 + j;
+      dok |= (oy >= 0 && oy < a.OH) ? (1 << j) : 0;
+      doff[j] = clampi(oy, 0, a.OH - 1) * a.OW * C;
+    }
+    auto lddy = [&](int ox, raw_t (&raw)[TT][3]) {
+      const int xo = clampi(ox, 0, a.OW - 1) * C;
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) raw[t][j] = P::ld(dyim + t * tstr + doff[j] + xo);
+    };
+    auto ldx = [&](int ix, raw_t (&raw)[TT]) {
+      const int xo = clampi(ix, 0, a.IW - 1) * C;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) raw[t] = P::ld(xim + t * tstr + xo);
+    };
+    f32x2 dyw[TT][3][3];
+    auto push = [&](int ox, const raw_t (&raw)[TT][3]) {
+      const bool cok = ox >= 0 && ox < a.OW;
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const bool ok = cok && ((dok >> j) & 1);
+          dyw[t][j][0] = dyw[t][j][1]; dyw[t][j][1] = dyw[t][j][2];
+          dyw[t][j][2] = ok ? P::up(raw[t][j]) : splat2(0.f);
+        }
+    };
+    raw_t rdy[TT][3], cdy[TT][3], rx[TT], cx[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { dyw[t][j][1] = splat2(0.f); dyw[t][j][2] = splat2(0.f); }
+    lddy(ix0 - 1, rdy); push(ix0 - 1, rdy);
+    lddy(ix0, rdy); push(ix0, rdy);
+    lddy(ix0 + 1, rdy); ldx(ix0, rx);
+#pragma unroll 1
+    for (int i = 0; i < ncol; ++i) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        cx[t] = rx[t];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cdy[t][j] = rdy[t][j];
+      }
+      lddy(ix0 + i + 2, rdy); ldx(ix0 + i + 1, rx);
+      push(ix0 + i + 1, cdy);
+      f32x2 xv[TT], z[TT], sg[TT], act[TT], da[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        xv[t] = P::up(cx[t]);
+        z[t] = xv[t] * sc + sh;
+        sg[t] = sigmoid2(z[t]);
+        act[t] = z[t] * sg[t];
+        da[t] = splat2(0.f);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int tap = (dt * 3 + ky) * 3 + kx;
+            const f32x2 wv = wl[tap][cp];
+#pragma unroll
+            for (int it = 0; it < TT; ++it) {
+              const int ot = it + 1 - dt;
+              if (ot >= 0 && ot < TT) {
+                const f32x2 d = dyw[ot][2 - ky][2 - kx];
+                da[it] += d * wv;
+                dwacc[tap] += d * act[it];
+              }
+            }
+          }
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const f32x2 gv = da[t] * (sg[t] * (splat2(1.0f) + z[t] * (splat2(1.0f) - sg[t])));
+        P::st(gim + (long)t * tstr + (long)(ix0 + i) * C, gv);
+        s1 += gv; s2 += gv * (xv[t] - mu);
+      }
+    }
+  }
+  s2 *= rs;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) *(f32x2*)&dwl[sl][t][2 * cp] = dwacc[t];
+  red[sl][0][cp] = s1[0]; red[sl][1][cp] = s1[1]; red[sl][2][cp] = s2[0]; red[sl][3][cp] = s2[1];
+  __syncthreads();
+  for (int e = tid; e < 64 * 27; e += 256) {
+    const int c = e / 27, t = e - c * 27;
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v += dwl[s][t][c];
+    if (cbeg + c < C) atomicAdd(a.dw + (long)cbeg * 27 + e, v);
+  }
+  if (tid < 128) {
+    const int kk = tid >> 6, c = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
+    if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+  }
+}
+
 // strips per launch: aim at >= one full round of the chip (256 CUs x 16 waves) before lengthening strips
-static DwStrips dw_strips(int images, int H, int W, int C, int R) {
+static DwStrips dw_strips(int images, int H, int W, int C, int R, int want_L = 0) {
   DwStrips g;
   g.nchunks = cdiv(C, 64);
   g.nbands = cdiv(H, R);
   int L = 16;
-  if (getenv("MDS_DW_L")) L = atoi(getenv("MDS_DW_L"));
+  if (want_L) L = want_L;
   else if ((long)images * g.nbands * cdiv(W, 16) * g.nchunks < 8192) L = 8;
   g.nseg = cdiv(W, L);
   g.L = cdiv(W, g.nseg);
   g.nseg = cdiv(W, g.L);
   g.nstrips = (long)images * g.nbands * g.nseg;
-  g.spt = 1;
-  if (getenv("MDS_DW_SPT")) g.spt = atoi(getenv("MDS_DW_SPT"));
+  g.spt = 1;   // strips per thread: 2 and 4 measured slower at every layer shape
   return g;
 }
 
@@ -502,6 +764,12 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
     const DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6);
     dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
+    return mds_check_launch("dw_fwd");
+  }
+  if (a->kt == 3 && a->T == DW3_T && !getenv("MDS_DW_OLD")) {
+    DwStrips g = dw_strips(a->N, a->OH, a->OW, a->C, 1, 20);   // strip length measured: 8/16/20/40 -> 38/39/36/63 us
+    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_fwd_kernel<T>, grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
   MDS_DISPATCH_DTYPE(a->dtype, T, {
@@ -746,6 +1014,12 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_bwd_kernel<T, 4>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_bwd");
   }
+  if (a->kt == 3 && a->T == DW3_T && !getenv("MDS_DW_OLD")) {
+    DwStrips g = dw_strips(a->N, a->IH, a->IW, a->C, 1, 16);   // 8/16/20/40 -> 80/67/82/145 us
+    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_bwd_kernel<T>, grid, block, 0, stream, *a, g));
+    return mds_check_launch("dw_bwd");
+  }
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     const int CC = DwCfg<T>::CC;
     const int nchunks = cdiv(a->C, CC);
@@ -753,7 +1027,6 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
     // the per-block fixed cost (tap staging, 36-value wave reductions, atomics) is amortised over a
     // whole row band in 2D (measured: 342 -> 215 us at 46x80x672); 3D blocks already walk T slices
     int tpb = a->kt == 3 ? 2 : (tiles_x < 8 ? tiles_x : 8);
-    if (getenv("MDS_DW_TPB")) tpb = atoi(getenv("MDS_DW_TPB"));
     dim3 grid(cdiv(tiles_x, tpb), cdiv(a->IH, 8), a->N * nchunks), block(256);
     const int dnpix = a->stride == 1 ? 10 * 18 : 6 * 10;
     const size_t smem = (size_t)a->kt * dnpix * CC * sizeof(T) + ((size_t)2 * a->kt * 9 * CC + 2 * CC) * sizeof(float);
