@@ -61,7 +61,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.stats && tid < CV_BN) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
 
     for (int kc = 0; kc < Cin; kc += 32) {
       // ---- issue every global load of this (n-tile, k-chunk) first: input patch, then the weights of
@@ -190,18 +189,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
         }
       }
     }
-    if (a.stats) {
+    if (a.stats) {   // one column per lane after the reduce-scatter: straight to the slot (no block barrier)
       const int e = reduce_scatter16(ps, i);
       reduce_scatter16(pss, i);
-      const int nl = 16 * (e >> 2) + 4 * q + (e & 3);
-      atomicAdd(&st_s[nl], ps[0]);
-      atomicAdd(&st_ss[nl], pss[0]);
-      __syncthreads();
-      if (tid < CV_BN && n0 + tid < Cout) {
-        const int slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7) % MDS_STAT_SLOTS;
+      const int n = n0 + 16 * (e >> 2) + 4 * q + (e & 3);
+      if (n < Cout) {
+        const int slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7 + wave) % MDS_STAT_SLOTS;
         float* st = a.stats + (long)slot * 2 * Cout;
-        atomicAdd(st + n0 + tid, st_s[tid]);
-        atomicAdd(st + Cout + n0 + tid, st_ss[tid]);
+        atomicAdd(st + n, ps[0]);
+        atomicAdd(st + Cout + n, pss[0]);
       }
     }
   }

@@ -33,8 +33,6 @@ __global__ __launch_bounds__(256, WN == 2 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd
   MDS_DYN_SMEM(smem);
   T* xs = (T*)smem;                          // [PW_BM][LD]
   T* ws = xs + PW_BM * LD;                   // [BN][LD]
-  float* st_s = (float*)(ws + BN * LD);      // [BN]
-  float* st_ss = st_s + BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -62,7 +60,6 @@ __global__ __launch_bounds__(256, WN == 2 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd
     for (int mf = 0; mf < MFW; ++mf)
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.stats && tid < BN) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
 
     RawV8<T> rx[NL], rw[NLW];
     auto issue = [&](int kc) {  // all global loads of one K-chunk
@@ -162,16 +159,15 @@ __global__ __launch_bounds__(256, WN == 2 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd
       }
     }
     if (a.stats) {
+      // after the reduce-scatter every lane of the wave holds ONE column's partial sums: add them to
+      // the slot straight away (no LDS staging, no block barrier at the end of every tile)
       const int e = reduce_scatter16(ps, i);
       reduce_scatter16(pss, i);
-      const int nl = 64 * wn + 16 * (e >> 2) + 4 * q + (e & 3);
-      atomicAdd(&st_s[nl], ps[0]);
-      atomicAdd(&st_ss[nl], pss[0]);
-      __syncthreads();
-      if (tid < BN && n0 + tid < N) {
-        float* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * N;
-        atomicAdd(st + n0 + tid, st_s[tid]);
-        atomicAdd(st + N + n0 + tid, st_ss[tid]);
+      const int n = n0 + 64 * wn + 16 * (e >> 2) + 4 * q + (e & 3);
+      if (n < N) {
+        float* st = a.stats + (long)((blockIdx.x + wm) % MDS_STAT_SLOTS) * 2 * N;
+        atomicAdd(st + n, ps[0]);
+        atomicAdd(st + N + n, pss[0]);
       }
     }
   }
@@ -192,7 +188,7 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   if (nt > 1) { gy = cdiv(1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
   dim3 grid(mt, gy), block(256);
 #define PW_GO(T, PRO) \
-  do { const size_t smem = (size_t)(PW_BM + BN) * PwCfg<T>::LD * sizeof(T) + 2 * BN * sizeof(float); \
+  do { const size_t smem = (size_t)(PW_BM + BN) * PwCfg<T>::LD * sizeof(T); \
        if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2>), grid, block, smem, stream, *a); \
        else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1>), grid, block, smem, stream, *a); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
