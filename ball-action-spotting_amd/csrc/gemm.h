@@ -72,6 +72,6 @@ MDS_DEV void lds_store8_u32(float* dst, const float (&v)[8]) {
 MDS_DEV void lds_store8_u32(bf16_t* dst, const float (&v)[8]) {
   uint32_t* d = (uint32_t*)dst;  // pitch is even -> 4-byte aligned
 #pragma unroll
-  for (int j = 0; j < 4; ++j) d[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+  for (int j = 0; j < 4; ++j) d[j] = pack2(v[2 * j], v[2 * j + 1]);
 }
 

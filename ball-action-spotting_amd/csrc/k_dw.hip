@@ -231,7 +231,7 @@ template <> struct Pair<bf16_t> {
   typedef uint32_t raw_t;
   static MDS_DEV raw_t ld(const bf16_t* p) { return *(const uint32_t*)p; }
   static MDS_DEV f32x2 up(raw_t u) { return (f32x2){bits2f(u << 16), bits2f(u & 0xffff0000u)}; }
-  static MDS_DEV void st(bf16_t* p, f32x2 v) { *(uint32_t*)p = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); }
+  static MDS_DEV void st(bf16_t* p, f32x2 v) { *(uint32_t*)p = pack2(v[0], v[1]); }
 };
 template <> struct Pair<float> {
   typedef f32x2 raw_t;

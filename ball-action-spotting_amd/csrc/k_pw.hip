@@ -132,31 +132,43 @@ __global__ __launch_bounds__(256, WN == 2 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd
       }
     }
 
-    // ---- epilogue: residual, store, statistics
+    // ---- epilogue: residual, store, statistics.  One row-validity test per m-fragment (not per
+    //      store): the per-lane `m < M` guard around every 8-byte store used to cost an exec-mask
+    //      save/restore and a branch per fragment — 1/4 of the epilogue's instructions.
     float ps[16], pss[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
 #pragma unroll
     for (int mf = 0; mf < MFW; ++mf) {
       const long m = m0 + 16 * MFW * wm + 16 * mf + i;
+      const bool ok = m < a.M;
+      T* yrow = y + (ok ? m : 0) * N + n0 + 64 * wn + 4 * q;
+      float v[4][4];
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        if (nf < nfr) {
-          const int n = n0 + 64 * wn + 16 * nf + 4 * q;
-          float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
-          if (m < a.M) {
-            if (a.residual) {
-              float rr[4];
-              load4((const T*)a.residual + m * N + n, rr);
+      for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += rr[r];
-            }
-            store4(y + m * N + n, v);
+        for (int r = 0; r < 4; ++r) v[nf][r] = acc[mf][nf][r];
+      if (a.residual && ok) {
+        const T* rrow = (const T*)a.residual + m * N + n0 + 64 * wn + 4 * q;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          if (nf < nfr) {
+            float rr[4];
+            load4(rrow + 16 * nf, rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[nf][r] += rr[r];
           }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[r]; pss[nf * 4 + r] += v[r] * v[r]; }
         }
       }
+      if (ok) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+          if (nf < nfr) store4(yrow + 16 * nf, v[nf]);
+      }
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)   // rows past M hold zeros (zero-filled operand): no guard needed
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[nf][r]; pss[nf * 4 + r] += v[nf][r] * v[nf][r]; }
     }
     if (a.stats) {
       // after the reduce-scatter every lane of the wave holds ONE column's partial sums: add them to
@@ -220,7 +232,7 @@ template <> struct WgCfg<bf16_t> { static const int MW = 2, LDT = WG_ROWS + 8; }
 template <> struct WgCfg<float> { static const int MW = 1, LDT = WG_ROWS + 4; };
 template <int LDT> MDS_DEV int wg_off(int c, int m) { return c * LDT + 8 * ((m >> 3) ^ ((c >> 3) & 7)) + (m & 7); }
 MDS_DEV void wg_put(bf16_t* base, int off, float v0, float v1) {
-  *(uint32_t*)(base + off) = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+  *(uint32_t*)(base + off) = pack2(v0, v1);
 }
 MDS_DEV void wg_put(float* base, int off, float v0, float) { base[off] = v0; }
 

@@ -27,14 +27,22 @@ MDS_DEV float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 MDS_DEV uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 MDS_DEV float bf2f(bf16_t v) { return bits2f((uint32_t)v << 16); }
 #ifndef MDS_EMU
-// round-to-nearest-even in hardware: pairs of these fold into one v_cvt_pk_bf16_f32
+// round-to-nearest-even in hardware
 MDS_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// two floats -> one dword of two bf16: exactly ONE v_cvt_pk_bf16_f32 (the scalar form followed by
+// shift/or costs three more VALU ops per pair — a quarter of the GEMM epilogues' instructions)
+MDS_DEV uint32_t pack2(float lo, float hi) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){lo, hi}, bf16x2_));
+}
 #else
 MDS_DEV bf16_t f2bf(float f) {  // round-to-nearest-even
   uint32_t u = f2bits(f);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+MDS_DEV uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 #endif
 // SiLU/sigmoid run on every element of every activation tensor (several times, because the
 // normalised tensor is never materialised): hardware v_exp_f32 / v_rcp_f32 (~1 ulp) instead of
@@ -82,7 +90,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 MDS_DEV u16x8 pack8(const float (&v)[8]) {
   u32x4 w;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) w[i] = pack2(v[2 * i], v[2 * i + 1]);
   return __builtin_bit_cast(u16x8, w);
 }
 MDS_DEV void store8(bf16_t* p, const float (&v)[8]) { *(u16x8*)p = pack8(v); }
@@ -91,7 +99,7 @@ MDS_DEV void load4(const bf16_t* p, float (&v)[4]) { u16x4 a = *(const u16x4*)p;
 MDS_DEV void store4(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = a; }
 MDS_DEV void store4(bf16_t* p, const float (&v)[4]) {
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  u32x2 w = {(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+  u32x2 w = {pack2(v[0], v[1]), pack2(v[2], v[3])};
   *(u32x2*)p = w;
 }
 
