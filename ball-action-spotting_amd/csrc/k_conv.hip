@@ -444,7 +444,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
   do {                                                                                                  \
     const int LD = CvLd<T>::v;                                                                          \
     int tg = a->ntaps;  /* taps staged per barrier group: all of them unless LDS (160 KiB) says no */   \
-    while (tg > 1 && (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) > 76 * 1024) tg = (tg > 3 ? 3 : tg - 1);     \
+    while (tg > 1 && (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) > 76 * 1024) --tg;                          \
     const size_t smem = (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) + 2 * CV_BN * sizeof(float) + 2 * MDS_MAX_TAPS * sizeof(int); \
     if (a->is == 1) MDS_LAUNCH((conv_fwd_kernel<T, PRO, 1>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
     else MDS_LAUNCH((conv_fwd_kernel<T, PRO, 2>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
