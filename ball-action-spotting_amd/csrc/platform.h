@@ -182,7 +182,7 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
 // [4][16] block, and lane i RECEIVES column i of that block (rows 0..3).  The rows may sit at
 // arbitrary addresses, so a [pixel][channel] image yields MFMA fragments whose reduction index is
 // the pixel — the weight-gradient GEMMs — in one instruction per 4 pixels (measured on hardware
-// with tmp probe; tests/test_k_conv.py covers it through conv_wgrad).
+// with tools/probes/tr_test.hip; tests/test_k_conv.py covers it through conv_wgrad).
 #ifndef MDS_EMU
 MDS_DEV u16x4 lds_tr4(const bf16_t* p) {
   typedef short s16x4 __attribute__((ext_vector_type(4)));
