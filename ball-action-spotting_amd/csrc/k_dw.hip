@@ -733,8 +733,241 @@ __global__ __launch_bounds__(256, 2) void dw3_bwd_kernel(mds_dw_bwd_args a, DwSt
   }
 }
 
+// ------------------------------------------------------------------------------------ 3x3 stride 2 (TF-SAME)
+// Sliding window for the two stride-2 layers.  Forward: R = 3 output rows need 7 input rows; an output
+// column consumes two new input columns (window col 0 <- old col 2).
+template <typename T>
+__global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
+  constexpr int R = 3, NR = 2 * R + 1;
+  typedef Pair<T> P;
+  typedef typename P::raw_t raw_t;
+  __shared__ float red[8][4][32];
+  const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
+  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const bool cvalid = c0 < C;
+  const int mode = a.pro.mode;
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
+  f32x2 w[3][3], sc = splat2(1.f), sh = splat2(0.f);
+  if (cvalid) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t / 3][t % 3] = (f32x2){a.w[(long)c0 * 9 + t], a.w[(long)(c0 + 1) * 9 + t]};
+    if (mode != MDS_PRO_NONE) { sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0); }
+  }
+  for (int k = 0; k < g.spt; ++k) {
+    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    if (!cvalid || strip >= g.nstrips) continue;
+    const int seg = (int)(strip % g.nseg);
+    const long bt = strip / g.nseg;
+    const int band = (int)(bt % g.nbands), img = (int)(bt / g.nbands);
+    const int oy0 = band * R, ox0 = seg * g.L;
+    const int nout = (a.OW - ox0 < g.L) ? a.OW - ox0 : g.L;
+    const T* xim = (const T*)a.x + (long)img * a.IH * a.IW * C + c0;
+    T* yim = (T*)a.y + ((long)img * a.OH + oy0) * a.OW * C + c0;
+    int roff[NR], rok = 0;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int iy = 2 * oy0 - a.pad_t + j;
+      rok |= (iy >= 0 && iy < a.IH) ? (1 << j) : 0;
+      roff[j] = clampi(iy, 0, a.IH - 1) * a.IW * C;
+    }
+    auto ldcol = [&](int ix, raw_t (&raw)[NR]) {
+      const int xo = clampi(ix, 0, a.IW - 1) * C;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) raw[j] = P::ld(xim + roff[j] + xo);
+    };
+    f32x2 win[NR][3];
+    auto activate = [&](int ix, const raw_t (&raw)[NR], int slot) {
+      const bool cok = ix >= 0 && ix < a.IW;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        f32x2 v = P::up(raw[j]);
+        if (mode != MDS_PRO_NONE) {
+          v = v * sc + sh;
+          if (mode != MDS_PRO_AFFINE) v = v * sigmoid2(v);
+        }
+        const bool ok = cok && ((rok >> j) & 1);
+        v = ok ? v : splat2(0.f);
+        if (slot == 1) win[j][1] = v; else win[j][2] = v;
+      }
+    };
+    raw_t ra[NR], rb[NR], ca[NR], cb[NR];
+    const int ixs = 2 * ox0 - a.pad_l;           // first input column of the strip
+    ldcol(ixs, ra); activate(ixs, ra, 2);
+    ldcol(ixs + 1, ra); ldcol(ixs + 2, rb);
+#pragma unroll 1
+    for (int o = 0; o < nout; ++o) {
+      const int ixb = ixs + 2 * o;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) { ca[j] = ra[j]; cb[j] = rb[j]; win[j][0] = win[j][2]; }
+      ldcol(ixb + 3, ra); ldcol(ixb + 4, rb);    // prefetch the next output's two new columns (clamped)
+      activate(ixb + 1, ca, 1);
+      activate(ixb + 2, cb, 2);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        f32x2 acc = splat2(0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc += win[2 * r + ky][kx] * w[ky][kx];
+        if (oy0 + r < a.OH) {
+          P::st(yim + ((long)r * a.OW + ox0 + o) * C, acc);
+          s1 += acc; s2 += acc * acc;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    red[sl][0][cp] = s1[0]; red[sl][1][cp] = s1[1]; red[sl][2][cp] = s2[0]; red[sl][3][cp] = s2[1];
+    __syncthreads();
+    if (tid < 128) {
+      const int kk = tid >> 6, c = tid & 63;
+      float t = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+    }
+  }
+}
+
+// Backward over INPUT pixels: a thread owns 4 input rows x pairs of input columns; the dy values that
+// reach them are a 3-row x 2-column window (slides one dy column per input-column pair).  With
+// iy = 4b + r, ix = 2c + p:   tap ky hits iff (r + PT - ky) is even -> window row (r+PT-ky+2)/2 - PT,
+// tap kx iff (p + PL - kx) is even -> window column (p+PL-kx+2)/2 - PL   (all compile-time).
+template <typename T, int PT, int PL>
+__global__ __launch_bounds__(256, 2) void dw2s_bwd_kernel(mds_dw_bwd_args a, DwStrips g) {
+  constexpr int R = 4;
+  typedef Pair<T> P;
+  typedef typename P::raw_t raw_t;
+  __shared__ float dwl[8][9][64];
+  __shared__ float red[8][4][32];
+  const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
+  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const bool cvalid = c0 < C;
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
+  f32x2 w[3][3], dwacc[3][3], sc = splat2(0.f), sh = splat2(0.f), mu = splat2(0.f), rs = splat2(0.f);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) dwacc[t / 3][t % 3] = splat2(0.f);
+  if (cvalid) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t / 3][t % 3] = (f32x2){a.w[(long)c0 * 9 + t], a.w[(long)(c0 + 1) * 9 + t]};
+    sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0);
+    mu = *(const f32x2*)(a.mean + c0); rs = *(const f32x2*)(a.rstd + c0);
+  }
+  for (int k = 0; k < g.spt; ++k) {
+    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    if (!cvalid || strip >= g.nstrips) continue;
+    const int seg = (int)(strip % g.nseg);
+    const long bt = strip / g.nseg;
+    const int band = (int)(bt % g.nbands), img = (int)(bt / g.nbands);
+    const int iy0 = band * R, ix0 = seg * g.L;          // g.L is even
+    const int npair = ((a.IW - ix0 < g.L ? a.IW - ix0 : g.L) + 1) >> 1;
+    const T* xim = (const T*)a.x + (long)img * a.IH * a.IW * C + c0;
+    T* gim = (T*)a.g + (long)img * a.IH * a.IW * C + c0;
+    const T* dyim = (const T*)a.dy + (long)img * a.OH * a.OW * C + c0;
+    const int oyb = iy0 / 2 - 1 + PT;
+    int xoff[R], doff[3], dok = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) xoff[r] = clampi(iy0 + r, 0, a.IH - 1) * a.IW * C;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int oy = oyb + j;
+      dok |= (oy >= 0 && oy < a.OH) ? (1 << j) : 0;
+      doff[j] = clampi(oy, 0, a.OH - 1) * a.OW * C;
+    }
+    auto lddy = [&](int ox, raw_t (&raw)[3]) {
+      const int xo = clampi(ox, 0, a.OW - 1) * C;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) raw[j] = P::ld(dyim + doff[j] + xo);
+    };
+    auto ldx = [&](int ix, raw_t (&raw)[R][2]) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int xo = clampi(ix + p, 0, a.IW - 1) * C;
+#pragma unroll
+        for (int r = 0; r < R; ++r) raw[r][p] = P::ld(xim + xoff[r] + xo);
+      }
+    };
+    f32x2 dyw[3][2];
+    auto push = [&](int ox, const raw_t (&raw)[3]) {
+      const bool cok = ox >= 0 && ox < a.OW;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const bool ok = cok && ((dok >> j) & 1);
+        dyw[j][0] = dyw[j][1];
+        dyw[j][1] = ok ? P::up(raw[j]) : splat2(0.f);
+      }
+    };
+    raw_t rdy[3], cdy[3], rx[R][2], cx[R][2];
+    const int cc0 = ix0 >> 1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dyw[j][1] = splat2(0.f);
+    lddy(cc0 - 1 + PL, rdy); push(cc0 - 1 + PL, rdy);
+    lddy(cc0 + PL, rdy); ldx(ix0, rx);
+#pragma unroll 1
+    for (int c = 0; c < npair; ++c) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cdy[j] = rdy[j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { cx[r][0] = rx[r][0]; cx[r][1] = rx[r][1]; }
+      lddy(cc0 + c + 1 + PL, rdy); ldx(ix0 + 2 * c + 2, rx);   // prefetch (clamped)
+      push(cc0 + c + PL, cdy);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int iy = iy0 + r, ix = ix0 + 2 * c + p;
+          const bool ok = iy < a.IH && ix < a.IW;
+          const f32x2 xv = P::up(cx[r][p]);
+          const f32x2 z = xv * sc + sh;
+          const f32x2 sg = sigmoid2(z);
+          const f32x2 act = ok ? z * sg : splat2(0.f);
+          f32x2 da = splat2(0.f);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            if (((r + PT - ky + 2) & 1) == 0) {
+              const int jr = (r + PT - ky + 2) / 2 - PT;
+#pragma unroll
+              for (int kx = 0; kx < 3; ++kx) {
+                if (((p + PL - kx + 2) & 1) == 0) {
+                  const int jc = (p + PL - kx + 2) / 2 - PL;
+                  const f32x2 d = dyw[jr][jc];
+                  da += d * w[ky][kx];
+                  dwacc[ky][kx] += d * act;
+                }
+              }
+            }
+          }
+          if (ok) {
+            const f32x2 gv = da * (sg * (splat2(1.0f) + z * (splat2(1.0f) - sg)));
+            P::st(gim + xoff[r] + (long)ix * C, gv);
+            s1 += gv; s2 += gv * (xv - mu);
+          }
+        }
+    }
+  }
+  s2 *= rs;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) *(f32x2*)&dwl[sl][t][2 * cp] = dwacc[t / 3][t % 3];
+  red[sl][0][cp] = s1[0]; red[sl][1][cp] = s1[1]; red[sl][2][cp] = s2[0]; red[sl][3][cp] = s2[1];
+  __syncthreads();
+  for (int e = tid; e < 64 * 9; e += 256) {
+    const int c = e / 9, t = e - c * 9;
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v += dwl[s][t][c];
+    if (cbeg + c < C) atomicAdd(a.dw + (long)cbeg * 9 + e, v);
+  }
+  if (tid < 128) {
+    const int kk = tid >> 6, c = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
+    if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+  }
+}
+
 // strips per launch: aim at >= one full round of the chip (256 CUs x 16 waves) before lengthening strips
-static DwStrips dw_strips(int images, int H, int W, int C, int R, int want_L = 0) {
+static DwStrips dw_strips(int images, int H, int W, int C, int R, int want_L = 0, bool even_L = false) {
   DwStrips g;
   g.nchunks = cdiv(C, 64);
   g.nbands = cdiv(H, R);
@@ -743,6 +976,7 @@ static DwStrips dw_strips(int images, int H, int W, int C, int R, int want_L = 0
   else if ((long)images * g.nbands * cdiv(W, 16) * g.nchunks < 8192) L = 8;
   g.nseg = cdiv(W, L);
   g.L = cdiv(W, g.nseg);
+  if (even_L) g.L = (g.L + 1) & ~1;   // stride-2 backward walks input-column PAIRS
   g.nseg = cdiv(W, g.L);
   g.nstrips = (long)images * g.nbands * g.nseg;
   g.spt = 1;   // strips per thread: 2 and 4 measured slower at every layer shape
@@ -764,6 +998,12 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
     const DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6);
     dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
+    return mds_check_launch("dw_fwd");
+  }
+  if (a->kt == 1 && a->stride == 2 && !getenv("MDS_DW_OLD")) {
+    const DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 3);
+    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw2s_fwd_kernel<T>, grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
   if (a->kt == 3 && a->T == DW3_T && !getenv("MDS_DW_OLD")) {
@@ -1012,6 +1252,18 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
     const DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4);
     dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_bwd_kernel<T, 4>), grid, block, 0, stream, *a, g));
+    return mds_check_launch("dw_bwd");
+  }
+  if (a->kt == 1 && a->stride == 2 && !getenv("MDS_DW_OLD")) {
+    MDS_REQUIRE((a->pad_t == 0 || a->pad_t == 1), "dw_bwd: pad_t");
+    const DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4, 16, true);
+    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    MDS_DISPATCH_DTYPE(a->dtype, T, {
+      if (a->pad_t == 0 && a->pad_l == 0) MDS_LAUNCH((dw2s_bwd_kernel<T, 0, 0>), grid, block, 0, stream, *a, g);
+      else if (a->pad_t == 0) MDS_LAUNCH((dw2s_bwd_kernel<T, 0, 1>), grid, block, 0, stream, *a, g);
+      else if (a->pad_l == 0) MDS_LAUNCH((dw2s_bwd_kernel<T, 1, 0>), grid, block, 0, stream, *a, g);
+      else MDS_LAUNCH((dw2s_bwd_kernel<T, 1, 1>), grid, block, 0, stream, *a, g);
+    });
     return mds_check_launch("dw_bwd");
   }
   if (a->kt == 3 && a->T == DW3_T && !getenv("MDS_DW_OLD")) {

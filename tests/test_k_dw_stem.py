@@ -31,6 +31,8 @@ DW_CASES = [  # N,T,H,W,C,stride,kt
     (3, 1, 5, 8, 136, 1, 1),
     (1, 1, 12, 18, 16, 2, 1),     # even: pad 0/1
     (2, 1, 11, 15, 24, 2, 1),     # odd: pad 1/1
+    (1, 1, 12, 15, 16, 2, 1),     # mixed: pad_t 0, pad_l 1
+    (1, 1, 11, 38, 72, 2, 1),     # mixed: pad_t 1, pad_l 0; several segments
     (2, 3, 5, 7, 24, 1, 3),
     (1, 5, 6, 9, 576, 1, 3),
 ]
