@@ -52,6 +52,14 @@ __global__ __launch_bounds__(256, WN == 2 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd
     }
   }
 
+  const T* xrow[NL];   // this thread's rows of the tile
+  bool xok[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const long m = m0 + srow + RPP * l;
+    xok[l] = m < a.M;
+    xrow[l] = x + (xok[l] ? m : 0) * K + 8 * svec;
+  }
   for (int n0 = blockIdx.y * BN; n0 < N; n0 += gridDim.y * BN) {
     int nfr = (N - n0 - 64 * wn) >> 4;  // valid 16-column fragments of this wave
     nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
@@ -62,16 +70,21 @@ __global__ __launch_bounds__(256, WN == 2 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     RawV8<T> rx[NL], rw[NLW];
+    const T* wrow[NLW];   // this thread's filter rows of the n-tile (row pointers hoisted out of the k-loop)
+    bool wok[NLW];
+#pragma unroll
+    for (int l = 0; l < NLW; ++l) {
+      const int n = n0 + srow + RPP * l;
+      wok[l] = n < N;
+      wrow[l] = w + (long)(wok[l] ? n : 0) * K + 8 * svec;
+    }
     auto issue = [&](int kc) {  // all global loads of one K-chunk
-      const int kk = kc + 8 * svec;
+      const bool kok = kc + 8 * svec < K;
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        const int r = srow + RPP * l;
-        const long m = m0 + r;
-        if (m < a.M && kk < K) rx[l].ld(x + m * K + kk); else rx[l].zero();
+        if (xok[l] && kok) rx[l].ld(xrow[l] + kc); else rx[l].zero();
         if (l < NLW) {
-          const int n = n0 + r;
-          if (n < N && kk < K) rw[l].ld(w + (long)n * K + kk); else rw[l].zero();
+          if (wok[l] && kok) rw[l].ld(wrow[l] + kc); else rw[l].zero();
         }
       }
     };
@@ -414,19 +427,39 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
 #pragma unroll
     for (int v = 0; v < KF; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // per-thread staging constants: row within a step, channel, validity, running pointers (the 64-bit
+  // address arithmetic per load and step was most of this loop's instruction count)
   RawV8<T> rx[XI], ry[YI];
+  int xr[XI], yr[YI];
+  bool xok[XI], yok[YI];
+  const T* px[XI];
+  const T* py[YI];
+#pragma unroll
+  for (int p = 0; p < XI; ++p) {
+    const int it = tid + 256 * p, kx = kt0 + 8 * (it % XCH);
+    xr[p] = it / XCH;
+    xok[p] = it < XN && kx < K;
+    px[p] = x + (mbeg + xr[p]) * K + (xok[p] ? kx : 0);
+  }
+#pragma unroll
+  for (int p = 0; p < YI; ++p) {
+    const int it = tid + 256 * p, n = n0 + 8 * (it % YCH);
+    yr[p] = it / YCH;
+    yok[p] = it < YN && n < N;
+    py[p] = dy + (mbeg + yr[p]) * N + (yok[p] ? n : 0);
+  }
+  const long xstep = (long)WG_ROWS * K, ystep = (long)WG_ROWS * N;
   auto issue = [&](long mb) {
+    const int left = (int)(mend - mb);   // rows of this step that exist
 #pragma unroll
     for (int p = 0; p < XI; ++p) {
-      const int it = tid + 256 * p, kx = kt0 + 8 * (it % XCH);
-      const long m = mb + it / XCH;
-      if (it < XN && m < mend && kx < K) rx[p].ld(x + m * K + kx); else rx[p].zero();
+      if (xok[p] && xr[p] < left) rx[p].ld(px[p]); else rx[p].zero();
+      px[p] += xstep;
     }
 #pragma unroll
     for (int p = 0; p < YI; ++p) {
-      const int it = tid + 256 * p, n = n0 + 8 * (it % YCH);
-      const long m = mb + it / YCH;
-      if (it < YN && m < mend && n < N) ry[p].ld(dy + m * N + n); else ry[p].zero();
+      if (yok[p] && yr[p] < left) ry[p].ld(py[p]); else ry[p].zero();
+      py[p] += ystep;
     }
   };
   issue(mbeg);
