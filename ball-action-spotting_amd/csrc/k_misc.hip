@@ -87,33 +87,41 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(mds_bn_finalize_args a
   __shared__ double red[2][8][FIN_CH];
   const int cl = threadIdx.x % FIN_CH, sg = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
+  const bool owner = sg == 0 && c < a.C;
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.training && a.num_batches_tracked) *a.num_batches_tracked += 1;
+  // the owner's parameter loads are requested before the statistics arrive: one memory round trip
+  float gam = 0.f, bet = 0.f, rm = 0.f, rv = 1.f;
+  if (owner) {
+    gam = a.gamma[c]; bet = a.beta[c];
+    if (a.running_mean) { rm = a.running_mean[c]; rv = a.running_var[c]; }
+  }
   if (a.training) fin_slot_sums(a.stats, a.C, c, sg, red, cl);
   __syncthreads();
-  if (sg != 0 || c >= a.C) return;
+  if (!owner) return;
   float mean, var;
   if (a.training) {
     double s = 0.0, ss = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
-    double m = s / (double)a.count;
-    double v = ss / (double)a.count - m * m;
+    const double inv = 1.0 / (double)a.count;
+    double m = s * inv;
+    double v = ss * inv - m * m;
     if (v < 0.0) v = 0.0;
     mean = (float)m;
     var = (float)v;
     if (a.running_mean) {
       float unb = a.count > 1 ? (float)(v * (double)a.count / (double)(a.count - 1)) : var;
-      a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-      a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * unb;
+      a.running_mean[c] = (1.0f - a.momentum) * rm + a.momentum * mean;
+      a.running_var[c] = (1.0f - a.momentum) * rv + a.momentum * unb;
     }
   } else {
-    mean = a.running_mean[c];
-    var = a.running_var[c];
+    mean = rm;
+    var = rv;
   }
   float rstd = 1.0f / sqrtf(var + a.eps);
-  float sc = a.gamma[c] * rstd;
+  float sc = gam * rstd;
   a.out[0 * a.C + c] = sc;
-  a.out[1 * a.C + c] = a.beta[c] - mean * sc;
+  a.out[1 * a.C + c] = bet - mean * sc;
   a.out[2 * a.C + c] = mean;
   a.out[3 * a.C + c] = rstd;
 }
@@ -130,17 +138,26 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mds_bn_bwd_finaliz
   __shared__ double red[2][8][FIN_CH];
   const int cl = threadIdx.x % FIN_CH, sg = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
+  const bool owner = sg == 0 && c < a.C;
+  // everything the channel's owner needs is requested up front: ONE memory round trip per launch
+  float gam = 0.f, rstd = 0.f, dg = 0.f, db = 0.f;
+  if (owner) {
+    gam = a.gamma[c]; rstd = a.bn[3 * a.C + c];
+    if (a.dgamma) dg = a.dgamma[c];
+    if (a.dbeta) db = a.dbeta[c];
+  }
   fin_slot_sums(a.stats, a.C, c, sg, red, cl);
   __syncthreads();
-  if (sg != 0 || c >= a.C) return;
+  if (!owner) return;
   double sg_ = 0.0, sgx = 0.0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sg_ += red[0][k][cl]; sgx += red[1][k][cl]; }
-  if (a.dgamma) a.dgamma[c] += (float)sgx;
-  if (a.dbeta) a.dbeta[c] += (float)sg_;
-  a.coef[0 * a.C + c] = a.gamma[c] * a.bn[3 * a.C + c];
-  a.coef[1 * a.C + c] = (float)(sg_ / (double)a.count);
-  a.coef[2 * a.C + c] = (float)(sgx / (double)a.count);
+  const float inv = 1.0f / (float)a.count;
+  if (a.dgamma) a.dgamma[c] = dg + (float)sgx;
+  if (a.dbeta) a.dbeta[c] = db + (float)sg_;
+  a.coef[0 * a.C + c] = gam * rstd;
+  a.coef[1 * a.C + c] = (float)sg_ * inv;
+  a.coef[2 * a.C + c] = (float)sgx * inv;
 }
 extern "C" int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->C > 0 && a->stats && a->gamma && a->bn && a->coef && a->count > 0,
