@@ -74,14 +74,14 @@ MDS_DEV void eval_g(const mds_gsrc_t& gs, long row, int c0, int C, const float (
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = u[j] * silu_gradf_(z[j]);
   } else if (gs.mode == MDS_G_SE_SILU) {
-    long grp = row / gs.rows_per_group;
+    const long grp = (long)((unsigned)row / (unsigned)gs.rows_per_group);   // rows < 2^32: a 32-bit divide is ~4x cheaper
     float ga[8], dp[8];
     load8f(gs.gate + grp * C + c0, ga);
     load8f(gs.dpooled + grp * C + c0, dp);
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = (u[j] * ga[j] + dp[j]) * silu_gradf_(z[j]);
   } else {  // MDS_G_MASK
-    float mk = gs.mask ? gs.mask[row / gs.rows_per_group] : 1.0f;
+    float mk = gs.mask ? gs.mask[(unsigned)row / (unsigned)gs.rows_per_group] : 1.0f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = u[j] * mk;
   }

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void bn_res_kernel(mds_bn_res_args a) {
   for (long row = (long)blockIdx.x * m.rpb + m.rsub; row < a.M; row += (long)gridDim.x * m.rpb) {
     float v[8];
     load8(y + row * a.C + c0, v);
-    float mk = a.mask ? a.mask[row / a.rows_per_group] : 1.0f;
+    float mk = a.mask ? a.mask[(unsigned)row / (unsigned)a.rows_per_group] : 1.0f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float z = v[j] * sc[j] + sh[j];
@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void bn_res_kernel(mds_bn_res_args a) {
   }
 }
 extern "C" int mds_bn_res(const mds_bn_res_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->M < 4294967295L, "bn_res: M must be below 2^32 rows");
   MDS_REQUIRE(a && a->M > 0 && a->C > 0 && a->C % 8 == 0 && a->C <= 2048, "bn_res: bad dims M=%ld C=%d", a ? a->M : 0, a ? a->C : 0);
   MDS_REQUIRE(a->y && a->out && a->scale && a->shift, "bn_res: null pointer");
   MDS_REQUIRE(!a->mask || a->rows_per_group > 0, "bn_res: mask needs rows_per_group");
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_ar
   }
 }
 extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->M < 4294967295L, "bn_bwd_reduce: M must be below 2^32 rows");
   MDS_REQUIRE(a && a->M > 0 && a->C % 8 == 0 && a->C <= 2048, "bn_bwd_reduce: bad dims");
   MDS_REQUIRE(a->g.u && a->y && a->bn && a->stats, "bn_bwd_reduce: null pointer");
   MDS_REQUIRE(a->g.mode == MDS_G_PLAIN || a->g.mode == MDS_G_SILU || a->g.rows_per_group > 0, "bn_bwd_reduce: rows_per_group");
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(mds_bn_bwd_apply_args
   }
 }
 extern "C" int mds_bn_bwd_apply(const mds_bn_bwd_apply_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->M < 4294967295L, "bn_bwd_apply: M must be below 2^32 rows");
   MDS_REQUIRE(a && a->M > 0 && a->C % 8 == 0 && a->C <= 2048, "bn_bwd_apply: bad dims");
   MDS_REQUIRE(a->g.u && a->y && a->bn && a->coef && a->dy, "bn_bwd_apply: null pointer");
   MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_apply_kernel<T>, dim3(stream_blocks(a->M, a->C)), dim3(256), 0, stream, *a));
