@@ -25,19 +25,21 @@ template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 
 // WN = waves along N: 2 -> 128x128 tile (2x2 waves of 64x64), two blocks per CU;
 //                      1 -> 128x64 tile (4x1 waves of 32x64), ~160 VGPRs, three blocks per CU.
-template <typename T, int PRO, int WN>
-__global__ __launch_bounds__(256, WN == 2 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+// BM = rows per tile: 128, or 64 for the small-M layers (stage 5 / 3D: 18400 rows are only 144 tiles of 128 —
+//      fewer blocks than CUs); WN = 2 only.
+template <typename T, int PRO, int WN, int BM>
+__global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
   typedef typename Frag<T>::type frag_t;
-  constexpr int KC = PwCfg<T>::KC, LD = PwCfg<T>::LD, VPR = KC / 8, RPP = 256 / VPR, NL = PW_BM / RPP;
-  constexpr int BN = 64 * WN, MFW = 2 * WN, NLW = BN / RPP;   // tile columns, m-fragments per wave, filter rows per thread
+  constexpr int KC = PwCfg<T>::KC, LD = PwCfg<T>::LD, VPR = KC / 8, RPP = 256 / VPR, NL = BM / RPP;
+  constexpr int BN = 64 * WN, MFW = (WN == 2 ? BM / 32 : BM / 64), NLW = BN / RPP;   // tile columns, m-fragments per wave, filter rows per thread
   MDS_DYN_SMEM(smem);
-  T* xs = (T*)smem;                          // [PW_BM][LD]
-  T* ws = xs + PW_BM * LD;                   // [BN][LD]
+  T* xs = (T*)smem;                          // [BM][LD]
+  T* ws = xs + BM * LD;                      // [BN][LD]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
-  const long m0 = (long)blockIdx.x * PW_BM;
+  const long m0 = (long)blockIdx.x * BM;
   const int K = a.K, N = a.N;
   const T* x = (const T*)a.x;
   const T* w = (const T*)a.w;
@@ -83,9 +85,10 @@ __global__ __launch_bounds__(256, WN == 2 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
         if (xok[l] && kok) rx[l].ld(xrow[l] + kc); else rx[l].zero();
-        if (l < NLW) {
-          if (wok[l] && kok) rw[l].ld(wrow[l] + kc); else rw[l].zero();
-        }
+      }
+#pragma unroll
+      for (int l = 0; l < NLW; ++l) {
+        if (wok[l] && kok) rw[l].ld(wrow[l] + kc); else rw[l].zero();
       }
     };
     issue(0);
@@ -208,14 +211,18 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   // 154 -> 119 us at 1.18 M x 128 -> 32); wider N measured 5-20 % slower with them despite 3 blocks/CU
   const int wn = a->N <= 64 ? 1 : 2;
   const int BN = 64 * wn;
-  const int mt = cdiv(a->M, PW_BM), nt = cdiv(a->N, BN);
+  // 64-row tiles below 400 k rows: twice the blocks for the stage-3..5 / 3D layers (isolated: -10...25 %;
+  // inside the step, where the weight-gradient stream fills the idle CUs anyway, +1 %)
+  const int bm = (wn == 2 && a->M <= 400000) ? 64 : PW_BM;
+  const int mt = cdiv(a->M, bm), nt = cdiv(a->N, BN);
   int gy = 1;
   if (nt > 1) { gy = cdiv(1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
   dim3 grid(mt, gy), block(256);
 #define PW_GO(T, PRO) \
-  do { const size_t smem = (size_t)(PW_BM + BN) * PwCfg<T>::LD * sizeof(T); \
-       if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2>), grid, block, smem, stream, *a); \
-       else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1>), grid, block, smem, stream, *a); } while (0)
+  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T); \
+       if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64>), grid, block, smem, stream, *a); \
+       else if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 128>), grid, block, smem, stream, *a); \
+       else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1, 128>), grid, block, smem, stream, *a); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: PW_GO(T, MDS_PRO_NONE); break;
