@@ -7,6 +7,8 @@
 // and zero padding applied after it — together with the weights of ALL taps, so the 9-tap MFMA
 // loop runs without a barrier: 2 barriers per chunk, 0.5 LDS fragment reads per MFMA.
 // Arithmetic intensity 100-600 FLOP/B: MFMA-bound layers.
+// The thin layers (whole filter slab + whole-channel patch in <= 76 KB of LDS) take the persistent
+// kernel conv_fwd_p_kernel instead; conv_wgrad_kernel is the weight gradient of both.
 #include <stdlib.h>
 #include "gemm.h"
 

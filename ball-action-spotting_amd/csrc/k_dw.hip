@@ -1,13 +1,17 @@
 // k_dw.hip — depthwise 3x3 (2D, stride 1 / TF-SAME stride 2) and 3x3x3 (3D) convolutions.
 //
-// HBM-bound VALU kernels (9 or 27 MACs per element); what limits them in practice is memory
-// latency, so both directions are LDS-tiled: a block owns an 8x16 pixel patch of a 128-byte
-// channel slab (64 bf16 / 32 fp32 channels), issues ALL global loads of the patch (+halo) back to
-// back (clamped addresses, masked afterwards), applies the producer's BN+SiLU once per element on
-// the way into LDS (zero padding after the activation), and then computes out of LDS.  For the
-// 3x3x3 case the block walks the T slices with a 3-slot ring, so every input slice is read once.
-// Filter taps sit in LDS ([tap][slab]); BatchNorm sums and filter gradients are reduced with wave
-// shuffles + LDS, then written with coalesced atomics in the parameter's own order.
+// HBM-bound VALU kernels (9 or 27 MACs per element).  Two generations live here:
+//   * the REGISTER SLIDING-WINDOW kernels (dw2_*, dw2s_*, dw3_*: second half of the file) serve every
+//     layer of the headline configuration: a lane owns a channel pair, a half-wave a 128-byte line, a
+//     thread walks a strip of rows keeping the activated window in registers — no LDS tiles, no
+//     barriers, 3-4 waves per SIMD (2.4-3.4x the tiled kernels);
+//   * the LDS-TILED kernels (dw_fwd_kernel / dw_bwd_kernel, first half) remain for the 3x3x3 case
+//     with T != 5 (frozen-encoder configuration, 11 slices): a block owns an 8x16 pixel patch of a
+//     128-byte channel slab, issues all global loads of the patch (+halo) back to back, applies the
+//     producer's BN+SiLU once per element on the way into LDS (zero padding after the activation) and
+//     walks the T slices with a 3-slot ring.
+// In both, BatchNorm sums and filter gradients are reduced in the block (shuffles / LDS) and written
+// with coalesced atomics in the parameter's own order.
 #include <stdlib.h>
 #include "elem.h"
 
