@@ -337,8 +337,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_p_kernel(mds_conv_fwd_args a,
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int xo_next = ktab[q];
     for (int s = 0; s < KS; ++s) {
-      const int xo = ktab[4 * s + q];
+      const int xo = xo_next;   // the tap-offset lookup of step s+1 is issued a step ahead: the fragment
+      xo_next = ktab[4 * (s + 1 < KS ? s + 1 : s) + q];   // addresses no longer wait for two LDS round trips
       frag_t xf[MF], wf[4];
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) xf[mf] = ld_frag(xs + xbase[mf] + xo);
