@@ -213,6 +213,13 @@ template <int RB>
 __global__ __launch_bounds__(256) void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
   __shared__ float part[4][SE_RMAX], hid[SE_RMAX], act[SE_RMAX];
   const int g = blockIdx.x, c = blockIdx.y * SE_CCH + threadIdx.x;
+  const bool cok = c < a.C;
+  // this thread's column of w2 and its bias do not depend on the hidden vector: requested first
+  float w2c[RB], s = 0.f;
+  if (cok) s = a.b2[c];
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+    w2c[r] = (cok && r < a.R) ? (a.w2t ? a.w2t[(long)r * a.C + c] : a.w2[(long)c * a.R + r]) : 0.f;
   se_matvec_rc<RB>(a.w1, a.pooled + (long)g * a.C, a.R, a.C, part, hid);
   if (threadIdx.x < a.R) {
     const float h = hid[threadIdx.x] + a.b1[threadIdx.x];
@@ -220,15 +227,9 @@ __global__ __launch_bounds__(256) void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
     if (blockIdx.y == 0) a.hidden[g * a.R + threadIdx.x] = h;
   }
   __syncthreads();
-  if (c >= a.C) return;
-  float s = a.b2[c];
-  if (a.w2t) {
-#pragma unroll 12
-    for (int r = 0; r < a.R; ++r) s += a.w2t[(long)r * a.C + c] * act[r];
-  } else {
-    const float* w = a.w2 + (long)c * a.R;
-    for (int r = 0; r < a.R; ++r) s += w[r] * act[r];
-  }
+  if (!cok) return;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) s += w2c[r] * (r < a.R ? act[r] : 0.f);
   a.gate[(long)g * a.C + c] = sigmoidf_(s);
 }
 extern "C" int mds_se_fc_fwd(const mds_se_fc_fwd_args* a, mds_stream_t stream) {
@@ -249,11 +250,29 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(mds_se_fc_bwd_args a) {
   __shared__ float part[4][SE_RMAX], dh[SE_RMAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x, C = a.C, R = a.R;
+  const int c = blockIdx.y * SE_CCH + tid;
+  const bool cok = c < C;
+  // Everything that does not depend on dh is requested FIRST (the kernel is a chain of memory round
+  // trips): this thread's column of w1, its gate, and the BatchNorm partial sums of its channel.
+  float w1c[RB], gt_c = 0.f, bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < RB; ++r) w1c[r] = (cok && r < R) ? a.w1[(long)r * C + c] : 0.f;
+  const bool bn = a.bnsums && a.bn_stats;
+  if (cok) {
+    gt_c = a.gate[(long)g * C + c];
+    if (bn) {
+      const float* b = a.bnsums + (long)g * a.bn_nblk * 4 * C + c;
+#pragma unroll 8
+      for (int k = 0; k < a.bn_nblk; ++k, b += 4 * C) {
+        bs[0] += b[0]; bs[1] += b[C]; bs[2] += b[2 * C]; bs[3] += b[3 * C];
+      }
+    }
+  }
   if (a.w2t) {  // de[c] staged once, then the block-wide [R][C] mat-vec
     __shared__ float de_s[2048];
-    for (int c = tid; c < C; c += 256) {
-      const float gt = a.gate[(long)g * C + c];
-      de_s[c] = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
+    for (int cc = tid; cc < C; cc += 256) {
+      const float gt = a.gate[(long)g * C + cc];
+      de_s[cc] = a.dgate[(long)g * C + cc] * gt * (1.0f - gt);
     }
     __syncthreads();
     se_matvec_rc<RB>(a.w2t, de_s, R, C, part, dh);
@@ -266,10 +285,10 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(mds_se_fc_bwd_args a) {
     float acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-    for (int c = tid; c < C; c += 256) {
-      const float gt = a.gate[(long)g * C + c];
-      const float de = a.dgate[(long)g * C + c] * gt * (1.0f - gt);
-      const float* w = a.w2 + (long)c * R;
+    for (int cc = tid; cc < C; cc += 256) {
+      const float gt = a.gate[(long)g * C + cc];
+      const float de = a.dgate[(long)g * C + cc] * gt * (1.0f - gt);
+      const float* w = a.w2 + (long)cc * R;
 #pragma unroll
       for (int r = 0; r < RB; ++r) acc[r] += de * w[r < R ? r : R - 1];
     }
@@ -287,23 +306,15 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(mds_se_fc_bwd_args a) {
     }
   }
   __syncthreads();
-  const int c = blockIdx.y * SE_CCH + tid;
-  if (c >= C) return;
+  if (!cok) return;
   float dp = 0.f;
-#pragma unroll 12
-  for (int r = 0; r < R; ++r) dp += dh[r] * a.w1[(long)r * C + c];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) dp += (r < R ? dh[r] : 0.f) * w1c[r];
   dp /= (float)a.rows_per_group;
   a.dpooled[(long)g * C + c] = dp;
-  if (a.bnsums && a.bn_stats) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* b = a.bnsums + (long)g * a.bn_nblk * 4 * C + c;
-#pragma unroll 8
-    for (int k = 0; k < a.bn_nblk; ++k, b += 4 * C) {
-      s[0] += b[0]; s[1] += b[C]; s[2] += b[2 * C]; s[3] += b[3 * C];
-    }
-    const float gt = a.gate[(long)g * C + c];
-    atomicAdd(a.bn_stats + c, gt * s[0] + dp * s[2]);
-    atomicAdd(a.bn_stats + C + c, gt * s[1] + dp * s[3]);
+  if (bn) {
+    atomicAdd(a.bn_stats + c, gt_c * bs[0] + dp * bs[2]);
+    atomicAdd(a.bn_stats + C + c, gt_c * bs[1] + dp * bs[3]);
   }
 }
 // launch B — parameter gradients: dw2[c][r], dw1[r][c] (thread per (r, c), c fastest); r == 0
