@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
   int* toff = (int*)(st_ss + CV_BN);                   // [ntaps] LDS element offset of each tap
   int* twi = toff + MDS_MAX_TAPS;                      // [ntaps] weight slot of each tap
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int b0 = blockIdx.x * CV_TB, a0 = blockIdx.y * TA, img = blockIdx.z;
   const int Cin = a.Cin, Cout = a.Cout;

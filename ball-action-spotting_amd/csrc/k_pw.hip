@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
   T* xs = (T*)smem;                          // [BM][LD]
   T* ws = xs + BM * LD;                      // [BN][LD]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);   // scalar: "nf < nfr" must be a scalar branch, not an exec-mask dance per fragment
   const int i = lane & 15, q = lane >> 4;
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const long m0 = (long)blockIdx.x * BM;
@@ -137,12 +137,10 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
 #pragma unroll
           for (int mf = 0; mf < MFW; ++mf) xf[mf] = ld_frag(xs + (16 * MFW * wm + 16 * mf + i) * LD + 32 * ks + 8 * q);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) {
-            if (nf < nfr) {
-              frag_t wf = ld_frag(ws + (64 * wn + 16 * nf + i) * LD + 32 * ks + 8 * q);
+          for (int nf = 0; nf < 4; ++nf) {   // no "nf < nfr" test here: filter rows past N are staged as zeros,
+            frag_t wf = ld_frag(ws + (64 * wn + 16 * nf + i) * LD + 32 * ks + 8 * q);   // and a branch-free k-loop schedules better
 #pragma unroll
-              for (int mf = 0; mf < MFW; ++mf) mma16(wf, xf[mf], acc[mf][nf]);  // acc[r] = y[m = i][n = 4q + r]
-            }
+            for (int mf = 0; mf < MFW; ++mf) mma16(wf, xf[mf], acc[mf][nf]);  // acc[r] = y[m = i][n = 4q + r]
           }
         }
       }
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
   MDS_DYN_SMEM(smem);
   T* xsT = (T*)smem;          // [KT][LDT]  channel-major
   T* dsT = xsT + KT * LDT;    // [NT][LDT]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int K = a.K, N = a.N;
   const int ntiles_k = (K + KT - 1) / KT;
