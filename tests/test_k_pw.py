@@ -35,8 +35,11 @@ def _apply_pro(x, mode, scale, shift, gate, rpg):
     (200, 112, 32, 3, False, True),
     (130, 16, 16, 1, True, False),
     (257, 192, 192, 0, True, False),
+    (400300, 16, 144, 2, False, True),  # above 400 k rows: the 128-row tile path (GPU only: too slow to simulate)
 ])
 def test_pw_fwd(be, dt, M, K, N, mode, res, stats):
+    if M > 100000 and be.name == "emu":
+        pytest.skip("large-M tile path is exercised on the GPU")
     code, tdt = DT[dt]
     g = torch.Generator().manual_seed(M * 7 + K)
     rpg = 50
