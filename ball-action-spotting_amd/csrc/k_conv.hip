@@ -418,7 +418,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
     const int KS = cdiv(a->ntaps * a->Cin, 32);
     const size_t esz = a->dtype == MDS_BF16 ? 2 : 4;
     const size_t smem = ((size_t)TH * TW * cvp_pitch_h(a->Cin, (int)esz) + (size_t)CV_BN * cvp_pitch_h(KS * 32, (int)esz)) * esz + 2 * CV_BN * sizeof(float) + (size_t)KS * 16;
-    if (TH * TW * (a->Cin / 8) <= 10 * 256 && smem <= 76 * 1024 && !getenv("MDS_CONV_OLD")) {  // two blocks per CU (measured: one resident block loses to the tile-per-block kernel)
+    if (TH * TW * (a->Cin / 8) <= 10 * 256 && smem <= 76 * 1024 && !mds_switch(MDS_SW_CONV_OLD)) {  // two blocks per CU (measured: one resident block loses to the tile-per-block kernel)
       const int tiles_a = cdiv(a->A, TA), tiles_b = cdiv(a->B, CV_TB);
       const long total = (long)a->N * tiles_a * tiles_b;
       const int nt = cdiv(a->Cout, CV_BN);

@@ -997,20 +997,20 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "dw_fwd: prologue");
   MDS_REQUIRE(a->pro.mode != MDS_PRO_BN_SILU_GATE, "dw_fwd: gate prologue unsupported");
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_fwd: grid.z");
-  if (a->kt == 1 && a->stride == 1 && !getenv("MDS_DW_OLD")) {
+  if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE(a->pad_t == 1 && a->pad_l == 1 && a->OH == a->IH && a->OW == a->IW, "dw_fwd: stride-1 geometry");
     const DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6);
     dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
-  if (a->kt == 1 && a->stride == 2 && !getenv("MDS_DW_OLD")) {
+  if (a->kt == 1 && a->stride == 2 && !mds_switch(MDS_SW_DW_OLD)) {
     const DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 3);
     dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw2s_fwd_kernel<T>, grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
-  if (a->kt == 3 && a->T == DW3_T && !getenv("MDS_DW_OLD")) {
+  if (a->kt == 3 && a->T == DW3_T && !mds_switch(MDS_SW_DW_OLD)) {
     DwStrips g = dw_strips(a->N, a->OH, a->OW, a->C, 1, 20);   // strip length measured: 8/16/20/40 -> 38/39/36/63 us
     dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_fwd_kernel<T>, grid, block, 0, stream, *a, g));
@@ -1251,14 +1251,14 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_BN_SILU && a->pro.scale && a->pro.shift, "dw_bwd: needs the BN+SiLU prologue of the forward");
   MDS_REQUIRE(a->stride == 2 ? (a->pad_l == 0 || a->pad_l == 1) : (a->pad_l == 1 && a->pad_t == 1), "dw_bwd: pad=(%d,%d) unsupported for stride %d", a->pad_t, a->pad_l, a->stride);
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_bwd: grid.z");
-  if (a->kt == 1 && a->stride == 1 && !getenv("MDS_DW_OLD")) {
+  if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE(a->OH == a->IH && a->OW == a->IW, "dw_bwd: stride-1 geometry");
     const DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4);
     dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_bwd_kernel<T, 4>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_bwd");
   }
-  if (a->kt == 1 && a->stride == 2 && !getenv("MDS_DW_OLD")) {
+  if (a->kt == 1 && a->stride == 2 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE((a->pad_t == 0 || a->pad_t == 1), "dw_bwd: pad_t");
     const DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4, 16, true);
     dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
@@ -1270,7 +1270,7 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
     });
     return mds_check_launch("dw_bwd");
   }
-  if (a->kt == 3 && a->T == DW3_T && !getenv("MDS_DW_OLD")) {
+  if (a->kt == 3 && a->T == DW3_T && !mds_switch(MDS_SW_DW_OLD)) {
     DwStrips g = dw_strips(a->N, a->IH, a->IW, a->C, 1, 16);   // 8/16/20/40 -> 80/67/82/145 us
     dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_bwd_kernel<T>, grid, block, 0, stream, *a, g));

@@ -1,6 +1,7 @@
 // k_misc.hip — error plumbing and the latency-class kernels (tiny per-channel / per-group math).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "elem.h"
 
 static thread_local char g_err[512] = "";
@@ -18,6 +19,11 @@ int mds_check_launch(const char* what) {
     return MDS_ERR_LAUNCH;
   }
   return 0;
+}
+bool mds_switch(int id) {   // thread-safe one-time read (C++11 static initialisation)
+  static const bool v[MDS_SW_COUNT] = {getenv("MDS_DW_OLD") != 0, getenv("MDS_CONV_OLD") != 0, getenv("MDS_WG_OLD") != 0,
+                                       getenv("MDS_STEM_OLD") != 0};
+  return id >= 0 && id < MDS_SW_COUNT && v[id];
 }
 extern "C" int mds_version(void) { return MDS_VERSION; }
 extern "C" const char* mds_last_error(void) { return g_err; }
@@ -156,8 +162,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mds_bn_bwd_finaliz
   if (a.dgamma) a.dgamma[c] = dg + (float)sgx;
   if (a.dbeta) a.dbeta[c] = db + (float)sg_;
   a.coef[0 * a.C + c] = gam * rstd;
-  a.coef[1 * a.C + c] = (float)sg_ * inv;
-  a.coef[2 * a.C + c] = (float)sgx * inv;
+  a.coef[1 * a.C + c] = a.batch_stats ? (float)sg_ * inv : 0.0f;
+  a.coef[2 * a.C + c] = a.batch_stats ? (float)sgx * inv : 0.0f;
 }
 extern "C" int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->C > 0 && a->stats && a->gamma && a->bn && a->coef && a->count > 0,

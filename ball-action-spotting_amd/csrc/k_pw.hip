@@ -571,7 +571,7 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4>), grid, block, (size_t)(KT + NT) * WgCfg<T>::LDT * sizeof(T), stream, *a, (int)rpb)
 #define WGT_GO(PRO) \
   MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4>), grid, block, (size_t)WG_ROWS * (KT + 16 + NT + 16) * sizeof(bf16_t), stream, *a, (int)rpb)
-  if (a->dtype == MDS_BF16 && !getenv("MDS_WG_OLD")) {
+  if (a->dtype == MDS_BF16 && !mds_switch(MDS_SW_WG_OLD)) {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: WGT_GO(MDS_PRO_NONE); break;
       case MDS_PRO_AFFINE: WGT_GO(MDS_PRO_AFFINE); break;

@@ -305,7 +305,7 @@ extern "C" int mds_stem_wgrad(const mds_stem_wgrad_args* a, mds_stream_t stream)
   MDS_REQUIRE(a && a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0, "stem_wgrad: bad dims");
   MDS_REQUIRE(a->Cout % 16 == 0 && a->Cout <= 32, "stem_wgrad: Cout=%d must be 16 or 32", a->Cout);
   MDS_REQUIRE(a->x && a->dy && a->dw, "stem_wgrad: null pointer");
-  if (a->dtype == MDS_BF16 && !getenv("MDS_STEM_OLD")) {
+  if (a->dtype == MDS_BF16 && !mds_switch(MDS_SW_STEM_OLD)) {
     const int tiles_a = cdiv(a->OH, SW_ROWS), tiles_b = cdiv(a->OW, SW_COLS);
     const long total = (long)a->N * tiles_a * tiles_b;
     const int tpb = (int)cdiv(total, total < 768 ? total : 768);   // three blocks per CU

@@ -9,6 +9,7 @@
 
 #ifndef MDS_EMU
 #include <hip/hip_runtime.h>
+#include <atomic>
 #endif
 
 #include "../../include/mds.h"
@@ -130,11 +131,11 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
 #define MDS_LAUNCH(kernel, grid, block, smem, stream, ...)                                          \
   do {                                                                                              \
     const size_t mds_smem_ = (size_t)(smem);                                                        \
-    if (mds_smem_ > 65536) {                                                                        \
-      static size_t mds_cur_ = 0;                                                                   \
-      if (mds_smem_ > mds_cur_) {                                                                   \
+    if (mds_smem_ > 65536) { /* opt-in is idempotent; the high-water mark only avoids repeating it */ \
+      static std::atomic<size_t> mds_cur_{0};                                                       \
+      if (mds_smem_ > mds_cur_.load(std::memory_order_relaxed)) {                                   \
         (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mds_smem_); \
-        mds_cur_ = mds_smem_;                                                                       \
+        mds_cur_.store(mds_smem_, std::memory_order_relaxed);                                       \
       }                                                                                             \
     }                                                                                               \
     hipLaunchKernelGGL(kernel, grid, block, mds_smem_, (hipStream_t)(stream), __VA_ARGS__);        \
@@ -250,6 +251,12 @@ MDS_DEV float wave_sum(float v) {
   return v;
 }
 #endif
+
+// ------------------------------------------------------------------ developer switches
+// MDS_*_OLD environment variables select the previous kernel generation of a family for A/B timing.
+// They are read ONCE per process (k_misc.hip), never on the launch path.
+enum { MDS_SW_DW_OLD = 0, MDS_SW_CONV_OLD, MDS_SW_WG_OLD, MDS_SW_STEM_OLD, MDS_SW_COUNT };
+bool mds_switch(int id);
 
 // ------------------------------------------------------------------ error plumbing (C ABI)
 void mds_set_error(const char* fmt, ...);

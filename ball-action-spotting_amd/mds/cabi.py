@@ -15,7 +15,10 @@ from typing import Dict
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
-HEADER = os.path.join(REPO_ROOT, "include", "mds.h")
+# the development tree keeps ONE header (include/mds.h); `make` ships a copy next to this file so that the
+# package still works when ball-action-spotting_amd/ is installed without the repository around it
+HEADER = next((h for h in (os.path.join(REPO_ROOT, "include", "mds.h"), os.path.join(HERE, "mds_abi.h")) if os.path.exists(h)),
+              os.path.join(REPO_ROOT, "include", "mds.h"))
 HIP_LIB = os.path.join(PKG_ROOT, "csrc", "libmds_hip.so")
 
 _SCALARS = {

@@ -18,6 +18,7 @@ Reference mapping: forward_2d / forward_3d / forward_head of
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import ctypes as C
 from typing import Dict, List, Optional
@@ -92,7 +93,7 @@ class BNL:
             pb.op(seg, "bn_bwd_reduce", dtype=pb.code, M=M, C=self.C, g=gsrc, y=y, bn=self.buf, stats=self.bstats)
         pb.op(seg, "bn_bwd_finalize", C=self.C, count=M, stats=self.bstats, gamma=P(self.mod.weight), bn=self.buf,
               dgamma=None if frozen else pb.grad(self.mod.weight), dbeta=None if frozen else pb.grad(self.mod.bias),
-              coef=self.coef)
+              coef=self.coef, batch_stats=int(pb.batch_stats))
         pb.op(seg, "bn_bwd_apply", dtype=pb.code, M=M, C=self.C, g=gsrc, y=y, bn=self.buf, coef=self.coef, dy=dy)
 
 
@@ -161,6 +162,7 @@ class Plan:
         self.enc_grad = enc_grad and need_grad
         self.m = module
         self.in_flight = False
+        self.generation = 0      # bumped by every grad-enabled forward: a stale autograd node must not run
         self.profile = None      # list -> run() brackets every launch with HIP events
         self._lazy: List[Lazy] = []
         self._zf, self._zb = 0, 0
@@ -238,12 +240,12 @@ class Plan:
         else:
             h, w = H, W  # for '3d' / 'head' plans H, W are the feature-map extent
             self.h, self.w = h, w
-        if self.kind in ("full", "3d"):
-            if self.kind == "3d":
+        if self.kind in ("full", "3d", "tail"):
+            if self.kind != "full":
                 self.feat = self.act(N * h * w, m.num_3d_features)
             yq, bnq = self._build_3d(B, S, h, w, self.feat)
             self.yq, self.bnq = yq, bnq
-        if self.kind in ("full", "head"):
+        if self.kind in ("full", "head", "tail"):
             if self.kind == "head":
                 self.yq, self.bnq = self.act(N * h * w, m.num_features // S), None
             self._build_head(B, S, h, w, self.yq, self.bnq)
@@ -261,6 +263,7 @@ class Plan:
                         break
                 if gout is None:
                     break
+            self.dfeat = gout if self.kind == "tail" else None   # "tail": gradient wrt the (b,S,h,w,192) features
 
     # -- helpers emitting a conv + its BN finalize
     def _pw(self, seg, x, M, K, N_, wparam, pro=None, stats_bn=None, residual=None, wt=None):
@@ -598,7 +601,12 @@ class Plan:
 
     # ------------------------------------------------------------------ execution
     def _stream(self):
-        return torch.cuda.current_stream().cuda_stream if self.device.type == "cuda" else 0
+        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+
+    def device_guard(self):
+        """every launch, the side stream and the mask RNG belong to the plan's device, whatever the
+        caller's current device is"""
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
 
     SIDE_OPS = ("pw_wgrad", "conv_wgrad", "stem_wgrad")
 
@@ -616,7 +624,7 @@ class Plan:
         # Backward: the weight-gradient GEMMs are leaves of the dependency graph (they only add
         # into the gradient arena), so they go to a second HIP stream and fill the CUs that the
         # short dgrad / BN-backward launches of the critical path leave idle.
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(self.device)
         side_h = side.cuda_stream
         evs, n = self._side_events, 0
         for name, fn, st, ref in self.bound[seg]:
@@ -635,7 +643,7 @@ class Plan:
     def join_backward(self):
         """the gradient arena is complete once the side stream has drained"""
         if getattr(self, "_side", None) is not None and self.profile is None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
 
     def _side_stream(self):
         if self.device.type != "cuda" or os.environ.get("MDS_SIDE_STREAM", "1") == "0":
@@ -669,6 +677,9 @@ class Plan:
         for st, field in self.input_slots:
             setattr(st, field, ptr)
         self._x_ref = x
+
+    def bind_dlogits(self, dlogits):
+        self.dlogits.tensor.copy_(dlogits.reshape(-1).float())
 
     def begin_forward(self, mask_override=None):
         self.zf_arena.tensor.zero_()

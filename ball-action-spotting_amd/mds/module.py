@@ -5,9 +5,16 @@ Same constructor, attributes, methods and ``state_dict`` as the reference class
 ``src/predictors.py`` and ``src/ema.py`` run on it unchanged.  All arithmetic
 runs in the hand-written gfx950 kernels of ``libmds_hip.so`` (C ABI: include/mds.h) driven by
 ``engine.Plan``; if the library is missing this module raises — there is no eager/CPU fallback.
+
+``torch.compile(module)`` (``scripts/ball_action/train.py:83-86``) is supported by construction: the
+public forwards are ``torch.compiler.disable``d, i.e. Dynamo treats the whole hot path as ONE opaque
+call (it already is a static launch schedule; there is nothing for a tracing compiler to add) and
+never traces into the planner.
 """
 from __future__ import annotations
 
+import warnings
+from collections import OrderedDict
 from typing import Optional
 
 import torch
@@ -17,19 +24,36 @@ from . import cabi
 from .engine import Plan
 from .structure import (EncoderP, InvertedResidual3dP, GeneralizedMeanPoolingP, TAIL_BN_EPS)
 
+MAX_PLANS = 8     # launch plans kept per module (LRU); each pins its activation arena (12 GB at config 2)
+
 
 class _PlanCache:
-    """Per-module cache of launch plans.  Never copied or pickled (EMA deep-copies the module,
+    """Per-module LRU cache of launch plans.  Never copied or pickled (EMA deep-copies the module,
     src/ema.py:40): a copy starts with an empty cache and re-plans on first use."""
 
     def __init__(self):
-        self.plans = {}
+        self.plans = OrderedDict()       # key -> [Plan, ...]
 
     def __deepcopy__(self, memo):
         return _PlanCache()
 
     def __reduce__(self):
         return (_PlanCache, ())
+
+    def count(self):
+        return sum(len(v) for v in self.plans.values())
+
+    def evict(self, keep_key):
+        """drop least-recently-used idle plans until at most MAX_PLANS remain"""
+        for key in list(self.plans):
+            if self.count() <= MAX_PLANS:
+                break
+            if key == keep_key:
+                continue
+            pool = self.plans[key]
+            pool[:] = [p for p in pool if p.in_flight]
+            if not pool:
+                del self.plans[key]
 
 
 class _Release:
@@ -39,7 +63,9 @@ class _Release:
         self.plan = plan
 
     def __del__(self):
-        self.plan.in_flight = False
+        plan = getattr(self, "plan", None)      # __del__ may run on a half-built / torn-down object
+        if plan is not None:
+            plan.in_flight = False
 
 
 class _MDSFunction(torch.autograd.Function):
@@ -47,24 +73,36 @@ class _MDSFunction(torch.autograd.Function):
     def forward(ctx, x, module, plan, *params):
         ctx.plan, ctx.module = plan, module
         ctx.token = _Release(plan)
+        ctx.consumed = False
+        ctx.save_for_backward(x)           # version-checked: an in-place edit of x before backward raises
         plan.in_flight = True
-        plan.bind_input(x)
-        plan.begin_forward(module._mask_override)
-        plan.run("f2d"); plan.run("f3d"); plan.run("fhead")
-        B = x.shape[0]
-        return plan.logits.tensor.view(B, -1).clone()
+        plan.generation += 1
+        ctx.generation = plan.generation
+        with plan.device_guard():
+            plan.bind_input(x)
+            plan.begin_forward(module._mask_override)
+            plan.run("f2d"); plan.run("f3d"); plan.run("fhead")
+            B = x.shape[0]
+            return plan.logits.tensor.view(B, -1).clone()
 
     @staticmethod
     def backward(ctx, dlogits):
         plan = ctx.plan
-        plan.dlogits.tensor.copy_(dlogits.reshape(-1).float())
-        plan.begin_backward()
-        plan.run("bhead"); plan.run("b3d"); plan.run("b2d")
-        plan.join_backward()
-        flat = plan.grad_arena.tensor.clone()      # one launch; the arena is reused next step
-        sync = getattr(ctx.module, "_grad_sync", None)
-        if sync is not None:
-            sync(flat)                             # data parallel: one RCCL all-reduce of the flat buffer
+        if ctx.consumed or ctx.generation != plan.generation:
+            raise RuntimeError("mds: the activations of this forward have been released (backward already ran, or the "
+                               "plan was reused by a later forward); a second backward / retain_graph is not supported")
+        (x,) = ctx.saved_tensors            # raises if x was modified in place since forward
+        ctx.consumed = True
+        with plan.device_guard():
+            plan.bind_input(x)
+            plan.bind_dlogits(dlogits)
+            plan.begin_backward()
+            plan.run("bhead"); plan.run("b3d"); plan.run("b2d")
+            plan.join_backward()
+            flat = plan.grad_arena.tensor.clone()      # one launch; the arena is reused next step
+            sync = getattr(ctx.module, "_grad_sync", None)
+            if sync is not None:
+                sync(flat)                             # data parallel: RCCL all-reduce of the flat buffer
         grads = []
         for p in plan.params:
             if p.requires_grad:
@@ -74,6 +112,64 @@ class _MDSFunction(torch.autograd.Function):
                 grads.append(None)
         plan.in_flight = False
         return (None, None, None, *grads)
+
+
+class _TailFunction(torch.autograd.Function):
+    """forward_3d -> forward_head as one differentiable call on given 2D features (fine-tuning the temporal
+    tail on cached features; also how the reference-generated `tail_chain` vectors reach the kernels)."""
+
+    @staticmethod
+    def forward(ctx, feats, module, plan, *params):
+        ctx.plan, ctx.token = plan, _Release(plan)
+        plan.in_flight = True
+        plan.generation += 1
+        ctx.generation, ctx.shape = plan.generation, feats.shape
+        b, s, c, h, w = feats.shape
+        with plan.device_guard():
+            plan.feat.tensor.view(b, s, h, w, c).copy_(feats.detach().permute(0, 1, 3, 4, 2))
+            plan.begin_forward(module._mask_override)
+            plan.run("f3d"); plan.run("fhead")
+            return plan.logits.tensor.view(b, -1).clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        plan = ctx.plan
+        if ctx.generation != plan.generation or not plan.in_flight:
+            raise RuntimeError("mds: the activations of this forward have been released")
+        b, s, c, h, w = ctx.shape
+        with plan.device_guard():
+            plan.bind_dlogits(dlogits)
+            plan.begin_backward()
+            plan.run("bhead"); plan.run("b3d")
+            plan.join_backward()
+            flat = plan.grad_arena.tensor.clone()
+            dfeats = plan.dfeat.tensor.view(b, s, h, w, c).permute(0, 1, 4, 2, 3).float().contiguous()
+        grads = [flat[plan.poff[id(p)]:plan.poff[id(p)] + p.numel()].view(p.shape) if p.requires_grad else None
+                 for p in plan.tail_params]
+        plan.in_flight = False
+        return (dfeats, None, None, *grads)
+
+
+def _load_pretrained_encoder(encoder: nn.Module, model_name: str, in_chans: int):
+    """``pretrained=True`` (configs/ball_action/sampling_weights_001.py:36): the reference gets ImageNet
+    weights from ``timm.create_model(..., pretrained=True)`` (multidim_stacker.py:166-176).  Do the same when
+    timm and its weight cache are reachable; otherwise say so LOUDLY — never a silent random init."""
+    try:
+        import timm  # noqa: F401  (absent from the build image; present in the reference's environment)
+        src = timm.create_model(model_name, pretrained=True, in_chans=in_chans, features_only=True, out_indices=[4])
+        sd = src.state_dict()
+        own = encoder.state_dict()
+        if set(sd) != set(own) or any(sd[k].shape != own[k].shape for k in own):
+            raise RuntimeError("timm state_dict does not match the mds encoder layout (timm version != 0.9.2?)")
+        encoder.load_state_dict(sd)
+        return True
+    except Exception as e:  # ImportError, no network / no cached weights, layout mismatch
+        warnings.warn(
+            f"mds.MultiDimStacker(pretrained=True): ImageNet weights for '{model_name}' could not be loaded "
+            f"({type(e).__name__}: {e}). The 2D encoder is RANDOMLY INITIALISED — load a checkpoint "
+            f"(load_state_dict / src.utils.load_weights_from_pretrain) before training stage 1, or install timm with "
+            f"cached weights.", RuntimeWarning, stacklevel=3)
+        return False
 
 
 class MultiDimStacker(nn.Module):
@@ -94,9 +190,8 @@ class MultiDimStacker(nn.Module):
         self.num_stacks = num_frames // stack_size
         self.num_features = num_3d_stack_proj * self.num_stacks
         self.drop_rate = drop_rate
-        # pretrained=True would pull timm/tf_efficientnetv2_b0.in1k from the HF hub; offline the caller
-        # loads weights (scripts/ball_action/train.py:48-62 does exactly that for every later stage).
         self.conv2d_encoder = EncoderP(in_chans=stack_size, drop_path_rate=drop_path_rate)
+        self.pretrained_loaded = _load_pretrained_encoder(self.conv2d_encoder, model_name, stack_size) if pretrained else False
         enc_chs = self.conv2d_encoder.feature_info[index_2d_features]["num_chs"]
         self.conv2d_projection = nn.Sequential(
             nn.Conv2d(enc_chs, num_3d_features, 1, bias=False), nn.BatchNorm2d(num_3d_features, eps=TAIL_BN_EPS))
@@ -119,6 +214,10 @@ class MultiDimStacker(nn.Module):
         self._cache = _PlanCache()            # .to()/.cuda()/.half() move parameters: re-plan
         return super()._apply(fn, *a, **k)
 
+    def clear_plans(self):
+        """Release every cached launch plan (and the activation arenas they pin)."""
+        self._cache = _PlanCache()
+
     def _library(self, x):
         if self._lib is not None:
             return self._lib
@@ -139,16 +238,20 @@ class MultiDimStacker(nn.Module):
         lib = self._library(x)
         enc_grad = any(p.requires_grad for p in self.conv2d_encoder.parameters())
         key = (kind, B, T, H, W, self._code(), self.training, need_grad, enc_grad, x.device)
-        pool = self._cache.plans.setdefault(key, [])
+        cache = self._cache
+        pool = cache.plans.setdefault(key, [])
+        cache.plans.move_to_end(key)
         for plan in pool:
             if not plan.in_flight and not plan.stale():
                 return plan
         pool[:] = [p for p in pool if not p.stale()]
         plan = Plan(self, lib, x.device, kind, B, T, H, W, self._code(), self.training, need_grad, enc_grad)
         pool.append(plan)
+        cache.evict(key)
         return plan
 
     # ------------------------------------------------------------------ reference API
+    @torch.compiler.disable
     def forward(self, x):
         b, t, h, w = x.shape
         assert t == self.num_frames and t % self.stack_size == 0
@@ -157,16 +260,18 @@ class MultiDimStacker(nn.Module):
         plan = self._plan(x, "full", b, t, h, w, need_grad)
         if need_grad:
             return _MDSFunction.apply(x, self, plan, *plan.params)
-        plan.bind_input(x)
-        plan.begin_forward(self._mask_override)
-        plan.run("f2d"); plan.run("f3d"); plan.run("fhead")
-        return plan.logits.tensor.view(b, -1).clone()
+        with plan.device_guard():
+            plan.bind_input(x)
+            plan.begin_forward(self._mask_override)
+            plan.run("f2d"); plan.run("f3d"); plan.run("fhead")
+            return plan.logits.tensor.view(b, -1).clone()
 
     def _inference_only(self, what):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(f"mds: {what} called on its own is an inference path (src/predictors.py:50-72); "
                                       f"wrap it in torch.no_grad() — training goes through forward()")
 
+    @torch.compiler.disable
     def forward_2d(self, x):
         self._inference_only("forward_2d")
         b, t, h, w = x.shape
@@ -174,31 +279,46 @@ class MultiDimStacker(nn.Module):
         s = t // self.stack_size
         x = x.float().contiguous()
         plan = self._plan(x, "2d", b, t, h, w, False)
-        plan.bind_input(x)
-        plan.begin_forward(None)
-        plan.run("f2d")
-        f = plan.feat.tensor.view(b, s, plan.h, plan.w, self.num_3d_features)
-        return f.permute(0, 1, 4, 2, 3).float().contiguous()      # (b, S, 192, h, w) like the reference
+        with plan.device_guard():
+            plan.bind_input(x)
+            plan.begin_forward(None)
+            plan.run("f2d")
+            f = plan.feat.tensor.view(b, s, plan.h, plan.w, self.num_3d_features)
+            return f.permute(0, 1, 4, 2, 3).float().contiguous()      # (b, S, 192, h, w) like the reference
 
+    @torch.compiler.disable
     def forward_3d(self, x):
         self._inference_only("forward_3d")
         b, t, c, h, w = x.shape
         assert c == self.num_3d_features and t == self.num_stacks
         plan = self._plan(x, "3d", b, t * self.stack_size, h, w, False)
-        plan.feat.tensor.view(b, t, h, w, c).copy_(x.permute(0, 1, 3, 4, 2))
-        plan.begin_forward(None)
-        plan.run("f3d")
-        cq = self.num_features // t
-        y = plan.out3d.tensor.view(b, t, h, w, cq)
-        return y.permute(0, 1, 4, 2, 3).reshape(b, self.num_features, h, w).float().contiguous()
+        with plan.device_guard():
+            plan.feat.tensor.view(b, t, h, w, c).copy_(x.permute(0, 1, 3, 4, 2))
+            plan.begin_forward(None)
+            plan.run("f3d")
+            cq = self.num_features // t
+            y = plan.out3d.tensor.view(b, t, h, w, cq)
+            return y.permute(0, 1, 4, 2, 3).reshape(b, self.num_features, h, w).float().contiguous()
 
+    @torch.compiler.disable
+    def forward_tail(self, feats):
+        """logits = forward_head(forward_3d(feats)) for feats of shape (b, num_stacks, 192, h, w), differentiable
+        with respect to the features and the tail parameters (not part of the reference API)."""
+        b, t, c, h, w = feats.shape
+        assert c == self.num_3d_features and t == self.num_stacks
+        plan = self._plan(feats, "tail", b, t * self.stack_size, h, w, True)
+        plan.tail_params = [p for n, p in self.named_parameters() if not n.startswith("conv2d_")]
+        return _TailFunction.apply(feats, self, plan, *plan.tail_params)
+
+    @torch.compiler.disable
     def forward_head(self, x):
         self._inference_only("forward_head")
         b, f, h, w = x.shape
         t = self.num_stacks
         cq = f // t
         plan = self._plan(x, "head", b, t * self.stack_size, h, w, False)
-        plan.yq.tensor.view(b, t, h, w, cq).copy_(x.view(b, t, cq, h, w).permute(0, 1, 3, 4, 2))
-        plan.begin_forward(self._mask_override)
-        plan.run("fhead")
-        return plan.logits.tensor.view(b, -1).clone()
+        with plan.device_guard():
+            plan.yq.tensor.view(b, t, h, w, cq).copy_(x.view(b, t, cq, h, w).permute(0, 1, 3, 4, 2))
+            plan.begin_forward(self._mask_override)
+            plan.run("fhead")
+            return plan.logits.tensor.view(b, -1).clone()

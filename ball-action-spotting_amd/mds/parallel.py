@@ -22,12 +22,13 @@ def shard_windows(num_windows: int, rank: int, world: int):
     return range(start, start + base + (1 if rank < extra else 0))
 
 
-def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
-    """In-place mean all-reduce of the flat gradient buffer (backend nccl == RCCL on ROCm)."""
+def allreduce_mean_(flat: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+    """In-place mean all-reduce of the flat gradient buffer (backend nccl == RCCL on ROCm).
+    `force` issues the collective even in a world of one (single-GPU test of the RCCL call path)."""
     if not dist.is_available() or not dist.is_initialized():
         return flat
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(world)
@@ -43,12 +44,12 @@ def broadcast_state(module: torch.nn.Module, src: int = 0, group=None):
             dist.broadcast(t, src=src, group=group)
 
 
-def data_parallel(module, group=None, broadcast: bool = True):
+def data_parallel(module, group=None, broadcast: bool = True, force_collective: bool = False):
     """Turn on gradient averaging across ranks for an mds.MultiDimStacker (returns the module).
 
     Kept as an attribute hook instead of a wrapper class so that ``argus``' attribute access
     (``nn_module.conv2d_encoder`` in src/argus_models.py:108) keeps working."""
     if broadcast:
         broadcast_state(module, 0, group)
-    module._grad_sync = lambda flat: allreduce_mean_(flat, group)
+    module._grad_sync = lambda flat: allreduce_mean_(flat, group, force_collective)
     return module

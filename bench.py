@@ -1,22 +1,36 @@
 """bench.py — frame-windows/sec (fwd+bwd) of the MultiDimStacker hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 without a torchrun environment: re-executes itself under
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU, RCCL).
 
-Workload (BASELINE.json configs[1], `sampling_weights_001`): per GPU a batch of 4 windows of
-15x736x1280 synthetic frames (uniform [0,1) fp32, seed 1234+rank), module kwargs of
-configs/ball_action/sampling_weights_001.py:30-45 (drop_rate = drop_path_rate = 0.2,
-pretrained=False, random init under seed 0), bf16 autocast, focal loss (alpha -1, gamma 1.2),
-backward, gradient all-reduce (N>1, RCCL) and a fused AdamW step.  A step is one pass of the hot
-path over one batch; inputs are resident in HBM before the timed region.
+Workloads (--config):
+  train    BASELINE.json configs[1] (`sampling_weights_001`): per GPU a batch of 4 windows of 15x736x1280 synthetic
+           frames (uniform [0,1) fp32, seed 1234+rank), module kwargs of configs/ball_action/sampling_weights_001.py:30-45
+           (drop_rate = drop_path_rate = 0.2, pretrained=False, random init under seed 0), bf16 autocast, focal loss
+           (alpha -1, gamma 1.2), backward, gradient all-reduce (N>1, RCCL), AdamW step.  THE headline metric.
+  long004  BASELINE.json configs[3] (`ball_finetune_long_004.py:8,67`): 4 x 33 x 736 x 1280 per GPU, 2D encoder frozen
+           (forward only, BatchNorm in train mode), temporal tail forward+backward.
+  predict  BASELINE.json configs[4] (src/predictors.py:50-75): sliding-window inference, one new 736x1280 frame per
+           step (uint8 720x1280 ingest -> pad -> /255), frames/s, with and without horizontal-flip TTA.
+A step is one pass of the hot path over one batch; inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     : dominant kernel, algorithmic bytes (or flops) per launch / measured launch time
+  roofline     : the dominant HIP kernel (largest share of the per-kernel pass, fwd and bwd uses of one kernel folded
+                 together), algorithmic bytes (or flops) per launch / HIP-event launch time, PMC traffic measured by a
+                 rocprofv3 child run of this very script, and the whole-path fraction of SURVEY.md §8(d)
   cpu_baseline : the oracle (kind "port") timed on this box's host cores, bounded sample.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,13 +38,10 @@ for p in (ROOT, os.path.join(ROOT, "ball-action-spotting_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0    # bf16 dense
-FLOP_PER_WINDOW = 424.9e9    # fwd 141.6 GFLOP x 3
-BYTES_PER_WINDOW_BLOCK = 1.498e9   # block-granular compulsory bytes, fwd+bwd
+# SURVEY.md §8(d) / BASELINE.md §2: algorithmic work per window (block-granular compulsory bytes)
+WORK = {"train": dict(flop=424.9e9, bytes=1.498e9), "long004": dict(flop=353.4e9, bytes=1.204e9)}
 
 CONFIG = dict(model_name="tf_efficientnetv2_b0.in1k", num_classes=2, num_frames=15, stack_size=3,
               index_2d_features=4, pretrained=False, num_3d_blocks=4, num_3d_features=192,
@@ -40,6 +51,7 @@ CONFIG = dict(model_name="tf_efficientnetv2_b0.in1k", num_classes=2, num_frames=
 
 def focal_loss(logits, target, gamma=1.2):
     """sigmoid focal loss, alpha=-1, mean (reference src/losses.py:34-50) in fp32."""
+    import torch
     x = logits.float()
     p = torch.sigmoid(x)
     ce = torch.nn.functional.binary_cross_entropy_with_logits(x, target, reduction="none")
@@ -51,7 +63,9 @@ def cpu_baseline(max_seconds=20.0):
     """The oracle (CPU restatement pinned to the reference) on the host cores, fp32 eager fwd+bwd of ONE
     full 15x736x1280 window, repeated until ~20 s of CPU work are spent (best pass reported).  If a single
     full-size pass exceeds the budget the sample falls back to a quarter of the pixels (15x368x640, same
-    network and frame count) and the rate is scaled by 1/4 — the `sample` string says which was used."""
+    network and frame count) and the rate is scaled by 1/4 — the `sample` string says which was used.
+    A bf16-autocast pass of the quarter-size sample is timed beside it (SURVEY §8d asks for both)."""
+    import torch
     from oracle import multidim_stacker_ref as orc
     cores = os.cpu_count() or 1
     threads = min(cores, 32)       # eager convolutions stop scaling (and oversubscribe) well before 256 threads
@@ -61,15 +75,17 @@ def cpu_baseline(max_seconds=20.0):
     m = orc.MultiDimStacker(**kw).train()
     tgt = torch.tensor([[1.0, 0.0]])
 
-    def run(h, w, budget):
+    def run(h, w, budget, amp=False, max_n=12):
         x = torch.rand(1, 15, h, w, generator=torch.Generator().manual_seed(1234))
         times, t_start = [], time.time()
         while True:
             t0 = time.time()
             m.zero_grad(set_to_none=True)
-            orc.sigmoid_focal_loss(m(x), tgt, alpha=-1.0, gamma=1.2).backward()
+            with torch.autocast("cpu", dtype=torch.bfloat16, enabled=amp):
+                out = m(x)
+            orc.sigmoid_focal_loss(out.float(), tgt, alpha=-1.0, gamma=1.2).backward()
             times.append(time.time() - t0)
-            if time.time() - t_start > budget or len(times) >= 12:
+            if time.time() - t_start > budget or len(times) >= max_n:
                 return times
 
     frac, shape = 1, "15x736x1280"
@@ -80,38 +96,105 @@ def cpu_baseline(max_seconds=20.0):
     timed = times[1:] if len(times) > 1 else times          # the first pass warms the allocator up
     sec = min(timed)
     scaled = "" if frac == 1 else f", scaled x1/{frac} to 15x736x1280 windows"
-    return {"value": round(1.0 / (sec * frac), 5), "unit": "frame-windows/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32 eager fwd+bwd of 1 window of {shape} (batch 1), best of {len(timed)} timed passes "
-                      f"({sum(times):.1f} s of CPU work in total){scaled}; host has {cores} logical cores, {threads} threads used",
-            "sec_per_sample": round(sec, 3)}
+    out = {"value": round(1.0 / (sec * frac), 5), "unit": "frame-windows/s", "cores": threads, "kind": "port",
+           "host_logical_cores": cores,
+           "sample": f"oracle fp32 eager fwd+bwd of 1 window of {shape} (batch 1), best of {len(timed)} timed passes "
+                     f"({sum(times):.1f} s of CPU work in total){scaled}; {threads} threads of {cores} logical cores used",
+           "sec_per_sample": round(sec, 3)}
+    try:
+        tb = run(368, 640, 6.0, amp=True, max_n=3)
+        out["bf16_autocast"] = {"value": round(1.0 / (min(tb) * 4), 5), "unit": "frame-windows/s",
+                                "sample": f"same oracle under torch.autocast('cpu', bfloat16), 15x368x640 sample scaled x1/4, "
+                                          f"best of {len(tb)} passes ({sum(tb):.1f} s)"}
+    except Exception as e:  # CPU bf16 convolutions may be unsupported on an old host
+        out["bf16_autocast"] = {"error": str(e)[:120]}
+    return out
 
 
-def pmc_traffic(kernel_key, dtype):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    very command, KiB units, FETCH_SIZE x2 on gfx950 — MI355X_MICROARCH.md §HBM).  PMC collection
-    cannot run inside the timed process, so the newest committed summary is reported; None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
-    if not files or dtype != "bf16":
+# ----------------------------------------------------------------------------------------------- PMC child runs
+def kernel_family(name):
+    """'void dw2_bwd_kernel<unsigned short, 4>(...)' -> 'dw_bwd' ; variants of one entry point share a key"""
+    fn = name.replace("void ", "").split("<")[0].split("(")[0]
+    fn = re.sub(r"\d", "", fn)
+    for v in ("_tr_kernel", "_p_kernel", "_tiled_kernel", "_kernel"):
+        if fn.endswith(v):
+            fn = fn[: -len(v)]
+            break
+    return fn.replace("dws_", "dw_")
+
+
+def pmc_child(counters, extra_args, timeout=240):
+    """Run this script under `rocprofv3 --pmc <counters>` (counter collection only — never combined with trace
+    domains) for 2 steps and return {kernel family: {counter: mean per launch, 'launches': n, 'us': mean duration}}."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
         return None
-    import re
-    ks = json.load(open(files[-1]))["kernels"]
-    want = kernel_key.split(".")[0] + "_kernel"
+    tmp = tempfile.mkdtemp(prefix="mds_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", *counters, "-d", tmp, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
+           os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--profile-steps", "0", "--no-cpu-baseline", "--no-pmc",
+           *extra_args]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None
+        agg, seen = {}, set()
+        for r in csv.DictReader(open(files[0])):
+            fam = kernel_family(r["Kernel_Name"])
+            e = agg.setdefault(fam, {"launches": set(), "dur": 0.0})
+            e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            d = r["Dispatch_Id"]
+            if d not in seen:
+                seen.add(d)
+                e["launches"].add(d)
+                e["dur"] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-3
+        out = {}
+        for fam, e in agg.items():
+            n = max(len(e["launches"]), 1)
+            out[fam] = {k: v / n for k, v in e.items() if k not in ("launches", "dur")}
+            out[fam]["launches"] = n
+            out[fam]["us"] = e["dur"] / n
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
-    def family(name):   # "void dw2_bwd_kernel<unsigned short, 4>(...)" -> "dw_bwd_kernel" (variants share a key)
-        fn = name.replace("void ", "").split("<")[0].split("(")[0]
-        fn = re.sub(r"\d", "", fn)
-        for v in ("_tr_kernel", "_p_kernel", "_tiled_kernel"):
-            fn = fn.replace(v, "_kernel")
-        return fn
 
-    tot = calls = 0.0
-    for name, v in ks.items():
-        if family(name) == want and ("unsigned short" in name or "<" not in name or "_tr_" in name or "_tiled" in name):
-            tot += v["hbm_bytes_per_launch"] * v["calls"]
-            calls += v["calls"]
-    return int(tot / calls) if calls else None
+def pmc_for(dom, extra_args):
+    """HBM traffic per launch of kernel family `dom` (FETCH_SIZE and WRITE_SIZE in separate passes, KiB units,
+    FETCH_SIZE x2 on gfx950 — MI355X_MICROARCH.md §HBM) and its MFMA-busy / wave-cycle split."""
+    res = {"traffic": None}
+    f = pmc_child(["FETCH_SIZE"], extra_args)
+    w = pmc_child(["WRITE_SIZE"], extra_args)
+    if f and w and dom in f and dom in w:
+        res["traffic"] = int(f[dom]["FETCH_SIZE"] * 1024 * 2 + w[dom]["WRITE_SIZE"] * 1024)
+        nsteps = 3.0      # the child runs 1 warm-up + 2 timed steps
+        res["step_traffic_GB"] = round((sum(f[k]["FETCH_SIZE"] * 2048 * f[k]["launches"] for k in f) +
+                                        sum(w[k]["WRITE_SIZE"] * 1024 * w[k]["launches"] for k in w)) / nsteps / 1e9, 2)
+    s = pmc_child(["SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"], extra_args)
+    if s and dom in s and s[dom].get("SQ_WAVE_CYCLES"):
+        e = s[dom]
+        res["sq"] = {"mfma_busy_frac_at_2.4GHz": round(e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * e["us"] * 1e-6 * 2.4e9), 4),
+                     "wave_parked": round(e.get("SQ_WAIT_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 3),
+                     "issue_stall": round(e.get("SQ_WAIT_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 3),
+                     "issuing": round(e.get("SQ_ACTIVE_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 3),
+                     "profiled_us": round(e["us"], 2)}
+    return res
+
+
+# ----------------------------------------------------------------------------------------------- main
+def respawn(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: launch one rank per GPU ourselves."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -119,18 +202,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="train", choices=["train", "long004", "predict"])
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--height", type=int, default=736)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child runs that measure roofline.traffic")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(args)
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -138,15 +228,27 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.config == "predict":
+        from tools import predict_bench
+        return predict_bench.bench_line(args, dev, rank, world)
+
     import mds
     from mds import parallel
     torch.manual_seed(0)
-    model = mds.MultiDimStacker(**CONFIG).to(dev).train()
+    cfg = dict(CONFIG)
+    T = 15
+    if args.config == "long004":
+        T = 33
+        cfg.update(num_frames=33)
+    model = mds.MultiDimStacker(**cfg).to(dev).train()
+    if args.config == "long004":      # src/argus_models.py:104-110: freeze flips requires_grad only; BN stays in train mode
+        for p in model.conv2d_encoder.parameters():
+            p.requires_grad_(False)
     if world > 1:
         parallel.data_parallel(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=3e-4, fused=True)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-4, fused=True)
     B = args.batch
-    x = torch.rand(B, 15, args.height, args.width, device=dev, generator=torch.Generator(dev).manual_seed(1234 + rank))
+    x = torch.rand(B, T, args.height, args.width, device=dev, generator=torch.Generator(dev).manual_seed(1234 + rank))
     target = torch.randint(0, 2, (B, 2), device=dev, generator=torch.Generator(dev).manual_seed(4321)).float()
     use_amp = args.dtype == "bf16"
 
@@ -179,8 +281,11 @@ def main():
     wps = B * world * args.steps / elapsed
     assert torch.isfinite(loss).item(), "non-finite loss"
 
-    # ---- per-kernel pass: HIP event pairs around every launch (on the launch stream)
+    # ---- per-kernel pass: HIP event pairs around every launch (on the launch stream).  Keyed by HIP kernel:
+    #      the data-gradient launches of pw_fwd / conv_fwd are the same kernels as the forward ones.
     roofline, breakdown, top_launches = None, None, None
+    full = (args.height, args.width) == (736, 1280)
+    work = WORK[args.config] if full else None
     if rank == 0 and args.profile_steps > 0:
         plan = next(p for pool in model._cache.plans.values() for p in pool if p.kind == "full" and p.need_grad)
         plan.profile = []
@@ -189,8 +294,7 @@ def main():
         torch.cuda.synchronize()
         agg = {}
         for name, seg, e0, e1, (nbytes, flops) in plan.profile:
-            key = name + (".bwd" if seg.startswith("b") and name in ("pw_fwd", "conv_fwd") else "")
-            a = agg.setdefault(key, [0.0, 0, 0.0, 0.0])
+            a = agg.setdefault(name, [0.0, 0, 0.0, 0.0])
             a[0] += e0.elapsed_time(e1); a[1] += 1; a[2] += nbytes; a[3] += flops
         top = sorted(plan.profile, key=lambda r: -r[2].elapsed_time(r[3]))[:30]
         top_launches = [{"kernel": r[0], "seg": r[1], "us": round(r[2].elapsed_time(r[3]) * 1e3, 1),
@@ -206,31 +310,41 @@ def main():
         avg_ms, avg_bytes, avg_flops = a[0] / a[1], a[2] / a[1], a[3] / a[1]
         gbs, tfl = avg_bytes / avg_ms / 1e6, avg_flops / avg_ms / 1e9
         hbm_bound = (avg_bytes / (HBM_PEAK_GBS * 1e9)) >= (avg_flops / (MFMA_PEAK_TFLOPS * 1e12))
-        traffic = pmc_traffic(dom, args.dtype)
         roofline = {"kernel": dom, "bound": "hbm" if hbm_bound else "mfma",
                     "achieved": round(gbs if hbm_bound else tfl, 2), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS,
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfl / MFMA_PEAK_TFLOPS), 4), "traffic": traffic,
+                    "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfl / MFMA_PEAK_TFLOPS), 4), "traffic": None,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": a[1] // args.profile_steps,
                     "alg_bytes_per_launch": int(avg_bytes), "alg_flops_per_launch": int(avg_flops),
-                    "share_of_kernel_time": round(a[0] / tot, 3),
-                    "whole_path": {"mfma_frac": round(FLOP_PER_WINDOW * wps / world / (MFMA_PEAK_TFLOPS * 1e12), 4),
-                                   "hbm_alg_frac_block_granular": round(BYTES_PER_WINDOW_BLOCK * wps / world / (HBM_PEAK_GBS * 1e9), 4)}}
+                    "kernel_TFLOPs": round(tfl, 1), "kernel_mfma_frac": round(tfl / MFMA_PEAK_TFLOPS, 4),
+                    "share_of_kernel_time": round(a[0] / tot, 3)}
+        if work:
+            t_window = elapsed / args.steps / B
+            roofline["frac_whole_path"] = round(max(work["flop"] / (MFMA_PEAK_TFLOPS * 1e12), work["bytes"] / (HBM_PEAK_GBS * 1e9)) / t_window, 4)
+            roofline["whole_path"] = {"mfma_frac": round(work["flop"] * wps / world / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                                      "hbm_alg_frac_block_granular": round(work["bytes"] * wps / world / (HBM_PEAK_GBS * 1e9), 4),
+                                      "definition": "SURVEY.md 8(d): max(F/2.5e15, B/8e12) / t_window"}
+        if world == 1 and not args.no_pmc:
+            extra = ["--config", args.config, "--batch", str(B), "--height", str(args.height), "--width", str(args.width),
+                     "--dtype", args.dtype]
+            roofline.update(pmc_for(dom, extra))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
     if rank == 0:
-        out = {"metric": "frame-windows/sec (fwd+bwd) at 15x736x1280, batch 4", "value": round(wps, 3),
+        what = {"train": "fwd + focal loss + bwd + grad all-reduce + AdamW",
+                "long004": "frozen 2D encoder fwd (BN in train mode) + tail fwd/bwd + focal loss + grad all-reduce + AdamW"}[args.config]
+        name = {"train": "sampling_weights_001", "long004": "ball_finetune_long_004"}[args.config]
+        out = {"metric": f"frame-windows/sec (fwd+bwd) at {T}x{args.height}x{args.width}, batch {B}", "value": round(wps, 3),
                "unit": "frame-windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"sampling_weights_001: {B}x15x{args.height}x{args.width} windows/GPU, "
-                                      "fwd + focal loss + bwd + grad all-reduce + AdamW",
+               "config": {"workload": f"{name}: {B}x{T}x{args.height}x{args.width} windows/GPU, {what}",
                           "global_batch": B * world, "parallelism": f"dp{world}", "drop_rate": 0.2, "drop_path_rate": 0.2},
                "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
-               "top_launches": top_launches if rank == 0 and args.profile_steps > 0 else None,
+               "top_launches": top_launches if args.profile_steps > 0 else None,
                "loss": round(float(loss.detach()), 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
         print(json.dumps(out))
     if world > 1:

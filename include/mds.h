@@ -10,7 +10,8 @@
  *  - Plain C: pointers + sizes only.  Every buffer is caller-owned device memory (PyTorch
  *    allocations); the library never allocates, frees or retains pointers.
  *  - Every call is asynchronous on the caller's HIP stream (`stream` = hipStream_t as void*),
- *    never synchronises, has no global mutable state except a thread-local error string.
+ *    never synchronises.  Process state: a thread-local error string, and (set once, idempotently) the
+ *    per-kernel opt-in to more than 64 KiB of LDS; both are safe under concurrent callers.
  *  - Return 0 on success, negative MDS_ERR_* otherwise; mds_last_error() describes it.
  *  - Activations are channels-last "rows": a tensor [rows][C] with C contiguous, rows =
  *    N*H*W (2D) or B*T*H*W (3D).  dtype selects the storage type of activations and packed
@@ -24,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 100
+#define MDS_VERSION 101
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -342,6 +343,8 @@ typedef struct {
   float* dgamma;    /* optional (NULL when the parameter is frozen) */
   float* dbeta;
   float* coef;      /* [3][C] */
+  int batch_stats;  /* 1: train-mode BN (batch statistics; the mean / xhat terms above).  0: eval-mode BN
+                       (running statistics are constants): coef1 = coef2 = 0, i.e. dy = gamma*rstd*g        */
 } mds_bn_bwd_finalize_args;
 int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream_t stream);
 

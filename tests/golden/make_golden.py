@@ -102,6 +102,37 @@ def main():
     d["y_eval"] = npy(blk(x2))
     out["ir3d"] = d
 
+    # ---- the same reference classes at channel counts the MFMA kernels accept (multiples of 16), so that the
+    #      vectors can be fed to the HIP path itself (tests/test_golden_hip.py), not only to the oracle ----
+    gem = ref.GeneralizedMeanPooling(3.0)
+    x = (torch.randn(3, 16, 5, 7, generator=gen(21)) * 1.5).requires_grad_(True)     # negatives -> clamp path
+    g = torch.randn(3, 16, generator=gen(22))
+    y = gem(x)
+    (y * g).sum().backward()
+    out["gem_c16"] = dict(x=npy(x), g=npy(g), y=npy(y), dx=npy(x.grad), dp=npy(gem.p.grad))
+    for tag, T_, H_, W_ in (("ir3d_c16_t5", 5, 5, 7), ("ir3d_c16_t3", 3, 6, 5)):
+        blk = fill_deterministic(
+            ref.InvertedResidual3d(16, 16, expansion_ratio=3, se_reduce_ratio=4,
+                                   act_layer=torch.nn.SiLU, drop_path_rate=0.0), 26)
+        blk.train()
+        x1 = torch.randn(2, 16, T_, H_, W_, generator=gen(27)).requires_grad_(True)
+        g1 = torch.randn(2, 16, T_, H_, W_, generator=gen(28))
+        y1 = blk(x1)
+        (y1 * g1).sum().backward()
+        d = dict(x1=npy(x1), g1=npy(g1), y1=npy(y1), dx1=npy(x1.grad))
+        for n, p in blk.named_parameters():
+            d["grad1." + n] = npy(p.grad)
+        for n, b in blk.named_buffers():
+            d["buf1." + n] = npy(b.float())
+        x2 = torch.randn(2, 16, T_, H_, W_, generator=gen(29))
+        y2 = blk(x2)
+        d.update(x2=npy(x2), y2=npy(y2))
+        for n, b in blk.named_buffers():
+            d["buf2." + n] = npy(b.float())
+        blk.eval()
+        d["y_eval"] = npy(blk(x2))
+        out[tag] = d
+
     # ---- forward_2d grouping with the fake encoder (eval mode) ----
     kw = dict(orc.BASIC_CONFIG_KWARGS, model_name="fake_grouping", drop_rate=0.0, drop_path_rate=0.0)
     m = fill_deterministic(ref.MultiDimStacker(**kw), 10).eval()

@@ -1,5 +1,12 @@
-"""Full-size (BASELINE config 2: 4 x 15 x 736 x 1280, bf16) checks through size-independent properties —
-the oracle needs minutes per window at this size, so the HIP path is checked against itself:
+"""Full-size checks (BASELINE configs 2 and 4).
+
+Against the oracle, one full window (the oracle's fp32 fwd+bwd of 1 x 15 x 736 x 1280 takes ~3 s on the GPU
+box's host, see bench.py cpu_baseline):
+  * fp32 HIP vs oracle at 1 x 15 x 736 x 1280: logits, EVERY parameter gradient, BN buffers within 1e-3;
+  * config 4 (ball_finetune_long_004): 1 x 33 x 736 x 1280, encoder frozen (fwd only, BN in train mode), tail
+    fwd+bwd, fp32, same bar;
+  * bf16 HIP vs the fp32 oracle on the same window: logits and the direction/size of the gradient.
+And at the full batch of 4 (bf16), through size-independent properties of the HIP path:
 
   * window-permutation equivariance: BatchNorm statistics are permutation invariant, so permuting the
     windows of the batch permutes the logits and leaves every parameter gradient unchanged;
@@ -106,3 +113,79 @@ def test_window_permutation_equivariance_fp32_tight():
     floor = 1e-2 * float(np.median([g.abs().max().item() for g in g1.values()]))
     worst = max((p.grad - g1[n]).abs().max().item() / max(g1[n].abs().max().item(), floor) for n, p in m.named_parameters())
     assert worst < 5e-3, worst
+
+
+def _full_window_pair(kw, frames, seed):
+    from det_init import fill_deterministic
+    ref = fill_deterministic(orc.MultiDimStacker(**kw), seed, scale=0.05)
+    prod = mds.MultiDimStacker(**kw)
+    prod.load_state_dict(ref.state_dict())
+    x = torch.rand(1, frames, 736, 1280, generator=torch.Generator().manual_seed(seed + 100))
+    return ref, prod.to(DEV), x
+
+
+def _oracle_step(ref, x, tgt):
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref.zero_grad(set_to_none=True)
+    logits = ref(x)
+    orc.sigmoid_focal_loss(logits, tgt, alpha=-1.0, gamma=1.2).backward()
+    return logits.detach(), {n: p.grad.detach() for n, p in ref.named_parameters() if p.grad is not None}
+
+
+def _rel(got, want, floor=0.0):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    return (got - want).abs().max().item() / max(want.abs().max().item(), floor, 1e-20)
+
+
+def test_fp32_full_window_vs_oracle_config2():
+    """BASELINE configs[1] shape, one window, fp32: HIP path vs the oracle — logits, all 6.77 M gradient values, buffers."""
+    import numpy as np
+    ref, prod, x = _full_window_pair(KW, 15, 11)
+    ref.train(); prod.train()
+    tgt = torch.tensor([[1.0, 0.0]])
+    lr, gr = _oracle_step(ref, x, tgt)
+    prod.zero_grad(set_to_none=True)
+    lp = prod(x.to(DEV))
+    orc.sigmoid_focal_loss(lp, tgt.to(DEV), alpha=-1.0, gamma=1.2).backward()
+    assert _rel(lp, lr) < 1e-3
+    gp = {n: p.grad for n, p in prod.named_parameters()}
+    floor = 1e-2 * float(np.median([g.abs().max().item() for g in gr.values()]))
+    errs = sorted(((_rel(gp[n], gr[n], floor), n) for n in gr), reverse=True)
+    assert errs[0][0] < 1e-3, errs[:6]
+    for (n, b), (_, b2) in zip(ref.named_buffers(), prod.named_buffers()):
+        assert _rel(b2, b, 1e-6) < 1e-3, n
+    # bf16 kernels on the same window against the fp32 oracle: bf16 rounding through 25 blocks is ~1e-2 on the logits;
+    # the gradient must keep its direction and size (a wrong layer in the 6.8 M-vector shows up here, cosine ~0.9 or less)
+    prod.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lb = prod(x.to(DEV))
+    orc.sigmoid_focal_loss(lb.float(), tgt.to(DEV), alpha=-1.0, gamma=1.2).backward()
+    assert _rel(lb, lr) < 5e-2
+    a = torch.cat([p.grad.flatten().cpu() for _, p in prod.named_parameters()])
+    b = torch.cat([gr[n].flatten() for n, _ in prod.named_parameters()])
+    cos = torch.dot(a, b).item() / (a.norm().item() * b.norm().item())
+    assert cos > 0.995 and abs(a.norm().item() / b.norm().item() - 1) < 5e-2, (cos, a.norm().item(), b.norm().item())
+
+
+def test_fp32_full_window_vs_oracle_config4_frozen_encoder():
+    """BASELINE configs[3] (ball_finetune_long_004.py:8,67): num_frames 33, 2D encoder frozen but in train mode."""
+    import numpy as np
+    kw = dict(KW, num_frames=33)
+    ref, prod, x = _full_window_pair(kw, 33, 12)
+    for m_ in (ref, prod):
+        for p in m_.conv2d_encoder.parameters():
+            p.requires_grad_(False)
+        m_.train()
+    tgt = torch.tensor([[0.0, 1.0]])
+    lr, gr = _oracle_step(ref, x, tgt)
+    prod.zero_grad(set_to_none=True)
+    lp = prod(x.to(DEV))
+    orc.sigmoid_focal_loss(lp, tgt.to(DEV), alpha=-1.0, gamma=1.2).backward()
+    assert _rel(lp, lr) < 1e-3
+    gp = {n: p.grad for n, p in prod.named_parameters() if p.grad is not None}
+    assert set(gp) == set(gr) and not any(n.startswith("conv2d_encoder") for n in gp)
+    floor = 1e-2 * float(np.median([g.abs().max().item() for g in gr.values()]))
+    errs = sorted(((_rel(gp[n], gr[n], floor), n) for n in gr), reverse=True)
+    assert errs[0][0] < 1e-3, errs[:6]
+    for (n, b), (_, b2) in zip(ref.named_buffers(), prod.named_buffers()):
+        assert _rel(b2, b, 1e-6) < 1e-3, n          # frozen encoder still updates its running statistics

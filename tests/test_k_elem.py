@@ -172,7 +172,7 @@ def test_bn_backward_chain(be, dt, mode, C):
     dgamma = torch.zeros(C, device=be.device); dbeta = torch.zeros(C, device=be.device)
     coef = torch.empty(3, C, device=be.device)
     be.call("bn_bwd_finalize", cabi.make("mds_bn_bwd_finalize_args", C=C, count=M, stats=st2, gamma=be.t(gamma),
-                                         bn=bn, dgamma=dgamma, dbeta=dbeta, coef=coef))
+                                         bn=bn, dgamma=dgamma, dbeta=dbeta, coef=coef, batch_stats=1))
     dy = torch.empty(M, C, dtype=tdt, device=be.device)
     be.call("bn_bwd_apply", cabi.make("mds_bn_bwd_apply_args", dtype=code, M=M, C=C, g=gs, y=yd, bn=bn, coef=coef, dy=dy))
     be.sync()

@@ -83,3 +83,104 @@ def test_full_model_train_step_fp32_vs_oracle():
     ref.eval(); prod.eval()
     with torch.no_grad():
         _cmp("eval logits", prod(x), ref(x), 1e-4, 1e-4)
+
+
+def _step(model, x, tgt):
+    model.zero_grad(set_to_none=True)
+    logits = model(x)
+    orc.sigmoid_focal_loss(logits, tgt, alpha=-1.0, gamma=1.2).backward()
+    return logits.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def test_torch_compile_wrap_is_one_opaque_call():
+    """scripts/ball_action/train.py:83-86 wraps nn_module in torch.compile: the hot path must stay ONE opaque
+    call (no tracing into the planner, no recompiles) and give the eager result, forward and backward."""
+    import warnings
+    import torch._dynamo as dynamo
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    _, prod = _pair(kw)
+    prod.train()
+    x = torch.rand(1, 15, 32, 64, generator=torch.Generator().manual_seed(2))
+    tgt = torch.tensor([[0.0, 1.0]])
+    state = copy.deepcopy(prod.state_dict())
+    le, ge = _step(prod, x, tgt)
+    prod.load_state_dict(state)
+    dynamo.reset()
+    cm = torch.compile(prod, backend="inductor")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lc, gc = _step(cm, x, tgt)
+        prod.load_state_dict(state)
+        lc2, gc2 = _step(cm, x, tgt)            # second call: same plan, no recompilation
+    msgs = [str(w.message) for w in rec]
+    assert not [m for m in msgs if "recompile" in m.lower() or "ctypes" in m.lower()], msgs
+    assert torch.equal(lc, le) and torch.equal(lc2, le)
+    for n in ge:
+        key = n if n in gc else "_orig_mod." + n
+        assert torch.equal(gc[key], ge[n]), n
+    # the eval/no-grad path and the predictor-style sub-forwards through the compiled wrapper
+    cm.eval()
+    with torch.no_grad():
+        y = cm(x)
+        f = cm.forward_2d(x[:, :3])
+    assert y.shape == (1, 2) and f.shape[:3] == (1, 1, 192)
+
+
+def test_eval_mode_backward_uses_running_statistics():
+    """forward() in eval() with grad enabled (fine-tuning a frozen-BN model): BatchNorm is an affine map with
+    constant running statistics, so dy = gamma*rstd*g (no batch-mean terms) — checked against the oracle."""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    ref, prod = _pair(kw)
+    x = torch.rand(1, 15, 48, 40, generator=torch.Generator().manual_seed(3))
+    tgt = torch.tensor([[1.0, 0.0]])
+    for bn in ref.modules():                    # realistic running statistics (see the train-step test)
+        if isinstance(bn, torch.nn.modules.batchnorm._BatchNorm):
+            bn.momentum = 1.0
+    ref.train()
+    with torch.no_grad():
+        ref(x)
+    prod.load_state_dict(ref.state_dict())
+    ref.eval(); prod.eval()
+    lr, gr = _step(ref, x, tgt)
+    lp, gp = _step(prod, x, tgt)
+    _cmp("eval logits", lp, lr, 1e-4, 1e-4)
+    floor = 1e-2 * float(np.median([g.abs().max().item() for g in gr.values()]))
+    worst = sorted(((gp[n] - gr[n]).abs().max().item() / max(gr[n].abs().max().item(), floor), n) for n in gr)[::-1]
+    assert worst[0][0] < 2e-3, worst[:6]
+    for (n, b), (_, b2) in zip(ref.named_buffers(), prod.named_buffers()):
+        assert torch.equal(b.float(), b2.float()), n      # eval: running statistics untouched
+
+
+def test_second_backward_and_inplace_input_edit_raise():
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    _, prod = _pair(kw)
+    prod.train()
+    x = torch.rand(1, 15, 32, 32, generator=torch.Generator().manual_seed(4))
+    loss = prod(x).sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="released"):
+        loss.backward()
+    x2 = x.clone()
+    loss = prod(x2).sum()
+    x2.add_(1.0)                                  # the stem weight gradient reads x again in backward
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+
+
+def test_pretrained_true_is_never_a_silent_random_init():
+    with pytest.warns(RuntimeWarning, match="RANDOMLY INITIALISED"):
+        m = mds.MultiDimStacker(**dict(orc.BASIC_CONFIG_KWARGS, pretrained=True))
+    assert m.pretrained_loaded is False
+
+
+def test_plan_cache_is_bounded():
+    from mds import module as mod
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    _, prod = _pair(kw)
+    prod.eval()
+    with torch.no_grad():
+        for w in range(mod.MAX_PLANS + 3):
+            prod.forward_head(torch.rand(1, 1280, 1, 1 + w))
+    assert prod._cache.count() <= mod.MAX_PLANS
+    prod.clear_plans()
+    assert prod._cache.count() == 0

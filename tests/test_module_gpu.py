@@ -178,3 +178,67 @@ def test_frozen_encoder_long_window():
     assert set(gp) == set(gr)
     assert grad_errors(gp, gr)[0][0] < 1e-3
     assert relerr(prod.conv2d_encoder.bn1.running_mean, ref.conv2d_encoder.bn1.running_mean, 1e-6) < 1e-3
+
+
+def test_rccl_world1_gradient_allreduce_path():
+    """The data-parallel code path over RCCL itself (backend 'nccl'), in a world of one: process-group init on the
+    GPU, state broadcast, and the flat-gradient all-reduce issued for real (the world==1 shortcut bypassed)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from mds import parallel
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+        ref, prod = build_pair(kw)
+        ref.train(); prod.train()
+        parallel.data_parallel(prod, force_collective=True)
+        calls = []
+        sync = prod._grad_sync
+        prod._grad_sync = lambda flat: (calls.append(flat.numel()), sync(flat))[1]
+        x = torch.rand(1, 15, 96, 128, generator=torch.Generator().manual_seed(8))
+        tgt = torch.tensor([[1.0, 0.0]])
+        lr, gr = step(ref, x, tgt)
+        lp, gp = step(prod, x.to(DEV), tgt.to(DEV))
+        torch.cuda.synchronize()
+        assert calls == [6_770_547]                      # ONE collective over the whole flat gradient arena
+        assert relerr(lp, lr) < 1e-3
+        assert grad_errors(gp, gr)[0][0] < 1e-3          # mean over a world of one == the local gradient
+        t = torch.ones(4, device=DEV)
+        dist.all_reduce(t)
+        assert t.sum().item() == 4.0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fp16_autocast_with_gradscaler():
+    """The reference's actual AMP recipe (src/argus_models.py:36,54,58): fp16 autocast + GradScaler.  fp16 autocast
+    maps to bf16 storage in the kernels (fp32 range: the 65536 loss scale cannot overflow); after unscaling the
+    gradients must be finite, the scaler must not skip the step, and they must match the un-scaled bf16 run."""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    ref, prod = build_pair(kw, scale=0.03)
+    prod.train()
+    x = torch.rand(2, 15, 96, 128, generator=torch.Generator().manual_seed(9)).to(DEV)
+    tgt = torch.tensor([[1.0, 0.0], [0.0, 1.0]], device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        _, g_plain = step(prod, x, tgt)
+    prod.load_state_dict(ref.state_dict())
+    opt = torch.optim.SGD(prod.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+    opt.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        logits = prod(x)
+    assert logits.dtype == torch.float32
+    loss = orc.sigmoid_focal_loss(logits, tgt, alpha=-1.0, gamma=1.2)
+    scaler.scale(loss).backward()
+    scaler.unscale_(opt)
+    grads = {n: p.grad.detach().clone() for n, p in prod.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    w0 = prod.classifier.weight.detach().clone()
+    scaler.step(opt); scaler.update()
+    assert scaler.get_scale() == 65536.0 and not torch.equal(w0, prod.classifier.weight)      # step taken, scale kept
+    floor = 1e-2 * float(np.median([g.abs().max().item() for g in g_plain.values()]))
+    worst = max(relerr(grads[n], g_plain[n], floor) for n in g_plain)
+    assert worst < 2e-2, worst      # same kernels, same bf16 storage: only the x65536 scaling of the fp32 accumulators differs
