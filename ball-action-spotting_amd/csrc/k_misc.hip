@@ -146,9 +146,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mds_bn_bwd_finaliz
   const int c = blockIdx.x * FIN_CH + cl;
   const bool owner = sg == 0 && c < a.C;
   // everything the channel's owner needs is requested up front: ONE memory round trip per launch
-  float gam = 0.f, rstd = 0.f, dg = 0.f, db = 0.f;
+  float gam = 0.f, rstd = 0.f, mean = 0.f, dg = 0.f, db = 0.f;
   if (owner) {
-    gam = a.gamma[c]; rstd = a.bn[3 * a.C + c];
+    gam = a.gamma[c]; rstd = a.bn[3 * a.C + c]; mean = a.bn[2 * a.C + c];
     if (a.dgamma) dg = a.dgamma[c];
     if (a.dbeta) db = a.dbeta[c];
   }
@@ -162,8 +162,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mds_bn_bwd_finaliz
   if (a.dgamma) a.dgamma[c] = dg + (float)sgx;
   if (a.dbeta) a.dbeta[c] = db + (float)sg_;
   a.coef[0 * a.C + c] = gam * rstd;
-  a.coef[1 * a.C + c] = a.batch_stats ? (float)sg_ * inv : 0.0f;
-  a.coef[2 * a.C + c] = a.batch_stats ? (float)sgx * inv : 0.0f;
+  const float k0 = gam * rstd, k1 = a.batch_stats ? (float)sg_ * inv : 0.0f, k2 = a.batch_stats ? (float)sgx * inv : 0.0f;
+  a.coef[1 * a.C + c] = k1;
+  a.coef[2 * a.C + c] = k2;
+  if (a.lin) {   // dy = k0*(g - k1 - (y - mean)*rstd*k2) = A*g + B*y + D
+    a.lin[0 * a.C + c] = k0;
+    a.lin[1 * a.C + c] = -k0 * k2 * rstd;
+    a.lin[2 * a.C + c] = k0 * (k2 * rstd * mean - k1);
+  }
 }
 extern "C" int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->C > 0 && a->stats && a->gamma && a->bn && a->coef && a->count > 0,

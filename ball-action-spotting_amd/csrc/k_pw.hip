@@ -27,8 +27,11 @@ template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 //                      1 -> 128x64 tile (4x1 waves of 32x64), ~160 VGPRs, three blocks per CU.
 // BM = rows per tile: 128, or 64 for the small-M layers (stage 5 / 3D: 18400 rows are only 144 tiles of 128 —
 //      fewer blocks than CUs); WN = 2 only.
-template <typename T, int PRO, int WN, int BM>
-__global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+// PRO == PW_PRO_DY: the x operand is dy = A*g + B*y + D formed on load (mds_dyp_t); POST: BatchNorm-backward
+// sums of the NEXT layer over the output tile in the epilogue (mds_poststat_t).
+#define PW_PRO_DY 5
+template <typename T, int PRO, int WN, int BM, bool POST>
+__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || POST ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
   typedef typename Frag<T>::type frag_t;
   constexpr int KC = PwCfg<T>::KC, LD = PwCfg<T>::LD, VPR = KC / 8, RPP = 256 / VPR, NL = BM / RPP;
   constexpr int BN = 64 * WN, MFW = (WN == 2 ? BM / 32 : BM / 64), NLW = BN / RPP;   // tile columns, m-fragments per wave, filter rows per thread
@@ -41,16 +44,19 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const long m0 = (long)blockIdx.x * BM;
   const int K = a.K, N = a.N;
-  const T* x = (const T*)a.x;
+  const T* x = (const T*)(PRO == PW_PRO_DY ? a.xdy.g.u : a.x);
   const T* w = (const T*)a.w;
   T* y = (T*)a.y;
+  const long ydiff = PRO == PW_PRO_DY ? (const T*)a.xdy.y - x : 0;   // the BN input y has x's layout
+  const int gmode = PRO == PW_PRO_DY ? a.xdy.g.mode : 0;
   const int svec = tid % VPR, srow = tid / VPR;  // staging: this thread's k-offset and first row
-  int grow[NL];  // squeeze-excite gate row of each staged row (one division per row per block)
-  if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
+  int grow[NL];  // squeeze-excite gate / DropPath-mask row of each staged row (one division per row per block)
+  if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE || (PRO == PW_PRO_DY && gmode == MDS_G_MASK)) {
+    const long rpg = PRO == PW_PRO_DY ? a.xdy.g.rows_per_group : a.pro.rows_per_group;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       const long m = m0 + srow + RPP * l;
-      grow[l] = (int)((m < a.M ? m : a.M - 1) / a.pro.rows_per_group);
+      grow[l] = (int)((m < a.M ? m : a.M - 1) / rpg);
     }
   }
 
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    RawV8<T> rx[NL], rw[NLW];
+    RawV8<T> rx[NL], rw[NLW], ry[PRO == PW_PRO_DY ? NL : 1];
     const T* wrow[NLW];   // this thread's filter rows of the n-tile (row pointers hoisted out of the k-loop)
     bool wok[NLW];
 #pragma unroll
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
         if (xok[l] && kok) rx[l].ld(xrow[l] + kc); else rx[l].zero();
+        if (PRO == PW_PRO_DY) { if (xok[l] && kok) ry[l].ld(xrow[l] + ydiff + kc); else ry[l].zero(); }
       }
 #pragma unroll
       for (int l = 0; l < NLW; ++l) {
@@ -98,6 +105,28 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
       if (PRO == MDS_PRO_NONE) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) rx[l].st(xs + (srow + RPP * l) * LD + 8 * svec);
+      } else if (PRO == PW_PRO_DY) {
+#pragma unroll
+        for (int l = 0; l < NLW; ++l) rw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);   // frees the filter registers first
+        float cA[8], cB[8], cD[8];
+        const bool kin = kk < K;
+        if (kin) { load8f(a.xdy.lin + kk, cA); load8f(a.xdy.lin + K + kk, cB); load8f(a.xdy.lin + 2 * K + kk, cD); }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          const int r = srow + RPP * l;
+          float u[8], yv[8];
+          rx[l].get(u);
+          ry[l].get(yv);
+          if (xok[l] && kin) {
+            const float mk = gmode == MDS_G_MASK ? a.xdy.g.mask[grow[l]] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = cA[j] * (u[j] * mk) + cB[j] * yv[j] + cD[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = 0.f;   // rows past M / channels past K contribute nothing (D != 0)
+          }
+          store8(xs + r * LD + 8 * svec, u);
+        }
       } else {
         float sc[8], sh[8];
         if (PRO != MDS_PRO_GATE && kk < K) { load8f(a.pro.scale + kk, sc); load8f(a.pro.shift + kk, sh); }
@@ -125,8 +154,10 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
           store8(xs + r * LD + 8 * svec, v);
         }
       }
+      if (PRO != PW_PRO_DY) {
 #pragma unroll
-      for (int l = 0; l < NLW; ++l) rw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
+        for (int l = 0; l < NLW; ++l) rw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
+      }
       __syncthreads();
       if (kc + KC < K) issue(kc + KC);  // in flight while the MFMAs below run
       const int ksteps = (K - kc >= KC) ? KC / 32 : ((K - kc + 31) >> 5);
@@ -152,6 +183,16 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
     float ps[16], pss[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
+    float* pbn = (float*)smem;   // POST: [4][BN] scale, shift, mean, rstd of the tile's columns (over the finished x/w tiles)
+    if (POST) {
+      __syncthreads();           // every wave is done with the fragment reads of the last chunk
+      if (tid < BN) {
+        const int n = n0 + tid;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pbn[k * BN + tid] = n < N ? a.post.bn[(long)k * N + n] : 0.f;
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int mf = 0; mf < MFW; ++mf) {
       const long m = m0 + 16 * MFW * wm + 16 * mf + i;
@@ -174,24 +215,52 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
           }
         }
       }
+      if (POST) {
+        // u of the next BatchNorm backward is this tile: g, sum g, sum g*xhat (rows past M: v == 0 -> g == 0)
+        const T* ysrow = (const T*)a.post.y + (ok ? m : 0) * N + n0 + 64 * wn + 4 * q;
+        const float mk = (a.post.mode == MDS_POST_MASK) ? a.post.mask[(unsigned)(ok ? m : 0) / (unsigned)a.post.rows_per_group] : 1.0f;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          if (nf < nfr) {
+            float ys[4];
+            load4(ysrow + 16 * nf, ys);
+            const float* pc = pbn + 64 * wn + 16 * nf + 4 * q;
+            const f32x4 mu = *(const f32x4*)(pc + 2 * BN), rs = *(const f32x4*)(pc + 3 * BN);
+            if (a.post.mode == MDS_POST_SILU) {
+              const f32x4 sc = *(const f32x4*)pc, sh = *(const f32x4*)(pc + BN);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[nf][r] *= silu_gradf_(ys[r] * sc[r] + sh[r]);   // g replaces u in memory
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float g = Elem<T>::rnd(v[nf][r]) * mk;      // the sums see what later readers will read
+              ps[nf * 4 + r] += g;
+              pss[nf * 4 + r] += g * ((ys[r] - mu[r]) * rs[r]);
+            }
+          }
+        }
+      }
       if (ok) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
           if (nf < nfr) store4(yrow + 16 * nf, v[nf]);
       }
+      if (!POST) {
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)   // rows past M hold zeros (zero-filled operand): no guard needed
+        for (int nf = 0; nf < 4; ++nf)   // rows past M hold zeros (zero-filled operand): no guard needed
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[nf][r]; pss[nf * 4 + r] += v[nf][r] * v[nf][r]; }
+          for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[nf][r]; pss[nf * 4 + r] += v[nf][r] * v[nf][r]; }
+      }
     }
-    if (a.stats) {
+    float* const stat_dst = POST ? a.post.stats : a.stats;
+    if (stat_dst) {
       // after the reduce-scatter every lane of the wave holds ONE column's partial sums: add them to
       // the slot straight away (no LDS staging, no block barrier at the end of every tile)
       const int e = reduce_scatter16(ps, i);
       reduce_scatter16(pss, i);
       const int n = n0 + 64 * wn + 16 * (e >> 2) + 4 * q + (e & 3);
       if (n < N) {
-        float* st = a.stats + (long)((blockIdx.x + wm) % MDS_STAT_SLOTS) * 2 * N;
+        float* st = stat_dst + (long)((blockIdx.x + wm) % MDS_STAT_SLOTS) * 2 * N;
         atomicAdd(st + n, ps[0]);
         atomicAdd(st + N + n, pss[0]);
       }
@@ -202,27 +271,47 @@ __global__ __launch_bounds__(256, WN == 2 && BM == 128 ? 2 : 3) void pw_fwd_kern
 extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_fwd: bad dims");
   MDS_REQUIRE(a->K % 8 == 0 && a->N % 16 == 0, "pw_fwd: K=%d must be a multiple of 8, N=%d of 16", a->K, a->N);
-  MDS_REQUIRE(a->x && a->w && a->y, "pw_fwd: null pointer");
+  const bool dy = a->xdy.mode != 0;
+  MDS_REQUIRE((dy || a->x) && a->w && a->y, "pw_fwd: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || (a->pro.scale && a->pro.shift), "pw_fwd: prologue needs scale/shift");
   MDS_REQUIRE((a->pro.mode != MDS_PRO_BN_SILU_GATE && a->pro.mode != MDS_PRO_GATE) || (a->pro.gate && a->pro.rows_per_group > 0), "pw_fwd: gate prologue");
+  if (dy) {
+    MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE && a->xdy.g.u && a->xdy.y && a->xdy.lin, "pw_fwd: dy prologue needs u, y, lin and no other prologue");
+    MDS_REQUIRE(a->xdy.g.mode == MDS_G_PLAIN || (a->xdy.g.mode == MDS_G_MASK && a->xdy.g.mask && a->xdy.g.rows_per_group > 0),
+                "pw_fwd: dy prologue takes PLAIN or MASK gradient sources (SILU is folded upstream by MDS_POST_SILU)");
+  }
+  const bool post = a->post.mode != MDS_POST_NONE;
+  if (post) {
+    MDS_REQUIRE(a->post.y && a->post.bn && a->post.stats && !a->stats, "pw_fwd: post statistics need y, bn, stats (and no forward stats)");
+    MDS_REQUIRE(a->post.mode != MDS_POST_MASK || (a->post.mask && a->post.rows_per_group > 0), "pw_fwd: post mask");
+    MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE && a->M < 4294967295L, "pw_fwd: post statistics are a data-gradient feature (no forward prologue)");
+  }
   // 128x64 tiles for the narrow projections (N <= 64: half of a 128-column tile would be padding;
   // 154 -> 119 us at 1.18 M x 128 -> 32); wider N measured 5-20 % slower with them despite 3 blocks/CU
   const int wn = a->N <= 64 ? 1 : 2;
   const int BN = 64 * wn;
   // 64-row tiles below 400 k rows: twice the blocks for the stage-3..5 / 3D layers (isolated: -10...25 %;
   // inside the step, where the weight-gradient stream fills the idle CUs anyway, +1 %)
-  const int bm = (wn == 2 && a->M <= 400000) ? 64 : PW_BM;
+  // (the dy-prologue variant keeps two operand tiles in flight: its 128-row form would spill)
+  const int bm = (wn == 2 && (a->M <= 400000 || dy)) ? 64 : PW_BM;
   const int mt = cdiv(a->M, bm), nt = cdiv(a->N, BN);
   int gy = 1;
   if (nt > 1) { gy = cdiv(1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
   dim3 grid(mt, gy), block(256);
-#define PW_GO(T, PRO) \
+#define PW_GO2(T, PRO, POST) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T); \
-       if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64>), grid, block, smem, stream, *a); \
-       else if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 128>), grid, block, smem, stream, *a); \
-       else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1, 128>), grid, block, smem, stream, *a); } while (0)
+       if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, POST>), grid, block, smem, stream, *a); \
+       else if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 128, POST>), grid, block, smem, stream, *a); \
+       else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1, 128, POST>), grid, block, smem, stream, *a); } while (0)
+#define PW_GO(T, PRO) PW_GO2(T, PRO, false)
+#define PW_GODY(T, POST) \
+  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T); \
+       if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 2, 64, POST>), grid, block, smem, stream, *a); \
+       else MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 1, 128, POST>), grid, block, smem, stream, *a); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
-    switch (a->pro.mode) {
+    if (dy) { if (post) PW_GODY(T, true); else PW_GODY(T, false); }
+    else if (post) PW_GO2(T, MDS_PRO_NONE, true);
+    else switch (a->pro.mode) {
       case MDS_PRO_NONE: PW_GO(T, MDS_PRO_NONE); break;
       case MDS_PRO_AFFINE: PW_GO(T, MDS_PRO_AFFINE); break;
       case MDS_PRO_BN_SILU: PW_GO(T, MDS_PRO_BN_SILU); break;
@@ -232,6 +321,8 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
     }
   });
 #undef PW_GO
+#undef PW_GO2
+#undef PW_GODY
   return mds_check_launch("pw_fwd");
 }
 
@@ -254,7 +345,18 @@ MDS_DEV void wg_put(bf16_t* base, int off, float v0, float v1) {
 }
 MDS_DEV void wg_put(float* base, int off, float v0, float) { base[off] = v0; }
 
-template <typename T, int PRO, int NF, int KF>
+// dy = A*g + B*y + D on 8 channels of one row (mds_dyp_t; gradient sources PLAIN / MASK)
+struct DyCoef { float A[8], B[8], D[8]; };
+MDS_DEV void dy_coef_load(const mds_dyp_t& d, int C, int c, DyCoef& k) {
+  load8f(d.lin + c, k.A); load8f(d.lin + C + c, k.B); load8f(d.lin + 2 * C + c, k.D);
+}
+MDS_DEV void dy_form(const mds_dyp_t& d, const DyCoef& k, long row, const float (&u)[8], const float (&yv)[8], float (&v)[8]) {
+  const float mk = d.g.mode == MDS_G_MASK ? d.g.mask[(unsigned)row / (unsigned)d.g.rows_per_group] : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = k.A[j] * (u[j] * mk) + k.B[j] * yv[j] + k.D[j];
+}
+
+template <typename T, int PRO, int NF, int KF, bool DYP>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, int rows_per_block) {
   typedef typename Frag<T>::type frag_t;
   constexpr int MW = WgCfg<T>::MW, LDT = WgCfg<T>::LDT;
@@ -273,7 +375,11 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
   long mend = mbeg + rows_per_block;
   if (mend > a.M) mend = a.M;
   const T* x = (const T*)a.x;
-  const T* dy = (const T*)a.dy;
+  const T* dy = (const T*)(DYP ? a.dyp.g.u : a.dy);
+  const long ydiff = DYP ? (const T*)a.dyp.y - dy : 0;
+  static_assert(256 % YCH == 0, "a thread keeps one 8-channel slice of dy");
+  DyCoef dk;
+  if (DYP && n0 + 8 * (tid % YCH) < N) dy_coef_load(a.dyp, N, n0 + 8 * (tid % YCH), dk);
   const int kfr = (K - kt0 >= KT) ? KF : ((K - kt0 + 15) >> 4);
 
   // when 256 % XCH == 0 a thread keeps the same 8-channel slice for every staged item: its BN
@@ -291,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
 #pragma unroll
     for (int v = 0; v < KF; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  RawV8<T> rx[XI][MW], ry[YI][MW];
+  RawV8<T> rx[XI][MW], ry[YI][MW], ryy[DYP ? YI : 1][MW];
   auto issue = [&](long mb) {   // every global load of one 64-row step
 #pragma unroll
     for (int p = 0; p < XI; ++p) {
@@ -309,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
       for (int h = 0; h < MW; ++h) {
         const long m = mb + (it / YCH) * MW + h;
         if (it < YN && m < mend && n < N) ry[p][h].ld(dy + m * N + n); else ry[p][h].zero();
+        if (DYP) { if (it < YN && m < mend && n < N) ryy[p][h].ld(dy + ydiff + m * N + n); else ryy[p][h].zero(); }
       }
     }
   };
@@ -353,7 +460,17 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
       if (it < YN) {
         float v[MW][8];
 #pragma unroll
-        for (int h = 0; h < MW; ++h) ry[p][h].get(v[h]);
+        for (int h = 0; h < MW; ++h) {
+          ry[p][h].get(v[h]);
+          if (DYP) {
+            const long m = mb + (it / YCH) * MW + h;
+            float yv[8], u[8];
+            ryy[p][h].get(yv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = v[h][j];
+            if (m < mend && n0 + 8 * (it % YCH) < N) dy_form(a.dyp, dk, m, u, yv, v[h]);
+          }
+        }
         const int ml = (it / YCH) * MW, yc = it % YCH;
 #pragma unroll
         for (int j = 0; j < 8; ++j) wg_put(dsT, wg_off<LDT>(8 * yc + j, ml), v[0][j], v[MW - 1][j]);
@@ -399,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
 // stores, and no bf16->fp32->bf16 round trip without a prologue); a fragment — 8 rows of one
 // channel — is two ds_read_b64_tr_b16.  Row pitches are odd multiples of 32 bytes so the 8 rows a
 // 32-lane LDS cycle touches sit in distinct bank groups.
-template <int PRO, int NF, int KF>
+template <int PRO, int NF, int KF, bool DYP>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a, int rows_per_block) {
   typedef bf16_t T;
   constexpr int NT = 64 * NF, KT = 16 * KF, XCH = KT / 8, YCH = NT / 8;
@@ -418,7 +535,11 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
   long mend = mbeg + rows_per_block;
   if (mend > a.M) mend = a.M;
   const T* x = (const T*)a.x;
-  const T* dy = (const T*)a.dy;
+  const T* dy = (const T*)(DYP ? a.dyp.g.u : a.dy);
+  const long ydiff = DYP ? (const T*)a.dyp.y - dy : 0;
+  static_assert(256 % YCH == 0, "a thread keeps one 8-channel slice of dy");
+  DyCoef dk;
+  if (DYP && n0 + 8 * (tid % YCH) < N) dy_coef_load(a.dyp, N, n0 + 8 * (tid % YCH), dk);
   const int kfr = (K - kt0 >= KT) ? KF : ((K - kt0 + 15) >> 4);
   constexpr bool FIXED_CH = (256 % XCH) == 0;
   float sc[8], sh[8];
@@ -434,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
 
   // per-thread staging constants: row within a step, channel, validity, running pointers (the 64-bit
   // address arithmetic per load and step was most of this loop's instruction count)
-  RawV8<T> rx[XI], ry[YI];
+  RawV8<T> rx[XI], ry[YI], ryy[DYP ? YI : 1];
   int xr[XI], yr[YI];
   bool xok[XI], yok[YI];
   const T* px[XI];
@@ -464,6 +585,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
 #pragma unroll
     for (int p = 0; p < YI; ++p) {
       if (yok[p] && yr[p] < left) ry[p].ld(py[p]); else ry[p].zero();
+      if (DYP) { if (yok[p] && yr[p] < left) ryy[p].ld(py[p] + ydiff); else ryy[p].zero(); }
       py[p] += ystep;
     }
   };
@@ -507,7 +629,22 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
 #pragma unroll
     for (int p = 0; p < YI; ++p) {
       const int it = tid + 256 * p;
-      if (it < YN) ry[p].st(ds + (it / YCH) * LDY + 8 * (it % YCH));
+      if (it < YN) {
+        if (!DYP) {
+          ry[p].st(ds + (it / YCH) * LDY + 8 * (it % YCH));
+        } else {
+          const long m = mb + yr[p];
+          float u[8], yv[8], v[8];
+          ry[p].get(u);
+          ryy[p].get(yv);
+          if (yok[p] && m < mend) dy_form(a.dyp, dk, m, u, yv, v);
+          else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          }
+          store8(ds + (it / YCH) * LDY + 8 * (it % YCH), v);
+        }
+      }
     }
     __syncthreads();
     if (mb + WG_ROWS < mend) issue(mb + WG_ROWS);   // next step's loads fly under this step's MFMAs
@@ -549,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
 extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_wgrad: bad dims");
   MDS_REQUIRE(a->K % 8 == 0 && a->N % 8 == 0, "pw_wgrad: K, N must be multiples of 8");
-  MDS_REQUIRE(a->x && a->dy && a->dw, "pw_wgrad: null pointer");
+  MDS_REQUIRE(a->x && (a->dy || a->dyp.mode) && a->dw, "pw_wgrad: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || (a->pro.scale && a->pro.shift), "pw_wgrad: prologue needs scale/shift");
   MDS_REQUIRE((a->pro.mode != MDS_PRO_BN_SILU_GATE && a->pro.mode != MDS_PRO_GATE) || (a->pro.gate && a->pro.rows_per_group > 0), "pw_wgrad: gate prologue");
   MDS_REQUIRE(a->M < 2147483647L, "pw_wgrad: M too large");
@@ -567,10 +704,20 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   rpb = ((rpb + WG_ROWS - 1) / WG_ROWS) * WG_ROWS;
   if (rpb < 4 * WG_ROWS) rpb = 4 * WG_ROWS;
   dim3 grid(cdiv(a->M, rpb), tiles), block(256);
+  const bool dyp = a->dyp.mode != 0;
+  if (dyp) {
+    MDS_REQUIRE(a->dyp.g.u && a->dyp.y && a->dyp.lin, "pw_wgrad: dy prologue needs u, y, lin");
+    MDS_REQUIRE(a->dyp.g.mode == MDS_G_PLAIN || (a->dyp.g.mode == MDS_G_MASK && a->dyp.g.mask && a->dyp.g.rows_per_group > 0),
+                "pw_wgrad: dy prologue takes PLAIN or MASK gradient sources");
+  }
 #define WG_GO(T, PRO) \
-  MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4>), grid, block, (size_t)(KT + NT) * WgCfg<T>::LDT * sizeof(T), stream, *a, (int)rpb)
+  do { const size_t smem_ = (size_t)(KT + NT) * WgCfg<T>::LDT * sizeof(T); \
+       if (dyp) MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4, true>), grid, block, smem_, stream, *a, (int)rpb); \
+       else MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4, false>), grid, block, smem_, stream, *a, (int)rpb); } while (0)
 #define WGT_GO(PRO) \
-  MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4>), grid, block, (size_t)WG_ROWS * (KT + 16 + NT + 16) * sizeof(bf16_t), stream, *a, (int)rpb)
+  do { const size_t smem_ = (size_t)WG_ROWS * (KT + 16 + NT + 16) * sizeof(bf16_t); \
+       if (dyp) MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4, true>), grid, block, smem_, stream, *a, (int)rpb); \
+       else MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4, false>), grid, block, smem_, stream, *a, (int)rpb); } while (0)
   if (a->dtype == MDS_BF16 && !mds_switch(MDS_SW_WG_OLD)) {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: WGT_GO(MDS_PRO_NONE); break;

@@ -167,3 +167,12 @@ def pro(mode=0, scale=None, shift=None, gate=None, rows_per_group=0):
 def gsrc(mode=0, u=None, gate=None, dpooled=None, mask=None, rows_per_group=0):
     return make("mds_gsrc_t", mode=mode, u=u, gate=gate, dpooled=dpooled, mask=mask,
                 rows_per_group=rows_per_group)
+
+
+def dyp(g, y, bn, lin):
+    """mds_dyp_t: dy = A*g + B*y + D formed on load (g: an mds_gsrc_t built with gsrc())."""
+    return make("mds_dyp_t", mode=1, g=g, y=y, bn=bn, lin=lin)
+
+
+def poststat(mode, y, bn, stats, mask=None, rows_per_group=0):
+    return make("mds_poststat_t", mode=mode, y=y, bn=bn, mask=mask, rows_per_group=rows_per_group, stats=stats)

@@ -30,6 +30,17 @@ from .cabi import MDS_STAT_SLOTS as SLOTS
 
 PRO_NONE, PRO_AFFINE, PRO_BN_SILU, PRO_BN_GATE, PRO_GATE = 0, 1, 2, 3, 4
 G_PLAIN, G_SILU, G_SE, G_MASK = 0, 1, 2, 3
+POST_NONE, POST_PLAIN, POST_MASK, POST_SILU = 0, 1, 2, 3
+
+
+class Grad:
+    """A gradient tensor handed from one backward closure to the next.  `reduced` names the BatchNorm layer
+    whose backward sums (sum g, sum g*xhat) the PRODUCING kernel already took in its epilogue (mds_poststat_t);
+    with POST_SILU the buffer holds g = u*silu'(z) instead of u."""
+    __slots__ = ("buf", "reduced")
+
+    def __init__(self, buf, reduced=None):
+        self.buf, self.reduced = buf, reduced
 
 
 class Lazy:
@@ -70,6 +81,7 @@ class BNL:
         self.stats = pb.zero_fwd(SLOTS * 2 * C_) if pb.batch_stats else None
         self.bstats = pb.zero_bwd(SLOTS * 2 * C_) if pb.need_grad else None
         self.coef = pb.f32(3 * C_) if pb.need_grad else None
+        self.lin = pb.f32(3 * C_) if pb.need_grad else None     # A, B, D of dy = A*g + B*y + D (mds_dyp_t)
 
     scale = property(lambda s: s.buf.sub(0, s.C))
     shift = property(lambda s: s.buf.sub(s.C, s.C))
@@ -86,15 +98,37 @@ class BNL:
               training=int(pb.batch_stats), running_mean=P(m.running_mean), running_var=P(m.running_var),
               num_batches_tracked=P(m.num_batches_tracked) if pb.batch_stats else None, out=self.buf)
 
-    def backward(self, pb, seg, gsrc, y, dy, reduce=True, frozen=False):
-        """emit reduce / finalize / apply; `gsrc` describes how g is derived (mds_gsrc_t)."""
-        M = self.count
-        if reduce:
-            pb.op(seg, "bn_bwd_reduce", dtype=pb.code, M=M, C=self.C, g=gsrc, y=y, bn=self.buf, stats=self.bstats)
-        pb.op(seg, "bn_bwd_finalize", C=self.C, count=M, stats=self.bstats, gamma=P(self.mod.weight), bn=self.buf,
+    def bwd_reduce(self, pb, seg, gsrc, y):
+        pb.op(seg, "bn_bwd_reduce", dtype=pb.code, M=self.count, C=self.C, g=gsrc, y=y, bn=self.buf, stats=self.bstats)
+
+    def bwd_finalize(self, pb, seg, frozen=False):
+        pb.op(seg, "bn_bwd_finalize", C=self.C, count=self.count, stats=self.bstats, gamma=P(self.mod.weight), bn=self.buf,
               dgamma=None if frozen else pb.grad(self.mod.weight), dbeta=None if frozen else pb.grad(self.mod.bias),
-              coef=self.coef, batch_stats=int(pb.batch_stats))
-        pb.op(seg, "bn_bwd_apply", dtype=pb.code, M=M, C=self.C, g=gsrc, y=y, bn=self.buf, coef=self.coef, dy=dy)
+              coef=self.coef, lin=self.lin, batch_stats=int(pb.batch_stats))
+
+    def backward(self, pb, seg, gsrc, y, dy, reduce=True, frozen=False):
+        """emit reduce / finalize / apply (dy materialised); `gsrc` describes how g is derived (mds_gsrc_t)."""
+        if reduce:
+            self.bwd_reduce(pb, seg, gsrc, y)
+        self.bwd_finalize(pb, seg, frozen)
+        pb.op(seg, "bn_bwd_apply", dtype=pb.code, M=self.count, C=self.C, g=gsrc, y=y, bn=self.buf, coef=self.coef, dy=dy)
+
+    def backward_fused(self, pb, seg, gsrc, y, reduce=True, frozen=False):
+        """reduce (unless the producer of u took the sums) / finalize; returns the dy-prologue descriptor that the
+        consumers of dy evaluate on load (mds_dyp_t) — no apply pass, no dy tensor.  gsrc: PLAIN or MASK."""
+        assert gsrc["mode"] in (G_PLAIN, G_MASK)
+        if reduce:
+            self.bwd_reduce(pb, seg, gsrc, y)
+        self.bwd_finalize(pb, seg, frozen)
+        return dict(_struct="mds_dyp_t", mode=1, g=gsrc, y=y, bn=self.buf, lin=self.lin)
+
+    def head(self, y, mode, mask=None, rpg=0):
+        """what a producing data-gradient GEMM needs to take this layer's backward sums in its epilogue"""
+        return dict(bn=self, y=y, mode=mode, mask=mask, rpg=rpg)
+
+    def post(self, head):
+        return dict(_struct="mds_poststat_t", mode=head["mode"], y=head["y"], bn=self.buf, mask=head["mask"],
+                    rows_per_group=head["rpg"], stats=self.bstats)
 
 
 def op_cost(name, kw, es):
@@ -161,6 +195,7 @@ class Plan:
         self.need_grad = need_grad
         self.enc_grad = enc_grad and need_grad
         self.m = module
+        self.fuse_bn_bwd = os.environ.get("MDS_FUSE_BN_BWD", "1") != "0"   # developer switch: 0 = reduce/apply kernels everywhere
         self.in_flight = False
         self.generation = 0      # bumped by every grad-enabled forward: a stale autograd node must not run
         self.profile = None      # list -> run() brackets every launch with HIP events
@@ -255,15 +290,15 @@ class Plan:
                     scale=self.bnq.scale, shift=self.bnq.shift, act=1, mask=None, rows_per_group=0,
                     shortcut=None, out=self.out3d)
         if self.need_grad:
+            chain = [(rec, bseg) for name, bseg in (("head", "bhead"), ("3d", "b3d"), ("2d", "b2d")) for rec in reversed(self._recs[name])]
             gout = None
-            for name, bseg in (("head", "bhead"), ("3d", "b3d"), ("2d", "b2d")):
-                for rec in reversed(self._recs[name]):
-                    gout = rec(bseg, gout)
-                    if gout is None:
-                        break
+            for i, (rec, bseg) in enumerate(chain):
+                nxt = chain[i + 1][0] if i + 1 < len(chain) else None
+                # `head` of the next closure: the BatchNorm whose backward consumes this closure's output directly
+                gout = rec(bseg, gout, getattr(nxt, "head", None) if self.fuse_bn_bwd else None)
                 if gout is None:
                     break
-            self.dfeat = gout if self.kind == "tail" else None   # "tail": gradient wrt the (b,S,h,w,192) features
+            self.dfeat = gout.buf if (self.kind == "tail" and gout is not None) else None   # gradient wrt the (b,S,h,w,192) features
 
     # -- helpers emitting a conv + its BN finalize
     def _pw(self, seg, x, M, K, N_, wparam, pro=None, stats_bn=None, residual=None, wt=None):
@@ -308,18 +343,25 @@ class Plan:
                             wi=wi, **common)
         return dxb
 
-    def _pw_bwd(self, seg, xin, pro, M, K, N_, wparam, dy, need_dx, residual=None, frozen=False):
-        """wgrad (+ dgrad) of a 1x1 conv y[M][N] = pro(x)[M][K] w^T."""
+    def _pw_bwd(self, seg, xin, pro, M, K, N_, wparam, dy, need_dx, residual=None, frozen=False, head=None):
+        """wgrad (+ dgrad) of a 1x1 conv y[M][N] = pro(x)[M][K] w^T.  `dy` is a materialised tensor or a dy-prologue
+        descriptor (BNL.backward_fused); `head`: take the next BatchNorm backward's sums in the dgrad epilogue."""
+        fused = isinstance(dy, dict)
         if not frozen:
-            self.op(seg, "pw_wgrad", dtype=self.code, M=M, K=K, N=N_, x=xin, dy=dy, dw=self.grad(wparam),
-                    pro=pro or dict(mode=0))
+            self.op(seg, "pw_wgrad", dtype=self.code, M=M, K=K, N=N_, x=xin, dy=None if fused else dy, dw=self.grad(wparam),
+                    pro=pro or dict(mode=0), **({"dyp": dy} if fused else {}))
         if not need_dx:
             return None
         wt = self.pack(wparam, cabi.MDS_PACK_IO_FLIP, N_, K, 1)       # [K][N]
         dx = self.act(M, K)
-        self.op(seg, "pw_fwd", dtype=self.code, M=M, K=N_, N=K, x=dy, w=wt, y=dx, pro=dict(mode=0),
-                residual=residual, stats=None)
-        return dx
+        extra = {}
+        if fused:
+            extra["xdy"] = dy
+        if head is not None:
+            extra["post"] = head["bn"].post(head)
+        self.op(seg, "pw_fwd", dtype=self.code, M=M, K=N_, N=K, x=None if fused else dy, w=wt, y=dx, pro=dict(mode=0),
+                residual=residual, stats=None, **extra)
+        return Grad(dx, head["bn"] if head is not None else None)
 
     # -- inverted-residual block (2D: T=1, kt=1 ; 3D: kt=3), shared by encoder stages 3-5 and conv3d_encoder
     def _ir_block(self, fseg, recs, blk, bn1m, bn2m, bn3m, xin, N, T, IH, IW, stride, groups, has_skip, frozen):
@@ -352,11 +394,17 @@ class Plan:
         self.op(fseg, "bn_res", dtype=self.code, M=Mout, C=cout, y=y3, scale=bn3.scale, shift=bn3.shift, act=0, mask=mask,
                 rows_per_group=rpg, shortcut=xin if has_skip else None, out=xout)
 
-        def bwd(seg, dout):
-            g3 = gsrc(G_MASK, dout, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout)
-            dy3 = self.act(Mout, cout)
-            bn3.backward(self, seg, g3, y3, dy3, frozen=frozen)
-            u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen)
+        fuse = self.fuse_bn_bwd
+
+        def bwd(seg, dout, nxt_head):
+            g3 = gsrc(G_MASK, dout.buf, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout.buf)
+            if fuse:
+                # BN3 backward: sums by the producer of dout when that was a 1x1 data-gradient GEMM, dy formed on load
+                dy3 = bn3.backward_fused(self, seg, g3, y3, reduce=dout.reduced is not bn3, frozen=frozen)
+            else:
+                dy3 = self.act(Mout, cout)
+                bn3.backward(self, seg, g3, y3, dy3, frozen=frozen)
+            u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen).buf
             dgate, dpool = self.zero_bwd(groups * mid), self.f32(groups * mid)
             nblk = self.lib.fn["se_bwd_reduce_blocks"](rpg, mid)
             bnsums = self.f32(groups * nblk * 4 * mid)
@@ -377,11 +425,15 @@ class Plan:
             self.op(seg, "dw_bwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
                     pad_l=pl, kt=kt, x=y1, dy=dy2, w=wdw, g=g1, dw=self.f32(mid * kt * 9) if frozen else self.grad(blk.conv_dw.weight),
                     pro=bn1.pro(), mean=bn1.mean, rstd=bn1.rstd, stats=bn1.bstats)
-            dy1 = self.act(Min, mid)
-            bn1.backward(self, seg, gsrc(G_PLAIN, g1), y1, dy1, reduce=False, frozen=frozen)
+            if fuse:
+                dy1 = bn1.backward_fused(self, seg, gsrc(G_PLAIN, g1), y1, reduce=False, frozen=frozen)
+            else:
+                dy1 = self.act(Min, mid)
+                bn1.backward(self, seg, gsrc(G_PLAIN, g1), y1, dy1, reduce=False, frozen=frozen)
             return self._pw_bwd(seg, xin, None, Min, cin, mid, blk.conv_pw.weight, dy1, True,
-                                residual=dout if has_skip else None, frozen=frozen)
+                                residual=dout.buf if has_skip else None, frozen=frozen, head=nxt_head)
 
+        bwd.head = bn3.head(y3, POST_MASK if mask is not None else POST_PLAIN, mask, rpg)
         recs.append(bwd)
         return xout, OH, OW
 
@@ -398,11 +450,11 @@ class Plan:
                 w=wst, y=y0, stats=bn0.stats)
         bn0.finalize(self, "f2d")
 
-        def stem_bwd(seg, u0):
+        def stem_bwd(seg, u0, nxt_head):
             if fr:
                 return None
             dy0 = self.act(N * OH * OW, 32)
-            bn0.backward(self, seg, gsrc(G_SILU, u0), y0, dy0)
+            bn0.backward(self, seg, gsrc(G_SILU, u0.buf), y0, dy0)
             self.op(seg, "stem_wgrad", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
                     x=self.x_in, dy=dy0, dw=self.grad(enc.conv_stem.weight))
             return None
@@ -429,11 +481,15 @@ class Plan:
                 rows_per_group=0, shortcut=None, out=feat)
         xenc = cur
 
-        def proj_bwd(seg, dfeat):
-            dyp = self.act(M, cf)
-            bnp.backward(self, seg, gsrc(G_SILU, dfeat), yp, dyp)
-            return self._pw_bwd(seg, xenc, None, M, cenc, cf, m.conv2d_projection[0].weight, dyp, need_dx=not fr)
+        def proj_bwd(seg, dfeat, nxt_head):
+            if dfeat.reduced is bnp:      # the 3D tail's last data-gradient GEMM stored g = dfeat*silu'(z) and took the sums
+                dyp = bnp.backward_fused(self, seg, gsrc(G_PLAIN, dfeat.buf), yp, reduce=False)
+            else:
+                dyp = self.act(M, cf)
+                bnp.backward(self, seg, gsrc(G_SILU, dfeat.buf), yp, dyp)
+            return self._pw_bwd(seg, xenc, None, M, cenc, cf, m.conv2d_projection[0].weight, dyp, need_dx=not fr, head=nxt_head)
 
+        proj_bwd.head = bnp.head(yp, POST_SILU)
         recs.append(proj_bwd)
         return feat, ch, cw
 
@@ -442,13 +498,13 @@ class Plan:
         y, bn1, OH, OW, pads = self._conv("f2d", xin, xin_bn.pro(), N, IH, IW, blk.cin, blk.cout, blk.stride,
                                           blk.conv.weight, blk.bn1)
 
-        def bwd(seg, u):
+        def bwd(seg, u, nxt_head):
             if fr:
                 return None
             dy_ = self.act(N * OH * OW, blk.cout)
-            bn1.backward(self, seg, gsrc(G_SILU, u), y, dy_)
+            bn1.backward(self, seg, gsrc(G_SILU, u.buf), y, dy_)
             self._conv_wgrad(seg, xin, xin_bn.pro(), N, IH, IW, blk.cin, OH, OW, blk.cout, blk.stride, pads, dy_, blk.conv.weight)
-            return self._conv_dgrad(seg, dy_, N, IH, IW, blk.cin, blk.cout, blk.stride, blk.conv.weight, pads, None)
+            return Grad(self._conv_dgrad(seg, dy_, N, IH, IW, blk.cin, blk.cout, blk.stride, blk.conv.weight, pads, None))
 
         recs.append(bwd)
         return y, bn1, OH, OW
@@ -474,19 +530,29 @@ class Plan:
         self.op("f2d", "bn_res", dtype=self.code, M=M, C=cout, y=yb, scale=bn2.scale, shift=bn2.shift, act=0, mask=mask,
                 rows_per_group=rpg, shortcut=xin if has_skip else None, out=xout)
 
-        def bwd(seg, dout):
+        fuse = self.fuse_bn_bwd
+
+        def bwd(seg, dout, nxt_head):
             if fr:
                 return None
-            g2 = gsrc(G_MASK, dout, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout)
-            dyb = self.act(M, cout)
-            bn2.backward(self, seg, g2, yb, dyb)
-            ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
+            g2 = gsrc(G_MASK, dout.buf, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout.buf)
             dya = self.act(M, mid)
-            bn1.backward(self, seg, gsrc(G_SILU, ua), ya, dya)
+            if fuse:
+                # BN2 (narrow) backward folded into the projection's weight / data gradient; that data-gradient GEMM
+                # stores g_a = u_a*silu'(z_a) and takes BN1's sums over it, so BN1's apply reads a PLAIN source
+                dyb = bn2.backward_fused(self, seg, g2, yb, reduce=dout.reduced is not bn2)
+                ga = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True, head=bn1.head(ya, POST_SILU))
+                bn1.backward(self, seg, gsrc(G_PLAIN, ga.buf), ya, dya, reduce=False)
+            else:
+                dyb = self.act(M, cout)
+                bn2.backward(self, seg, g2, yb, dyb)
+                ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
+                bn1.backward(self, seg, gsrc(G_SILU, ua.buf), ya, dya)
             self._conv_wgrad(seg, xin, pro_in, N, IH, IW, cin, OH, OW, mid, blk.stride, pads, dya, blk.conv_exp.weight)
-            return self._conv_dgrad(seg, dya, N, IH, IW, cin, mid, blk.stride, blk.conv_exp.weight, pads,
-                                    dout if has_skip else None)
+            return Grad(self._conv_dgrad(seg, dya, N, IH, IW, cin, mid, blk.stride, blk.conv_exp.weight, pads,
+                                         dout.buf if has_skip else None))
 
+        bwd.head = bn2.head(yb, POST_MASK if mask is not None else POST_PLAIN, mask, rpg)
         recs.append(bwd)
         return xout, OH, OW
 
@@ -504,10 +570,10 @@ class Plan:
         yq = self._pw("f3d", cur, M, cf, cq, m.conv3d_projection[0].weight, stats_bn=bnq)
         x3 = cur
 
-        def bwd(seg, uq):
+        def bwd(seg, uq, nxt_head):
             dyq = self.act(M, cq)
-            bnq.backward(self, seg, gsrc(G_SILU, uq), yq, dyq)
-            return self._pw_bwd(seg, x3, None, M, cf, cq, m.conv3d_projection[0].weight, dyq, True)
+            bnq.backward(self, seg, gsrc(G_SILU, uq.buf), yq, dyq)
+            return self._pw_bwd(seg, x3, None, M, cf, cq, m.conv3d_projection[0].weight, dyq, True, head=nxt_head)
 
         recs.append(bwd)
         return yq, bnq
@@ -529,14 +595,14 @@ class Plan:
                 b=P(m.classifier.bias), logits=self.logits)
         self.dlogits = self.f32(B * ncls) if self.need_grad else None
 
-        def bwd(seg, _):
+        def bwd(seg, _, nxt_head):
             dpo = self.f32(B * F_)
             self.op(seg, "head_bwd", B=B, F=F_, NC=ncls, pooled=pooled, mask=dmask, w=P(m.classifier.weight),
                     dlogits=self.dlogits, dpooled=dpo, dw=self.grad(m.classifier.weight), db=self.grad(m.classifier.bias))
             uq = self.act(B * S * h * w, cq)
             self.op(seg, "gem_bwd", dtype=self.code, groups=B * S, rows_per_group=h * w, C=cq, y=yq, pro=pro, p=P(gp.p),
                     eps=float(gp.eps), pooled=pooled, dpooled=dpo, u=uq, dp=self.grad(gp.p), accum=self.zero_bwd(B * S * cq))
-            return uq
+            return Grad(uq)
 
         self._recs["head"].append(bwd)
 
@@ -587,8 +653,7 @@ class Plan:
             if k == "_struct":
                 continue
             if isinstance(v, dict):
-                sub = "mds_gsrc_t" if v.get("_struct") == "mds_gsrc_t" else "mds_pro_t"
-                v = self._bind(sub, v)
+                v = self._bind(v.get("_struct", "mds_pro_t"), v)
             elif isinstance(v, Lazy) and v.kind == "input":
                 self._input_fields.append((struct_name, k))
                 v = 0

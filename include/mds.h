@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 101
+#define MDS_VERSION 102
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -56,6 +56,56 @@ typedef struct {
   long rows_per_group;
 } mds_pro_t;
 
+/* ---- gradient sources: g (grad wrt a BatchNorm output z) is derived on the fly from an upstream tensor u:
+ *   MDS_G_PLAIN      g = u
+ *   MDS_G_SILU       g = u * silu'(z)
+ *   MDS_G_SE_SILU    g = (u * gate[grp][c] + dpooled[grp][c]) * silu'(z)
+ *   MDS_G_MASK       g = u * mask[grp]                                   (DropPath)           */
+#define MDS_G_PLAIN 0
+#define MDS_G_SILU 1
+#define MDS_G_SE_SILU 2
+#define MDS_G_MASK 3
+typedef struct {
+  int mode;
+  const void* u;        /* [M][C] */
+  const float* gate;    /* [groups][C] */
+  const float* dpooled; /* [groups][C] */
+  const float* mask;    /* [groups]    */
+  long rows_per_group;
+} mds_gsrc_t;
+
+/* ---- "dy prologue": BatchNorm backward folded into the consumers of dy.  With the per-channel
+ * coefficients lin = {A, B, D} written by mds_bn_bwd_finalize,
+ *   dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) = A*g + B*y + D          (y = raw conv output)
+ * so a kernel that needs dy (the data-gradient GEMM, the weight-gradient GEMM) reads u and y and
+ * forms dy while loading; the elementwise "apply" pass and the dy tensor disappear.
+ * (replaces the second half of torch's native_batch_norm_backward behind BatchNormAct2d/3d.)   */
+typedef struct {
+  int mode;            /* 0: the operand pointer of the consumer IS dy;  1: dy formed on load      */
+  mds_gsrc_t g;        /* u and how g derives from it: PLAIN or MASK (a SiLU factor is folded into u by the
+                          producer, MDS_POST_SILU, or by mds_bn_bwd_apply)                           */
+  const void* y;       /* [M][C] raw conv output of the BatchNorm's input                          */
+  const float* bn;     /* [4][C] scale, shift, mean, rstd                                          */
+  const float* lin;    /* [3][C] A, B, D                                                           */
+} mds_dyp_t;
+
+/* ---- "post statistics": the first half of BatchNorm backward (sum g, sum g*xhat) folded into the
+ * epilogue of the kernel that PRODUCES u (a data-gradient GEMM): the output tile v is u of a BN layer
+ * whose raw input is y.  MDS_POST_SILU also stores g = v*silu'(z) instead of v, so that every later
+ * reader sees a PLAIN gradient source.                                                            */
+#define MDS_POST_NONE 0
+#define MDS_POST_PLAIN 1   /* g = v                         */
+#define MDS_POST_MASK 2    /* g = v * mask[row / rows_per_group]; v itself is stored (it is also the shortcut gradient) */
+#define MDS_POST_SILU 3    /* g = v * silu'(y*scale+shift); g is stored                                              */
+typedef struct {
+  int mode;
+  const void* y;       /* [M][N] raw conv output */
+  const float* bn;     /* [4][N] */
+  const float* mask;   /* [groups] (MASK) */
+  long rows_per_group;
+  float* stats;        /* [SLOTS][2][N] caller-zeroed: sum g, sum g*xhat */
+} mds_poststat_t;
+
 /* ---- K4: 1x1 convolution = GEMM  y[M][N] = pro(x)[M][K] * w[N][K]^T  (+ residual)
  * replaces nn.Conv2d/Conv3d k=1 at multidim_stacker.py:106,120,179-183,199-203 and timm
  * conv_pw/conv_pwl; also used as its own data-gradient (w = transposed pack).                  */
@@ -69,6 +119,9 @@ typedef struct {
   mds_pro_t pro;
   const void* residual; /* optional [M][N], added after the product                            */
   float* stats;         /* optional [SLOTS][2][N]                                               */
+  mds_dyp_t xdy;        /* data-gradient use: xdy.mode == 1 -> the x operand is dy formed on load
+                           (channels = K; `x` ignored, pro must be NONE)                         */
+  mds_poststat_t post;  /* data-gradient use: BN-backward sums of the NEXT layer in the epilogue */
 } mds_pw_fwd_args;
 int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream);
 
@@ -82,6 +135,7 @@ typedef struct {
   const void* dy; /* [M][N]                                      */
   float* dw;      /* [N][K] fp32                                 */
   mds_pro_t pro;
+  mds_dyp_t dyp;  /* dyp.mode == 1 -> the dy operand is formed on load (channels = N; `dy` ignored) */
 } mds_pw_wgrad_args;
 int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream);
 
@@ -305,22 +359,7 @@ int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream);
 
 /* ---- BatchNorm backward, split in reduce / finalize / apply.  g (grad wrt the BN output z) is
  * derived on the fly from an upstream tensor u:
- *   MDS_G_PLAIN      g = u
- *   MDS_G_SILU       g = u * silu'(z)
- *   MDS_G_SE_SILU    g = (u * gate[grp][c] + dpooled[grp][c]) * silu'(z)
- *   MDS_G_MASK       g = u * mask[grp]                                   (DropPath)           */
-#define MDS_G_PLAIN 0
-#define MDS_G_SILU 1
-#define MDS_G_SE_SILU 2
-#define MDS_G_MASK 3
-typedef struct {
-  int mode;
-  const void* u;        /* [M][C] */
-  const float* gate;    /* [groups][C] */
-  const float* dpooled; /* [groups][C] */
-  const float* mask;    /* [groups]    */
-  long rows_per_group;
-} mds_gsrc_t;
+ *   (mds_gsrc_t, defined with the operand transforms at the top of this header)               */
 
 typedef struct {
   int dtype;
@@ -343,6 +382,7 @@ typedef struct {
   float* dgamma;    /* optional (NULL when the parameter is frozen) */
   float* dbeta;
   float* coef;      /* [3][C] */
+  float* lin;       /* optional [3][C]: A, B, D of mds_dyp_t (dy = A*g + B*y + D)                          */
   int batch_stats;  /* 1: train-mode BN (batch statistics; the mean / xhat terms above).  0: eval-mode BN
                        (running statistics are constants): coef1 = coef2 = 0, i.e. dy = gamma*rstd*g        */
 } mds_bn_bwd_finalize_args;

@@ -14,7 +14,7 @@ import torch
 from backends import be, DT  # noqa: F401
 from det_init import fill_deterministic, FakeEncoder
 from mds import cabi
-from mds.engine import Plan
+from mds.engine import Plan, Grad
 from mds.structure import InvertedResidual3dP
 from oracle import multidim_stacker_ref as orc
 import mds
@@ -103,7 +103,7 @@ class BlockPlan(Plan):
                                          1, B, True, False)
         if self.need_grad:
             self.dout = self.act(M, blk.cout)
-            self.dxin = recs[-1]("b3d", self.dout)
+            self.dxin = recs[-1]("b3d", Grad(self.dout), None).buf
 
 
 def rows3d(x):            # (B, C, T, H, W) -> [B*T*H*W][C]

@@ -94,3 +94,121 @@ def test_pw_wgrad(be, dt, M, K, N, mode):
         a = a.to(tdt).float()
     ref = dy.float().t() @ a
     assert_close(dw, ref, dt, scale=M ** 0.5, msg="dw")
+
+
+def _bn_setup(be, y, gamma, beta, eps=1e-5):
+    """forward statistics of a train-mode BN over raw input y -> the kernels' [4][C] buffer (scale, shift, mean, rstd)"""
+    M, C = y.shape
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, C)
+    st[0, 0] = y.float().sum(0); st[0, 1] = (y.float() ** 2).sum(0)
+    out = torch.empty(4, C, device=be.device)
+    be.call("bn_finalize", cabi.make("mds_bn_finalize_args", C=C, count=M, stats=be.t(st), gamma=be.t(gamma), beta=be.t(beta), eps=eps,
+                                     momentum=0.1, training=1, running_mean=None, running_var=None, num_batches_tracked=None, out=out))
+    return out
+
+
+def _bn_bwd_lin(be, g, y, bn, gamma):
+    """sum g, sum g*xhat (torch) -> mds_bn_bwd_finalize -> lin = {A, B, D}"""
+    M, C = y.shape
+    bnc = bn.cpu()
+    xhat = (y.float() - bnc[2]) * bnc[3]
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, C)
+    st[3, 0] = g.sum(0); st[5, 1] = (g * xhat).sum(0)
+    coef = torch.empty(3, C, device=be.device); lin = torch.empty(3, C, device=be.device)
+    be.call("bn_bwd_finalize", cabi.make("mds_bn_bwd_finalize_args", C=C, count=M, stats=be.t(st), gamma=be.t(gamma), bn=bn, dgamma=None,
+                                         dbeta=None, coef=coef, lin=lin, batch_stats=1))
+    return lin
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,C,N,gmode,res,post", [
+    (300, 48, 64, 0, False, 0),       # PLAIN dy prologue
+    (260, 96, 144, 3, True, 2),       # MASK gradient source + residual + MASK post statistics, two n-tiles
+    (515, 16, 32, 0, True, 3),        # narrow (128x64 tile variant) + SILU post statistics (g stored)
+    (130, 192, 16, 3, False, 1),      # several k-chunks, PLAIN post statistics
+])
+def test_pw_fwd_bn_backward_fusion(be, dt, M, C, N, gmode, res, post):
+    """data-gradient GEMM with BatchNorm backward folded in on both sides: the operand dy = BN'(g) is formed on load
+    from (u, y, lin), and the sums of the NEXT BatchNorm backward are taken over the output tile."""
+    code, tdt = DT[dt]
+    g_ = torch.Generator().manual_seed(M + 13 * C + post)
+    rpg = 37
+    groups = (M + rpg - 1) // rpg
+    grp = torch.arange(M) // rpg
+    u = torch.randn(M, C, generator=g_).to(tdt)
+    y = (1.5 * torch.randn(M, C, generator=g_) + 0.3).to(tdt)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g_); beta = 0.1 * torch.randn(C, generator=g_)
+    mask = (torch.rand(groups, generator=g_) < 0.7).float() / 0.7
+    w = (torch.randn(N, C, generator=g_) / C ** 0.5).to(tdt)
+    r = torch.randn(M, N, generator=g_).to(tdt)
+    # reference BN backward (fp32 autograd on the stored values)
+    yf = y.float().requires_grad_(True)
+    z = F.batch_norm(yf, None, None, gamma, beta, True, 0.1, 1e-5)
+    gsrc_ref = u.float() * (mask[grp, None] if gmode == 3 else 1.0)
+    z.backward(gsrc_ref)
+    dy_ref = yf.grad
+    bn = _bn_setup(be, y, gamma, beta)
+    lin = _bn_bwd_lin(be, gsrc_ref, y, bn, gamma)
+    ud, yd = be.t(u), be.t(y)
+    xdy = cabi.dyp(cabi.gsrc(gmode, ud, None, None, be.t(mask), rpg), yd, bn, lin)
+    out = torch.full((M, N), float("nan")).to(tdt).to(be.device)
+    # next layer's BatchNorm (the one whose backward sums the epilogue takes)
+    ys = (torch.randn(M, N, generator=g_) * 1.2 - 0.2).to(tdt)
+    gamma2 = 1 + 0.2 * torch.randn(N, generator=g_); beta2 = 0.1 * torch.randn(N, generator=g_)
+    mask2 = (torch.rand(groups, generator=g_) < 0.6).float() / 0.6
+    bn2 = _bn_setup(be, ys, gamma2, beta2)
+    st2 = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device)
+    kw = {}
+    if post:
+        kw["post"] = cabi.poststat(post, be.t(ys), bn2, st2, be.t(mask2), rpg)
+    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=C, N=N, x=None, w=be.t(w), y=out, pro=cabi.pro(0),
+                                residual=be.t(r) if res else None, stats=None, xdy=xdy, **kw))
+    be.sync()
+    dyq = dy_ref.to(tdt).float() if dt == "bf16" else dy_ref
+    v = dyq @ w.float().t() + (r.float() if res else 0.0)
+    b2 = bn2.cpu()
+    zs = ys.float() * b2[0] + b2[1]
+    sg = torch.sigmoid(zs)
+    stored = v * (sg * (1 + zs * (1 - sg))) if post == 3 else v
+    assert_close(out, stored, dt, scale=2, msg="out")
+    if post:
+        gq = out.float().cpu() * (mask2[grp, None] if post == 2 else 1.0)      # the sums are defined on what was stored
+        xh = (ys.float() - b2[2]) * b2[3]
+        s = st2.sum(0).cpu()
+        assert_close(s[0], gq.sum(0), "f32", scale=50 * M ** 0.5, msg="post sum g")
+        assert_close(s[1], (gq * xh).sum(0), "f32", scale=50 * M ** 0.5, msg="post sum g*xhat")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,N,mode,gmode", [(500, 32, 64, 0, 0), (333, 48, 144, 2, 3), (700, 112, 32, 4, 3), (90, 16, 16, 0, 0)])
+def test_pw_wgrad_dy_prologue(be, dt, M, K, N, mode, gmode):
+    code, tdt = DT[dt]
+    g_ = torch.Generator().manual_seed(M * 5 + N)
+    rpg = 97
+    groups = (M + rpg - 1) // rpg
+    grp = torch.arange(M) // rpg
+    x = torch.randn(M, K, generator=g_).to(tdt)
+    u = torch.randn(M, N, generator=g_).to(tdt)
+    y = (1.3 * torch.randn(M, N, generator=g_) - 0.4).to(tdt)
+    gamma = 1 + 0.2 * torch.randn(N, generator=g_); beta = 0.1 * torch.randn(N, generator=g_)
+    mask = (torch.rand(groups, generator=g_) < 0.7).float() / 0.7
+    scale, shift, gate = _mk_pro(be, mode, K, groups, g_)
+    yf = y.float().requires_grad_(True)
+    gsrc_ref = u.float() * (mask[grp, None] if gmode == 3 else 1.0)
+    F.batch_norm(yf, None, None, gamma, beta, True, 0.1, 1e-5).backward(gsrc_ref)
+    bn = _bn_setup(be, y, gamma, beta)
+    lin = _bn_bwd_lin(be, gsrc_ref, y, bn, gamma)
+    dw = torch.zeros(N, K, device=be.device)
+    dyp = cabi.dyp(cabi.gsrc(gmode, be.t(u), None, None, be.t(mask), rpg), be.t(y), bn, lin)
+    be.call("pw_wgrad", cabi.make("mds_pw_wgrad_args", dtype=code, M=M, K=K, N=N, x=be.t(x), dy=None, dw=dw,
+                                  pro=cabi.pro(mode, scale, shift, gate, rpg), dyp=dyp))
+    be.sync()
+    a = x.float()
+    if mode == 4:
+        a = a * gate.cpu()[grp]
+    else:
+        a = _apply_pro(a, mode, scale, shift, gate, rpg)
+    dyq = yf.grad
+    if dt == "bf16":
+        a, dyq = a.to(tdt).float(), dyq.to(tdt).float()
+    assert_close(dw, dyq.t() @ a, dt, scale=M ** 0.5, msg="dw")
