@@ -149,6 +149,7 @@ def make(struct_name: str, **kw):
             keep.append(v)
             v = ptr(v)
         if isinstance(v, C.Structure):
+            keep.extend(getattr(v, "_keep", ()))     # a nested struct is copied by value: its tensors must stay alive
             setattr(st, k, v)
         elif isinstance(v, (list, tuple)):
             arr = getattr(st, k)

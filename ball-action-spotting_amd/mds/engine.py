@@ -195,7 +195,7 @@ class Plan:
         self.need_grad = need_grad
         self.enc_grad = enc_grad and need_grad
         self.m = module
-        self.fuse_bn_bwd = os.environ.get("MDS_FUSE_BN_BWD", "1") != "0"   # developer switch: 0 = reduce/apply kernels everywhere
+        self.fuse_bn_bwd = os.environ.get("MDS_FUSE_BN_BWD", "0") == "1"   # developer switch. Measured (round 2): folding BN backward into the register-staged GEMMs costs more than the reduce/apply passes it removes (227 vs 244 windows/s) — off until the GEMM core can absorb it
         self.in_flight = False
         self.generation = 0      # bumped by every grad-enabled forward: a stale autograd node must not run
         self.profile = None      # list -> run() brackets every launch with HIP events

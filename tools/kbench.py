@@ -78,7 +78,8 @@ def bench_pw(which):
         st = torch.zeros(SLOTS, 2, N, device=dev)
         pro = cabi.pro(mode, sc, sh, gate, rpg)
         if which == "pw_fwd":
-            a = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=pro, residual=None, stats=st)
+            a = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=pro, residual=None,
+                          stats=None if os.environ.get("KB_NOSTATS") else st)
             timeit(f"pw_fwd {tag}", lambda: lib.call("pw_fwd", a, stream()), (M * K + M * N + N * K) * 2, 2 * M * K * N)
         else:
             dy = rnd(M, N); dw = torch.zeros(N, K, device=dev)
