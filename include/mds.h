@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 102
+#define MDS_VERSION 103
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
