@@ -356,13 +356,26 @@ __global__ __launch_bounds__(256) void se_bwd_b_kernel(mds_se_fc_bwd_args a) {
   a.dw1[(long)r * C + c] += s1;
   if (r == 0) a.db2[c] += db2;
 }
-extern "C" int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
+static int se_fc_bwd_check(const mds_se_fc_bwd_args* a) {
   MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->C <= 2048 && a->R > 0 && a->R <= SE_RMAX && a->rows_per_group > 0, "se_fc_bwd: bad dims (R <= %d, C <= 2048)", SE_RMAX);
   MDS_REQUIRE(a->scratch && a->dgate && a->gate && a->hidden && a->pooled && a->dpooled, "se_fc_bwd: null pointer");
   MDS_REQUIRE(!(a->bnsums && a->bn_stats) || a->bn_nblk > 0, "se_fc_bwd: bn_nblk");
+  return 0;
+}
+extern "C" int mds_se_fc_bwd_data(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
+  if (int rc = se_fc_bwd_check(a)) return rc;
   SE_DISPATCH_RB(a->R, MDS_LAUNCH(se_bwd_a_kernel<RB>, dim3(a->groups, cdiv(a->C, SE_CCH)), dim3(256), 0, stream, *a));
+  return mds_check_launch("se_fc_bwd_data");
+}
+extern "C" int mds_se_fc_bwd_params(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
+  if (int rc = se_fc_bwd_check(a)) return rc;
+  MDS_REQUIRE(a->dw1 && a->db1 && a->dw2 && a->db2, "se_fc_bwd_params: null gradient pointer");
   MDS_LAUNCH(se_bwd_b_kernel, dim3(cdiv((long)a->R * a->C, 256)), dim3(256), 0, stream, *a);
-  return mds_check_launch("se_fc_bwd");
+  return mds_check_launch("se_fc_bwd_params");
+}
+extern "C" int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
+  if (int rc = mds_se_fc_bwd_data(a, stream)) return rc;
+  return mds_se_fc_bwd_params(a, stream);
 }
 
 // ------------------------------------------------------------------ head (dropout mask + Linear)

@@ -102,7 +102,7 @@ class Lib:
             f.restype = C.c_int
             self.fn[name[4:]] = f
         for op in list(self.fn):
-            st = STRUCTS.get(f"mds_{op}_args")
+            st = STRUCTS.get(f"mds_{op}_args") or STRUCTS.get(f"mds_{op.rsplit('_', 1)[0]}_args")   # se_fc_bwd_data -> mds_se_fc_bwd_args
             if st is not None:
                 self.fn[op].argtypes = [C.POINTER(st), C.c_void_p]
         if "se_bwd_reduce_blocks" in self.fn:

@@ -415,10 +415,12 @@ class Plan:
             else:
                 sg = [self.grad(se.conv_reduce.weight), self.grad(se.conv_reduce.bias), self.grad(se.conv_expand.weight),
                       self.grad(se.conv_expand.bias)]
-            self.op(seg, "se_fc_bwd", groups=groups, C=mid, R=R, rows_per_group=rpg, dgate=dgate, gate=gate, hidden=hidden,
-                    pooled=pooled, w1=P(se.conv_reduce.weight), w2=P(se.conv_expand.weight), dpooled=dpool,
-                    scratch=self.f32(groups * R), dw1=sg[0], db1=sg[1], dw2=sg[2], db2=sg[3],
-                    bnsums=bnsums, bn_nblk=nblk, bn_stats=bn2.bstats, w2t=w2t)
+            sekw = dict(groups=groups, C=mid, R=R, rows_per_group=rpg, dgate=dgate, gate=gate, hidden=hidden,
+                        pooled=pooled, w1=P(se.conv_reduce.weight), w2=P(se.conv_expand.weight), dpooled=dpool,
+                        scratch=self.f32(groups * R), dw1=sg[0], db1=sg[1], dw2=sg[2], db2=sg[3],
+                        bnsums=bnsums, bn_nblk=nblk, bn_stats=bn2.bstats, w2t=w2t)
+            self.op(seg, "se_fc_bwd_data", _struct="mds_se_fc_bwd_args", **sekw)
+            self.op(seg, "se_fc_bwd_params", _struct="mds_se_fc_bwd_args", **sekw)     # parameter gradients: second stream
             dy2 = self.act(Mout, mid)
             bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, reduce=False, frozen=frozen)
             g1 = self.act(Min, mid)
@@ -639,7 +641,7 @@ class Plan:
             out = []
             for name, kw in ops:
                 self._input_fields = []
-                st = self._bind(f"mds_{name}_args", kw)
+                st = self._bind(kw.get("_struct", f"mds_{name}_args"), kw)
                 for _, field in self._input_fields:
                     self.input_slots.append((st, field))
                 out.append((name, self.lib.fn[name], st, C.byref(st)))
@@ -673,7 +675,7 @@ class Plan:
         caller's current device is"""
         return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
 
-    SIDE_OPS = ("pw_wgrad", "conv_wgrad", "stem_wgrad")
+    SIDE_OPS = ("pw_wgrad", "conv_wgrad", "stem_wgrad", "se_fc_bwd_params")
 
     def run(self, seg):
         if self.profile is not None:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 103
+#define MDS_VERSION 104
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -356,6 +356,11 @@ typedef struct {
   const float* w2t;    /* optional [R][C] copy of w2, see mds_se_fc_fwd_args                       */
 } mds_se_fc_bwd_args;
 int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream);
+/* the same in two halves, for callers that overlap them: `_data` produces dpooled / the BatchNorm sums (on the
+ * critical path of the backward pass), `_params` the four parameter gradients from what `_data` left in
+ * `scratch` (a leaf of the dependency graph: the planner issues it on its second stream).            */
+int mds_se_fc_bwd_data(const mds_se_fc_bwd_args* a, mds_stream_t stream);
+int mds_se_fc_bwd_params(const mds_se_fc_bwd_args* a, mds_stream_t stream);
 
 /* ---- BatchNorm backward, split in reduce / finalize / apply.  g (grad wrt the BN output z) is
  * derived on the fly from an upstream tensor u:
