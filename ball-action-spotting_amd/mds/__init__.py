@@ -1,3 +1,4 @@
 """mds — MI355X-native MultiDimStacker hot path (drop-in for src/models/multidim_stacker.py)."""
 from .module import MultiDimStacker  # noqa: F401
 from .cabi import MdsError, load  # noqa: F401
+from . import train  # noqa: F401  (FocalLoss / FusedAdamW / ModelEma: SURVEY 8(f) N2)

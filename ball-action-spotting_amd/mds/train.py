@@ -1,0 +1,254 @@
+"""SURVEY §8(f) N2 — what surrounds the hot path in the reference's train step, each as ONE HIP launch.
+
+Drop-ins for the reference's classes (same constructor arguments and call signatures):
+
+  FocalLoss   <- src/losses.py:53-66      (registered as "focal_loss" in src/argus_models.py:22-25)
+  FusedAdamW  <- torch.optim.AdamW        (argus builds it from ("AdamW", {...}), configs/ball_action/*.py:51)
+  ModelEma    <- src/ema.py:13-55         (created in scripts/ball_action/train.py:80-82, updated every step,
+                                           src/argus_models.py:65-66)
+
+torch runs these as ~15 (loss fwd+bwd) + 9 (fused AdamW) + ~1500 (ModelEma: three ops per state_dict entry)
+launches per step; here: 2 + 1 + ~7.  As everywhere in this package there is no CPU fallback: CPU tensors raise
+unless the test-suite's kernel simulator has been injected (`mds.train.LIB = ...`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from copy import deepcopy
+
+import torch
+from torch import nn
+
+from . import cabi
+
+LIB = None            # tests inject the kernel simulator here; product: cabi.load()
+REDUCTIONS = {"none": cabi.MDS_REDUCE_NONE, "mean": cabi.MDS_REDUCE_MEAN, "sum": cabi.MDS_REDUCE_SUM}
+CHUNK = cabi.MDS_OPT_CHUNK
+
+
+def _lib(t: torch.Tensor):
+    if LIB is not None:
+        return LIB
+    if not t.is_cuda:
+        raise cabi.MdsError("mds.train runs on MI355X only: move the tensors to cuda")
+    return cabi.load()
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+# ------------------------------------------------------------------------------------------------ focal loss
+class _Focal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets, alpha, gamma, reduction):
+        x = inputs.detach().float().contiguous()
+        t = targets.detach().float().contiguous()
+        assert x.shape == t.shape, "focal loss: inputs and targets must have the same shape"
+        n = x.numel()
+        red = REDUCTIONS[reduction]
+        loss = torch.zeros(n if red == cabi.MDS_REDUCE_NONE else 1, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        lib = _lib(x)
+        with torch.cuda.device(x.device) if x.is_cuda else _null():
+            args = cabi.make("mds_focal_args", n=n, x=x, t=t, alpha=float(alpha), gamma=float(gamma), reduction=red, loss=loss, dx=dx)
+            lib.check(lib.fn["focal_fwd_bwd"](C.byref(args), _stream(x)), "focal_fwd_bwd")
+        ctx.save_for_backward(dx)
+        ctx.in_dtype = inputs.dtype
+        return loss.view(x.shape) if red == cabi.MDS_REDUCE_NONE else loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dx,) = ctx.saved_tensors
+        return (dx * gout).to(ctx.in_dtype), None, None, None, None
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def sigmoid_focal_loss(inputs, targets, alpha: float = -1.0, gamma: float = 2.0, reduction: str = "mean"):
+    """src/losses.py:5-50 — value and gradient from one kernel."""
+    return _Focal.apply(inputs, targets, alpha, gamma, reduction)
+
+
+class FocalLoss(nn.Module):
+    def __init__(self, alpha: float = -1.0, gamma: float = 2.0, reduction: str = "mean"):
+        super().__init__()
+        self.alpha, self.gamma, self.reduction = alpha, gamma, reduction
+
+    def forward(self, inputs, targets):
+        return sigmoid_focal_loss(inputs, targets, alpha=self.alpha, gamma=self.gamma, reduction=self.reduction)
+
+
+# ------------------------------------------------------------------------------------------------ tables
+def _chunk_table(numels, device):
+    """[(tensor index, chunk index)] for every MDS_OPT_CHUNK-sized piece of every tensor, as a device int32 array"""
+    rows = []
+    for i, n in enumerate(numels):
+        rows.extend((i, c) for c in range((n + CHUNK - 1) // CHUNK))
+    return torch.tensor(rows, dtype=torch.int32).reshape(-1, 2).contiguous().to(device), len(rows)
+
+
+def _tensor_table(entries, device):
+    """entries: (ptr, goff, soff, n) -> device copy of an mds_opt_tensor array"""
+    T = cabi.STRUCTS["mds_opt_tensor"]
+    arr = (T * len(entries))()
+    for k, (p, goff, soff, n) in enumerate(entries):
+        arr[k].p, arr[k].goff, arr[k].soff, arr[k].n = p, goff, soff, n
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+# ------------------------------------------------------------------------------------------------ AdamW
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW (decoupled weight decay, bias correction; no amsgrad / maximize) as one launch per param group.
+
+    The moments live in two flat fp32 buffers per group (exposed through `state[p]['exp_avg' | 'exp_avg_sq']` as
+    views, so `state_dict()` has torch's layout); gradients are addressed relative to one base pointer when they are
+    views of one buffer — which is how mds.MultiDimStacker hands them over — so the device table is built once."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, *, maximize=False):
+        if amsgrad or maximize:
+            raise NotImplementedError("mds FusedAdamW: amsgrad / maximize are not implemented (no reference config uses them)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._g = {}          # group index -> dict(exp_avg, exp_avg_sq, soff, step, cache)
+
+    def _group_state(self, gi, group):
+        gs = self._g.get(gi)
+        if gs is None:
+            ps = [p for p in group["params"]]
+            dev = ps[0].device
+            assert all(p.dtype == torch.float32 and p.device == dev and p.is_contiguous() for p in ps), \
+                "mds FusedAdamW: fp32 contiguous parameters on one device"
+            soff, off = {}, 0
+            for p in ps:
+                soff[id(p)] = off
+                off += (p.numel() + 3) // 4 * 4          # keep every tensor's moments 16-byte aligned
+            gs = dict(exp_avg=torch.zeros(off, device=dev), exp_avg_sq=torch.zeros(off, device=dev), soff=soff, step=0, cache=None)
+            for p in ps:
+                o = soff[id(p)]
+                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": gs["exp_avg"][o:o + p.numel()].view_as(p),
+                                 "exp_avg_sq": gs["exp_avg_sq"][o:o + p.numel()].view_as(p)}
+            self._g[gi] = gs
+        return gs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            active = [p for p in group["params"] if p.grad is not None]
+            if not active:
+                continue
+            gs = self._group_state(gi, group)
+            dev = active[0].device
+            grads = [p.grad for p in active]
+            assert all(g.dtype == torch.float32 and g.is_contiguous() for g in grads), "mds FusedAdamW: fp32 contiguous gradients"
+            base = grads[0].untyped_storage().data_ptr()
+            shared = all(g.untyped_storage().data_ptr() == base for g in grads)
+            if not shared:
+                base = 0
+            sig = (shared, tuple(id(p) for p in active), tuple(g.data_ptr() - base for g in grads))
+            cache = gs["cache"]
+            if cache is None or cache["sig"] != sig:
+                entries = [(p.data_ptr(), (g.data_ptr() - base) // 4, gs["soff"][id(p)], p.numel()) for p, g in zip(active, grads)]
+                chunks, nchunks = _chunk_table([p.numel() for p in active], dev)
+                cache = gs["cache"] = dict(sig=sig, table=_tensor_table(entries, dev), chunks=chunks, nchunks=nchunks)
+            gs["step"] += 1
+            t = gs["step"]
+            b1, b2 = group["betas"]
+            lib = _lib(active[0])
+            args = cabi.make("mds_adamw_args", table=cache["table"], chunks=cache["chunks"], nchunks=cache["nchunks"], gbase=base,
+                             exp_avg=gs["exp_avg"], exp_avg_sq=gs["exp_avg_sq"], lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
+                             eps=float(group["eps"]), weight_decay=float(group["weight_decay"]), bias1=1.0 - b1 ** t,
+                             bias2=1.0 - b2 ** t, found_inf=None)
+            with torch.cuda.device(dev) if dev.type == "cuda" else _null():
+                lib.check(lib.fn["multi_adamw"](C.byref(args), _stream(active[0])), "multi_adamw")
+            cache["keep"] = grads            # the launch is asynchronous: the gradient buffer must outlive it
+        return loss
+
+    def state_dict(self):
+        for gi, group in enumerate(self.param_groups):
+            gs = self._g.get(gi)
+            if gs is not None:
+                for p in group["params"]:
+                    self.state[p]["step"] = torch.tensor(float(gs["step"]))
+        return super().state_dict()
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        for gi, group in enumerate(self.param_groups):
+            loaded = {id(p): self.state.get(p) for p in group["params"]}
+            self._g.pop(gi, None)
+            saved = {k: v for k, v in loaded.items() if v}
+            for p in group["params"]:
+                self.state.pop(p, None)
+            gs = self._group_state(gi, group)
+            for p in group["params"]:
+                st = saved.get(id(p))
+                if st:
+                    self.state[p]["exp_avg"].copy_(st["exp_avg"])
+                    self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
+                    gs["step"] = int(float(st["step"]))
+
+
+# ------------------------------------------------------------------------------------------------ EMA
+class ModelEma(nn.Module):
+    """src/ema.py:13-55: a moving average of everything in the model's state_dict, iterated in order.
+    Same-device float entries are updated by one multi-tensor launch; the integer entries (BatchNorm's
+    num_batches_tracked) follow the reference's arithmetic (float blend, truncating cast) in a few batched ops."""
+
+    def __init__(self, model, decay=0.9999, device=None):
+        super().__init__()
+        self.ema = deepcopy(model)
+        self.ema.eval()
+        self.decay = decay
+        self.device = device
+        if self.device is not None:
+            self.ema.to(device=device)
+        self._cache = None
+
+    def _update(self, model, update_fn):
+        with torch.no_grad():
+            for ema_v, model_v in zip(self.ema.state_dict().values(), model.state_dict().values()):
+                if self.device is not None:
+                    model_v = model_v.to(device=self.device)
+                ema_v.copy_(update_fn(ema_v, model_v))
+
+    @torch.no_grad()
+    def update(self, model):
+        evs, mvs = list(self.ema.state_dict().values()), list(model.state_dict().values())
+        fused_ok = self.device is None and all(e.device == m.device for e, m in zip(evs, mvs)) and (evs[0].is_cuda or LIB is not None)
+        if not fused_ok:      # EMA kept on another device (src/ema.py `device='cpu'`): the reference's own loop
+            return self._update(model, update_fn=lambda e, m: self.decay * e + (1. - self.decay) * m)
+        fl = [(e, m) for e, m in zip(evs, mvs) if e.dtype == torch.float32 and m.dtype == torch.float32 and e.is_contiguous() and m.is_contiguous()]
+        rest = [(e, m) for e, m in zip(evs, mvs) if not (e.dtype == torch.float32 and m.dtype == torch.float32 and e.is_contiguous() and m.is_contiguous())]
+        dev = evs[0].device
+        sig = tuple((e.data_ptr(), m.data_ptr()) for e, m in fl)
+        if self._cache is None or self._cache["sig"] != sig:
+            entries = [(e.data_ptr(), m.data_ptr() // 4, 0, e.numel()) for e, m in fl]     # absolute source addresses (gbase = NULL)
+            chunks, nchunks = _chunk_table([e.numel() for e, _ in fl], dev)
+            self._cache = dict(sig=sig, table=_tensor_table(entries, dev), chunks=chunks, nchunks=nchunks)
+        c = self._cache
+        lib = _lib(evs[0])
+        args = cabi.make("mds_ema_args", table=c["table"], chunks=c["chunks"], nchunks=c["nchunks"], gbase=None, decay=float(self.decay))
+        with torch.cuda.device(dev) if dev.type == "cuda" else _null():
+            lib.check(lib.fn["multi_ema"](C.byref(args), _stream(evs[0])), "multi_ema")
+        ints = [(e, m) for e, m in rest if e.numel() == 1 and not e.is_floating_point()]
+        if ints:
+            es = torch.stack([e.reshape(()) for e, _ in ints]).double()
+            ms = torch.stack([m.reshape(()) for _, m in ints]).double()
+            new = (self.decay * es + (1. - self.decay) * ms).to(ints[0][0].dtype)     # the reference's float blend + truncating copy_
+            torch._foreach_copy_([e.reshape(()) for e, _ in ints], list(new.unbind()))
+        for e, m in rest:
+            if not (e.numel() == 1 and not e.is_floating_point()):
+                e.copy_(self.decay * e + (1. - self.decay) * m)
+
+    def set(self, model):
+        self._update(model, update_fn=lambda e, m: m)

@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child runs that measure roofline.traffic")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--torch-step", action="store_true", help="torch's focal loss + torch.optim.AdamW(fused=True) instead of mds.train")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -246,7 +247,12 @@ def main():
             p.requires_grad_(False)
     if world > 1:
         parallel.data_parallel(model)
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-4, fused=True)
+    from mds import train as mtrain
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    if args.torch_step:
+        opt, loss_fn = torch.optim.AdamW(trainable, lr=3e-4, fused=True), focal_loss
+    else:      # loss value+gradient in one launch, AdamW over all tensors in one launch
+        opt, loss_fn = mtrain.FusedAdamW(trainable, lr=3e-4), mtrain.FocalLoss(alpha=-1.0, gamma=1.2)
     B = args.batch
     x = torch.rand(B, T, args.height, args.width, device=dev, generator=torch.Generator(dev).manual_seed(1234 + rank))
     target = torch.randint(0, 2, (B, 2), device=dev, generator=torch.Generator(dev).manual_seed(4321)).float()
@@ -255,7 +261,7 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp):
-            loss = focal_loss(model(x), target)
+            loss = loss_fn(model(x), target)
         loss.backward()
         opt.step()
         return loss
@@ -326,7 +332,7 @@ def main():
                                       "definition": "SURVEY.md 8(d): max(F/2.5e15, B/8e12) / t_window"}
         if world == 1 and not args.no_pmc:
             extra = ["--config", args.config, "--batch", str(B), "--height", str(args.height), "--width", str(args.width),
-                     "--dtype", args.dtype]
+                     "--dtype", args.dtype] + (["--torch-step"] if args.torch_step else [])
             roofline.update(pmc_for(dom, extra))
 
     cpu = None
@@ -334,7 +340,8 @@ def main():
         cpu = cpu_baseline()
 
     if rank == 0:
-        what = {"train": "fwd + focal loss + bwd + grad all-reduce + AdamW",
+        stepk = "torch focal loss / AdamW(fused)" if args.torch_step else "mds.train fused focal loss / multi-tensor AdamW"
+        what = {"train": f"fwd + focal loss + bwd + grad all-reduce + AdamW ({stepk})",
                 "long004": "frozen 2D encoder fwd (BN in train mode) + tail fwd/bwd + focal loss + grad all-reduce + AdamW"}[args.config]
         name = {"train": "sampling_weights_001", "long004": "ball_finetune_long_004"}[args.config]
         out = {"metric": f"frame-windows/sec (fwd+bwd) at {T}x{args.height}x{args.width}, batch {B}", "value": round(wps, 3),

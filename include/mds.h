@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 104
+#define MDS_VERSION 105
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -464,6 +464,61 @@ typedef struct {
   float* db;            /* [NC]    += */
 } mds_head_bwd_args;
 int mds_head_bwd(const mds_head_bwd_args* a, mds_stream_t stream);
+
+/* ---- what surrounds the hot path in a training step, as single launches.
+ * Sigmoid focal loss forward + backward in one pass (src/losses.py:34-50): per element
+ *   p = sigmoid(x), ce = BCEWithLogits(x, t), p_t = p*t + (1-p)*(1-t), l = [alpha_t] * ce * (1-p_t)^gamma
+ * writes the reduced loss (mean / sum; or the per-element losses for reduction "none") and dl/dx (already
+ * divided by n for "mean"), so autograd's backward is one scale by the incoming gradient.               */
+#define MDS_REDUCE_NONE 0
+#define MDS_REDUCE_MEAN 1
+#define MDS_REDUCE_SUM 2
+typedef struct {
+  long n;
+  const float* x;      /* [n] logits (fp32) */
+  const float* t;      /* [n] targets       */
+  float alpha, gamma;
+  int reduction;
+  float* loss;         /* [1] caller-zeroed accumulator (MEAN / SUM), or [n] (NONE) */
+  float* dx;           /* [n] d loss / d x (for NONE: d l_i / d x_i)                 */
+} mds_focal_args;
+int mds_focal_fwd_bwd(const mds_focal_args* a, mds_stream_t stream);
+
+/* Multi-tensor AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias correction) over a
+ * device-resident table of tensors in ONE launch; src/argus_models.py:62 `scaler.step(self.optimizer)`.
+ * Gradients are addressed as gbase + goff (the engine hands all gradients over as views of one flat
+ * buffer, so the table survives from step to step) and the moments live in two flat buffers.        */
+typedef struct {
+  float* p;            /* parameter                                   */
+  long goff;           /* gradient = (const float*)gbase + goff        */
+  long soff;           /* moments  = exp_avg + soff, exp_avg_sq + soff */
+  long n;
+} mds_opt_tensor;
+typedef struct {
+  const mds_opt_tensor* table;   /* device [ntensors] */
+  const int* chunks;             /* device [nchunks][2]: tensor index, first element / MDS_OPT_CHUNK */
+  int nchunks;
+  const float* gbase;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float lr, beta1, beta2, eps, weight_decay;
+  float bias1, bias2;            /* 1 - beta1^t, 1 - beta2^t for this step */
+  const float* found_inf;        /* optional [1] (GradScaler): the whole update is skipped when != 0 */
+} mds_adamw_args;
+#define MDS_OPT_CHUNK 4096
+int mds_multi_adamw(const mds_adamw_args* a, mds_stream_t stream);
+
+/* Multi-tensor exponential moving average: ema = decay*ema + (1-decay)*model for every float entry of
+ * the state_dict (src/ema.py:47-55); table entries: p = ema tensor, goff = offset of the model tensor
+ * from `gbase` in ELEMENTS (gbase may be NULL with goff = absolute address / 4).                      */
+typedef struct {
+  const mds_opt_tensor* table;
+  const int* chunks;
+  int nchunks;
+  const float* gbase;
+  float decay;
+} mds_ema_args;
+int mds_multi_ema(const mds_ema_args* a, mds_stream_t stream);
 
 /* ---- parameter packing: fp32 PyTorch parameters -> the layouts/dtypes the kernels read.
  * One launch handles a device-resident table of jobs.                                          */
