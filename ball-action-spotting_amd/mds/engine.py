@@ -292,12 +292,23 @@ class Plan:
         if self.need_grad:
             chain = [(rec, bseg) for name, bseg in (("head", "bhead"), ("3d", "b3d"), ("2d", "b2d")) for rec in reversed(self._recs[name])]
             gout = None
+            # Gradient buckets for data parallelism: closures run in reverse parameter order, so once closure i
+            # has been issued every parameter at or above min(lo of closures 0..i) is final; a cut after ~1.5 M elements
+            # lets the all-reduce of that slice of the flat arena start while the rest of the backward still runs.
+            self.cuts = {}           # (segment, number of ops issued) -> (lo, hi) slice of the gradient arena
+            hi, lo, executed = self.grad_arena.numel, self.grad_arena.numel, []
             for i, (rec, bseg) in enumerate(chain):
                 nxt = chain[i + 1][0] if i + 1 < len(chain) else None
                 # `head` of the next closure: the BatchNorm whose backward consumes this closure's output directly
                 gout = rec(bseg, gout, getattr(nxt, "head", None) if self.fuse_bn_bwd else None)
+                last = gout is None or nxt is None
+                lo = min(lo, getattr(rec, "lo", lo))
+                if len(self.segs[bseg]) and (hi - lo >= self.BUCKET_ELEMS or last) and hi > lo:
+                    self.cuts[(bseg, len(self.segs[bseg]))] = (lo, hi)
+                    hi = lo
                 if gout is None:
                     break
+            self.grad_lo = hi        # parameters below this offset receive no gradient in this plan (frozen encoder)
             self.dfeat = gout.buf if (self.kind == "tail" and gout is not None) else None   # gradient wrt the (b,S,h,w,192) features
 
     # -- helpers emitting a conv + its BN finalize
@@ -436,6 +447,7 @@ class Plan:
                                 residual=dout.buf if has_skip else None, frozen=frozen, head=nxt_head)
 
         bwd.head = bn3.head(y3, POST_MASK if mask is not None else POST_PLAIN, mask, rpg)
+        bwd.lo = self._lo(blk)
         recs.append(bwd)
         return xout, OH, OW
 
@@ -461,6 +473,7 @@ class Plan:
                     x=self.x_in, dy=dy0, dw=self.grad(enc.conv_stem.weight))
             return None
 
+        stem_bwd.lo = self._lo(enc.conv_stem, enc.bn1)
         recs.append(stem_bwd)
         cur, cur_bn, ch, cw = y0, bn0, OH, OW      # cur_bn != None: `cur` is a raw tensor read through BN+SiLU
         for blk in enc.block_list():
@@ -492,6 +505,7 @@ class Plan:
             return self._pw_bwd(seg, xenc, None, M, cenc, cf, m.conv2d_projection[0].weight, dyp, need_dx=not fr, head=nxt_head)
 
         proj_bwd.head = bnp.head(yp, POST_SILU)
+        proj_bwd.lo = self._lo(m.conv2d_projection)
         recs.append(proj_bwd)
         return feat, ch, cw
 
@@ -508,6 +522,7 @@ class Plan:
             self._conv_wgrad(seg, xin, xin_bn.pro(), N, IH, IW, blk.cin, OH, OW, blk.cout, blk.stride, pads, dy_, blk.conv.weight)
             return Grad(self._conv_dgrad(seg, dy_, N, IH, IW, blk.cin, blk.cout, blk.stride, blk.conv.weight, pads, None))
 
+        bwd.lo = self._lo(blk)
         recs.append(bwd)
         return y, bn1, OH, OW
 
@@ -555,6 +570,7 @@ class Plan:
                                          dout.buf if has_skip else None))
 
         bwd.head = bn2.head(yb, POST_MASK if mask is not None else POST_PLAIN, mask, rpg)
+        bwd.lo = self._lo(blk)
         recs.append(bwd)
         return xout, OH, OW
 
@@ -577,6 +593,7 @@ class Plan:
             bnq.backward(self, seg, gsrc(G_SILU, uq.buf), yq, dyq)
             return self._pw_bwd(seg, x3, None, M, cf, cq, m.conv3d_projection[0].weight, dyq, True, head=nxt_head)
 
+        bwd.lo = self._lo(m.conv3d_projection)
         recs.append(bwd)
         return yq, bnq
 
@@ -606,6 +623,7 @@ class Plan:
                     eps=float(gp.eps), pooled=pooled, dpooled=dpo, u=uq, dp=self.grad(gp.p), accum=self.zero_bwd(B * S * cq))
             return Grad(uq)
 
+        bwd.lo = self._lo(gp, m.classifier)
         self._recs["head"].append(bwd)
 
     # ------------------------------------------------------------------ binding
@@ -676,17 +694,30 @@ class Plan:
         return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
 
     SIDE_OPS = ("pw_wgrad", "conv_wgrad", "stem_wgrad", "se_fc_bwd_params")
+    BUCKET_ELEMS = 1_500_000
+
+    def _lo(self, *mods_or_params):
+        """lowest gradient-arena offset among the given parameters / modules' parameters"""
+        ps = []
+        for m in mods_or_params:
+            ps.extend(m.parameters() if isinstance(m, torch.nn.Module) else [m])
+        return min(self.poff[id(p)] for p in ps)
+
+    cut_hook = None     # data parallelism: called as cut_hook(plan, lo, hi) when arena[lo:hi] is final (all its launches issued)
 
     def run(self, seg):
         if self.profile is not None:
             return self._run_profiled(seg)
         stream = self._stream()
         side = self._side_stream() if seg[0] == "b" else None
+        hook = self.cut_hook if seg[0] == "b" else None
         if side is None:
-            for name, fn, st, ref in self.bound[seg]:
+            for k, (name, fn, st, ref) in enumerate(self.bound[seg]):
                 rc = fn(ref, stream)
                 if rc:
                     self.lib.check(rc, name)
+                if hook is not None and (seg, k + 1) in self.cuts:
+                    hook(self, *self.cuts[(seg, k + 1)])
             return
         # Backward: the weight-gradient GEMMs are leaves of the dependency graph (they only add
         # into the gradient arena), so they go to a second HIP stream and fill the CUs that the
@@ -694,7 +725,7 @@ class Plan:
         main = torch.cuda.current_stream(self.device)
         side_h = side.cuda_stream
         evs, n = self._side_events, 0
-        for name, fn, st, ref in self.bound[seg]:
+        for k, (name, fn, st, ref) in enumerate(self.bound[seg]):
             if name in self.SIDE_OPS:
                 if n == len(evs):
                     evs.append(torch.cuda.Event())
@@ -706,6 +737,8 @@ class Plan:
                 rc = fn(ref, stream)
             if rc:
                 self.lib.check(rc, name)
+            if hook is not None and (seg, k + 1) in self.cuts:
+                hook(self, *self.cuts[(seg, k + 1)])
 
     def join_backward(self):
         """the gradient arena is complete once the side stream has drained"""

@@ -93,16 +93,23 @@ class _MDSFunction(torch.autograd.Function):
                                "plan was reused by a later forward); a second backward / retain_graph is not supported")
         (x,) = ctx.saved_tensors            # raises if x was modified in place since forward
         ctx.consumed = True
+        sync = getattr(ctx.module, "_grad_sync", None)
+        bucketed = hasattr(sync, "on_cut")
         with plan.device_guard():
             plan.bind_input(x)
             plan.bind_dlogits(dlogits)
             plan.begin_backward()
+            plan.cut_hook = sync.on_cut if bucketed else None     # data parallel: all-reduce each slice as soon as it is final
             plan.run("bhead"); plan.run("b3d"); plan.run("b2d")
+            plan.cut_hook = None
             plan.join_backward()
-            flat = plan.grad_arena.tensor.clone()      # one launch; the arena is reused next step
-            sync = getattr(ctx.module, "_grad_sync", None)
-            if sync is not None:
-                sync(flat)                             # data parallel: RCCL all-reduce of the flat buffer
+            if bucketed:
+                world = sync.finish(plan)
+                flat = plan.grad_arena.tensor / world if world > 1 else plan.grad_arena.tensor.clone()
+            else:
+                flat = plan.grad_arena.tensor.clone()  # one launch; the arena is reused next step
+                if sync is not None:
+                    sync(flat)                         # data parallel: one RCCL all-reduce of the flat buffer
         grads = []
         for p in plan.params:
             if p.requires_grad:

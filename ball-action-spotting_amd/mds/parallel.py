@@ -7,7 +7,8 @@ parameter gradients.  The engine hands over ONE flat fp32 gradient buffer (6.77 
 27.1 MB) at the end of backward, so the exchange is a single RCCL all-reduce over xGMI — the
 largest message a ring can get here, which is what a per-link-bound (7 x ~153 GB/s, no switch)
 fabric wants — issued on the compute stream's tail (a 27 MB ring all-reduce is ~0.3 ms vs a
-multi-ms step).  No collective touches the data path.
+multi-ms step).  No collective touches the data path.  `BucketedSync` (the default) splits that buffer into a few
+slices in backward order and overlaps their all-reduces with the rest of the backward pass.
 """
 from __future__ import annotations
 
@@ -44,12 +45,64 @@ def broadcast_state(module: torch.nn.Module, src: int = 0, group=None):
             dist.broadcast(t, src=src, group=group)
 
 
-def data_parallel(module, group=None, broadcast: bool = True, force_collective: bool = False):
+class BucketedSync:
+    """Gradient averaging overlapped with the backward pass.
+
+    The engine reports, while it is still issuing launches, that a slice arena[lo:hi] of the flat gradient buffer is
+    final (every kernel that writes it has been enqueued — on the main stream or on the weight-gradient stream): the
+    slice is all-reduced in place from a communication stream that waits for exactly those two points, in the order
+    head -> 3D tail -> stage 5 ... stem.  Slices are >= 1.5 M elements (6 MB): xGMI is point-to-point, a ring
+    all-reduce is bound per link, so few large messages beat many small ones.  `finish` makes the compute stream
+    wait for the collectives before the gradients are handed to autograd."""
+
+    def __init__(self, group=None, force: bool = False):
+        self.group, self.force = group, force
+        self.handles, self.comm, self.events = [], None, []
+
+    def active(self):
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
+
+    def on_cut(self, plan, lo, hi):
+        if not self.active():
+            return
+        buf = plan.grad_arena.tensor[lo:hi]
+        if buf.is_cuda:
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(device=buf.device)
+            main = torch.cuda.current_stream(buf.device)
+            for s_ in (main, getattr(plan, "_side", None)):
+                if s_ is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(s_)
+                    self.comm.wait_event(ev)
+                    self.events.append(ev)
+            with torch.cuda.stream(self.comm):
+                self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi))
+        else:
+            self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi))
+
+    def finish(self, plan):
+        """-> world size the sums have to be divided by (1 when nothing was exchanged)"""
+        if not self.handles:
+            return 1
+        for h, _, _ in self.handles:
+            h.wait()
+        if self.comm is not None:
+            torch.cuda.current_stream(plan.device).wait_stream(self.comm)
+        self.buckets = [(lo, hi) for _, lo, hi in self.handles]     # kept for inspection by tests
+        self.handles, self.events = [], []
+        return dist.get_world_size(self.group)
+
+    def __call__(self, flat):      # the unbucketed interface (one all-reduce of the finished buffer)
+        return allreduce_mean_(flat, self.group, self.force)
+
+
+def data_parallel(module, group=None, broadcast: bool = True, force_collective: bool = False, bucketed: bool = True):
     """Turn on gradient averaging across ranks for an mds.MultiDimStacker (returns the module).
 
     Kept as an attribute hook instead of a wrapper class so that ``argus``' attribute access
     (``nn_module.conv2d_encoder`` in src/argus_models.py:108) keeps working."""
     if broadcast:
         broadcast_state(module, 0, group)
-    module._grad_sync = lambda flat: allreduce_mean_(flat, group, force_collective)
+    module._grad_sync = BucketedSync(group, force_collective) if bucketed else (lambda flat: allreduce_mean_(flat, group, force_collective))
     return module

@@ -61,6 +61,11 @@ def _worker(rank, world, port, tmp):
     got = torch.cat([p.grad.flatten() for p in prod.parameters()])
     err = (got - want).abs().max().item() / want.abs().max().item()
     assert err < 1e-3, err
+    # the exchange ran as several slices of the flat arena, in backward order (head first, stem last), covering it once
+    buckets = prod._grad_sync.buckets
+    total = sum(p.numel() for p in prod.parameters())
+    assert len(buckets) >= 3 and buckets[0][1] == total and buckets[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(buckets, buckets[1:])) and all(hi - lo >= 1_000_000 for lo, hi in buckets[:-1])
     torch.save(got, os.path.join(tmp, f"g{rank}.pt"))
     dist.barrier()
     if rank == 0:                                            # every rank holds the same averaged gradient
@@ -69,17 +74,18 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_gloo_world2_gradients_match_mean_of_oracle(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_gradients_match_mean_of_oracle(tmp_path, world):
     sys.path_extra = [p for p in sys.path if "repo" in p]
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     procs = []
-    for r in range(2):
-        p = ctx.Process(target=_spawn_entry, args=(r, 2, port, str(tmp_path), sys.path_extra))
+    for r in range(world):
+        p = ctx.Process(target=_spawn_entry, args=(r, world, port, str(tmp_path), sys.path_extra))
         p.start(); procs.append(p)
     for p in procs:
-        p.join(600)
+        p.join(900)
         assert p.exitcode == 0
 
 
