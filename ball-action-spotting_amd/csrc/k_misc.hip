@@ -139,6 +139,24 @@ extern "C" int mds_bn_finalize(const mds_bn_finalize_args* a, mds_stream_t strea
   return mds_check_launch("bn_finalize");
 }
 
+// eval-mode BatchNorm of every layer of a plan in one launch (grid.y = layer)
+__global__ __launch_bounds__(256) void bn_eval_table_kernel(const mds_bn_eval_job* jobs) {
+  const mds_bn_eval_job jb = jobs[blockIdx.y];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < jb.C; c += gridDim.x * blockDim.x) {
+    const float mean = jb.running_mean[c], rstd = 1.0f / sqrtf(jb.running_var[c] + jb.eps);
+    const float sc = jb.gamma[c] * rstd;
+    jb.out[c] = sc;
+    jb.out[jb.C + c] = jb.beta[c] - mean * sc;
+    jb.out[2 * jb.C + c] = mean;
+    jb.out[3 * jb.C + c] = rstd;
+  }
+}
+extern "C" int mds_bn_eval_table(const mds_bn_eval_job* jobs_dev, int njobs, int max_c, mds_stream_t stream) {
+  MDS_REQUIRE(jobs_dev && njobs > 0 && max_c > 0, "bn_eval_table: empty table");
+  MDS_LAUNCH(bn_eval_table_kernel, dim3(cdiv(max_c, 256), njobs), dim3(256), 0, stream, jobs_dev);
+  return mds_check_launch("bn_eval_table");
+}
+
 // ------------------------------------------------------------------ BN finalize (bwd)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mds_bn_bwd_finalize_args a) {
   __shared__ double red[2][8][FIN_CH];

@@ -47,8 +47,16 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(mds_stem_fwd_args a) {
     for (int j = 0; j < 8; ++j) {
       const int iy = oy * 2 + tky[j] - a.pad_t, ix = ox * 2 + tkx[j] - a.pad_l;
       xv[j] = 0.f;
-      if (tp[j] >= 0 && ox < a.OW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-        xv[j] = a.x[(((long)n * 3 + tp[j]) * a.H + iy) * a.W + ix];
+      if (tp[j] >= 0 && ox < a.OW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+        if (a.ingest.u8) {   // raw uint8 frame: pad + /255 (+ mirrored re-read for the TTA copies) while gathering
+          const int ns = n < a.ingest.nsrc ? n : n - a.ingest.nsrc;
+          const int sy = iy - a.ingest.pad_top, sx = (n < a.ingest.nsrc ? ix : a.W - 1 - ix) - a.ingest.pad_left;
+          if (sy >= 0 && sy < a.ingest.src_h && sx >= 0 && sx < a.ingest.src_w)
+            xv[j] = (float)a.ingest.u8[(((long)ns * 3 + tp[j]) * a.ingest.src_h + sy) * a.ingest.src_w + sx] * a.ingest.scale;
+        } else {
+          xv[j] = a.x[(((long)n * 3 + tp[j]) * a.H + iy) * a.W + ix];
+        }
+      }
     }
     frag_from8(xf, xv);
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -82,7 +90,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(mds_stem_fwd_args a) {
 extern "C" int mds_stem_fwd(const mds_stem_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0, "stem_fwd: bad dims");
   MDS_REQUIRE(a->Cout % 16 == 0 && a->Cout <= 32, "stem_fwd: Cout=%d must be 16 or 32", a->Cout);
-  MDS_REQUIRE(a->x && a->w && a->y, "stem_fwd: null pointer");
+  MDS_REQUIRE((a->x || a->ingest.u8) && a->w && a->y, "stem_fwd: null pointer");
+  MDS_REQUIRE(!a->ingest.u8 || (a->ingest.nsrc > 0 && a->ingest.src_h > 0 && a->ingest.src_w > 0 && a->N <= 2 * a->ingest.nsrc),
+              "stem_fwd: ingest needs nsrc, src_h, src_w and N <= 2 * nsrc");
   const long ngroups = (long)a->N * a->OH * ((a->OW + 15) / 16);
   long nb = (ngroups + 3) / 4;
   if (nb > 4096) nb = 4096;

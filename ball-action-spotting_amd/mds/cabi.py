@@ -22,7 +22,7 @@ HEADER = next((h for h in (os.path.join(REPO_ROOT, "include", "mds.h"), os.path.
 HIP_LIB = os.path.join(PKG_ROOT, "csrc", "libmds_hip.so")
 
 _SCALARS = {
-    "int": C.c_int, "long": C.c_long, "float": C.c_float, "long long": C.c_longlong,
+    "int": C.c_int, "long": C.c_long, "float": C.c_float, "long long": C.c_longlong, "unsigned char": C.c_ubyte,
 }
 
 
@@ -109,6 +109,8 @@ class Lib:
             self.fn["se_bwd_reduce_blocks"].argtypes = [C.c_long, C.c_int]
         if "pack_weights" in self.fn:
             self.fn["pack_weights"].argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        if "bn_eval_table" in self.fn:
+            self.fn["bn_eval_table"].argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 
     def check(self, rc: int, op: str):
         if rc != 0:

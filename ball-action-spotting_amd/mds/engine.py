@@ -93,6 +93,9 @@ class BNL:
 
     def finalize(self, pb, seg):
         m = self.mod
+        if not pb.batch_stats:      # eval: running statistics only — every layer of the plan in one table-driven launch
+            pb.eval_bn.append((m, self.C, self.buf))
+            return
         pb.op(seg, "bn_finalize", C=self.C, count=self.count, stats=self.stats, gamma=P(m.weight), beta=P(m.bias),
               eps=float(m.eps), momentum=float(m.momentum if m.momentum is not None else 0.1),
               training=int(pb.batch_stats), running_mean=P(m.running_mean), running_var=P(m.running_var),
@@ -185,8 +188,10 @@ def gsrc(mode, u, gate=None, dpooled=None, mask=None, rpg=0):
 class Plan:
     """The recorded schedules + buffers for one configuration."""
 
-    def __init__(self, module, lib, device, kind, B, T, H, W, code, training, need_grad, enc_grad):
+    def __init__(self, module, lib, device, kind, B, T, H, W, code, training, need_grad, enc_grad, ingest=None):
         self.lib, self.device, self.kind = lib, device, kind
+        self.ingest = ingest        # (src_h, src_w): the 2D encoder reads raw uint8 frames (pad + /255 + TTA flip fused in the stem)
+        self.eval_bn = []           # (module, C, out buffer) of every BatchNorm of an eval-mode plan
         self.code = code
         self.tdt = torch.bfloat16 if code == cabi.MDS_BF16 else torch.float32
         self.training = training
@@ -460,8 +465,15 @@ class Plan:
         y0 = self.act(N * OH * OW, 32)
         bn0 = BNL(self, enc.bn1, 32, N * OH * OW)
         wst = self.pack(enc.conv_stem.weight, cabi.MDS_PACK_STEM, 32, 27, 1)
-        self.op("f2d", "stem_fwd", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl, x=self.x_in,
-                w=wst, y=y0, stats=bn0.stats)
+        extra = {}
+        if self.ingest is not None:      # raw frames: [nsrc][3][src_h][src_w] uint8, images beyond nsrc are the mirrored TTA copies
+            src_h, src_w, nsrc = self.ingest
+            assert not self.need_grad and N in (nsrc, 2 * nsrc) and src_h <= H and src_w <= W
+            self.x_u8 = self._own(nsrc * 3 * src_h * src_w, torch.uint8)
+            extra["ingest"] = dict(_struct="mds_ingest_t", u8=self.x_u8, nsrc=nsrc, src_h=src_h, src_w=src_w,
+                                   pad_top=(H - src_h) // 2, pad_left=(W - src_w) // 2, scale=1.0 / 255.0)
+        self.op("f2d", "stem_fwd", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
+                x=None if self.ingest is not None else self.x_in, w=wst, y=y0, stats=bn0.stats, **extra)
         bn0.finalize(self, "f2d")
 
         def stem_bwd(seg, u0, nxt_head):
@@ -650,6 +662,16 @@ class Plan:
             self.pack_max = max(self.pack_max, dst.numel)
         self.pack_table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         self.param_ptrs = tuple(p.data_ptr() for p, *_ in self.pack_jobs)
+        if self.eval_bn:
+            BJ = cabi.STRUCTS["mds_bn_eval_job"]
+            bj = (BJ * len(self.eval_bn))()
+            for j, (m, C_, out) in enumerate(self.eval_bn):
+                bj[j].gamma, bj[j].beta = m.weight.detach().data_ptr(), m.bias.detach().data_ptr()
+                bj[j].running_mean, bj[j].running_var = m.running_mean.data_ptr(), m.running_var.data_ptr()
+                bj[j].out, bj[j].eps, bj[j].C = out.resolve().data_ptr(), float(m.eps), C_
+            self.eval_bn_table = torch.frombuffer(bytearray(bytes(bj)), dtype=torch.uint8).to(dev)
+            self.eval_bn_maxc = max(C_ for _, C_, _ in self.eval_bn)
+            self.param_ptrs += tuple(t.data_ptr() for m, _, _ in self.eval_bn for t in (m.weight, m.bias, m.running_mean, m.running_var))
         # bind every recorded launch
         self.bound: Dict[str, list] = {}
         self.costs: Dict[str, list] = {}
@@ -790,10 +812,16 @@ class Plan:
                 r = torch.rand(self._mask_total, device=self.device)
                 self.mask_arena.tensor.copy_((r < self.mask_keep).float() / self.mask_keep)
         self.pack_weights()
+        if self.eval_bn:
+            self.lib.check(self.lib.fn["bn_eval_table"](self.eval_bn_table.data_ptr(), len(self.eval_bn), self.eval_bn_maxc,
+                                                        self._stream()), "bn_eval_table")
 
     def begin_backward(self):
         self.zb_arena.tensor.zero_()
         self.grad_arena.tensor.zero_()
 
     def stale(self):
-        return self.param_ptrs != tuple(p.data_ptr() for p, *_ in self.pack_jobs)
+        cur = tuple(p.data_ptr() for p, *_ in self.pack_jobs)
+        if self.eval_bn:
+            cur += tuple(t.data_ptr() for m, _, _ in self.eval_bn for t in (m.weight, m.bias, m.running_mean, m.running_var))
+        return self.param_ptrs != cur

@@ -241,10 +241,10 @@ class MultiDimStacker(nn.Module):
             return cabi.MDS_BF16              # fp16 autocast (the reference's AMP) also maps to bf16 storage
         return cabi.MDS_F32
 
-    def _plan(self, x, kind, B, T, H, W, need_grad):
+    def _plan(self, x, kind, B, T, H, W, need_grad, ingest=None):
         lib = self._library(x)
         enc_grad = any(p.requires_grad for p in self.conv2d_encoder.parameters())
-        key = (kind, B, T, H, W, self._code(), self.training, need_grad, enc_grad, x.device)
+        key = (kind, B, T, H, W, self._code(), self.training, need_grad, enc_grad, x.device, ingest)
         cache = self._cache
         pool = cache.plans.setdefault(key, [])
         cache.plans.move_to_end(key)
@@ -252,7 +252,7 @@ class MultiDimStacker(nn.Module):
             if not plan.in_flight and not plan.stale():
                 return plan
         pool[:] = [p for p in pool if not p.stale()]
-        plan = Plan(self, lib, x.device, kind, B, T, H, W, self._code(), self.training, need_grad, enc_grad)
+        plan = Plan(self, lib, x.device, kind, B, T, H, W, self._code(), self.training, need_grad, enc_grad, ingest=ingest)
         pool.append(plan)
         cache.evict(key)
         return plan

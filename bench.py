@@ -186,6 +186,109 @@ def pmc_for(dom, extra_args):
     return res
 
 
+# ----------------------------------------------------------------------------------------------- config 5: sliding-window inference
+def bench_predict(args, dev, rank, world):
+    """BASELINE.json configs[4] (src/predictors.py:50-75): a stream of raw 720x1280 uint8 frames, one new frame per step
+    through mds.predict.StreamPredictor (fused ingest, device feature store, eval BN table, hipGraph replay); replicas
+    only across GPUs (each rank its own stream, no collective).  value = frames/s without TTA in fp32 (the reference's
+    predictor runs outside autocast); the TTA and bf16 rates and the module-call path of round 1 are reported beside it."""
+    import torch
+    import torch.distributed as dist
+    import mds
+    from mds.predict import StreamPredictor
+    torch.manual_seed(0)
+    model = mds.MultiDimStacker(**dict(CONFIG, drop_rate=0.0, drop_path_rate=0.0)).to(dev)
+    # realistic running statistics: one training-mode pass with momentum 1 (random-init running stats blow eval mode up)
+    for bn in model.modules():
+        if isinstance(bn, torch.nn.modules.batchnorm._BatchNorm):
+            bn.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(torch.rand(1, 15, 736, 1280, device=dev))
+    model.eval()
+    model.clear_plans()
+    pool = torch.randint(0, 256, (64, 720, 1280), dtype=torch.uint8, device=dev, generator=torch.Generator(dev).manual_seed(99 + rank))
+    K, Wm = args.steps, max(args.warmup, 40)          # the first 28 frames only fill the window
+
+    def run(tta, cdt, graphs=True):
+        sp = StreamPredictor(model, frame_size=(1280, 736), tta=tta, compute_dtype=cdt, use_graphs=graphs)
+        idx = 0
+        for _ in range(Wm):
+            sp.predict(pool[idx % 64], idx); idx += 1
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            out, _ = sp.predict(pool[idx % 64], idx); idx += 1
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert out is not None and torch.isfinite(out).all()
+        return el
+
+    def module_path(tta):      # round 1's path: forward_2d / forward_3d / forward_head module calls on padded fp32 frames
+        b = 2 if tta else 1
+        feats = [torch.randn(b, 1, 192, 23, 40, device=dev) for _ in range(5)]
+        frames = torch.rand(b, 3, 736, 1280, device=dev)
+        def one():
+            with torch.no_grad():
+                f = model.forward_2d(frames)
+                feats.pop(0); feats.append(f)
+                return model.forward_head(model.forward_3d(torch.cat(feats, dim=1)))
+        for _ in range(5):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            one()
+        torch.cuda.synchronize()
+        return 50 / (time.perf_counter() - t0)
+
+    el = run(False, None)
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    fps = K * world / el
+    extra = {}
+    if rank == 0 and world == 1:
+        extra = {"fp32_tta_frames_per_s": round(K / run(True, None), 1), "bf16_frames_per_s": round(K / run(False, "bf16"), 1),
+                 "bf16_tta_frames_per_s": round(K / run(True, "bf16"), 1), "fp32_no_graph_frames_per_s": round(K / run(False, None, graphs=False), 1),
+                 "round1_module_call_path_frames_per_s": round(module_path(False), 1)}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import multidim_stacker_ref as orc
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        ref = orc.MultiDimStacker(**dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)).eval()
+        fr = torch.rand(1, 3, 736, 1280); feats = [torch.randn(1, 1, 192, 23, 40) for _ in range(5)]
+        ts = []
+        with torch.no_grad():
+            for _ in range(6):
+                t0 = time.time()
+                f = ref.forward_2d(fr); feats.pop(0); feats.append(f)
+                ref.forward_head(ref.forward_3d(torch.cat(feats, dim=1)))
+                ts.append(time.time() - t0)
+        cpu = {"value": round(1.0 / min(ts[1:]), 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+               "host_logical_cores": os.cpu_count(),
+               "sample": f"oracle fp32, predictor access pattern (one new 3x736x1280 stack + tail on 5 cached stacks), best of 5 frames ({sum(ts):.1f} s)"}
+    if rank == 0:
+        t_frame = el / K
+        out = {"metric": "frames/sec, sliding-window inference (src/predictors.py) on raw 720x1280 frames padded to 736x1280", "value": round(fps, 2),
+               "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(t_frame * 1e3, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "sliding-window predictor: 1 new uint8 frame per step, 15-frame window stride 2, no TTA, fp32; one independent stream per GPU",
+                          "parallelism": f"replicas x{world}"},
+               "roofline": {"bound": "mfma", "frac_whole_path": round(max(35.9e9 / (MFMA_PEAK_TFLOPS * 1e12), 0.12e9 / (HBM_PEAK_GBS * 1e9)) / t_frame, 5),
+                            "definition": "SURVEY.md 8(d) config 5: 35.9 GFLOP, 0.12 GB per frame; launch-latency bound in practice",
+                            "kernel": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None},
+               "cpu_baseline": cpu, **extra}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 # ----------------------------------------------------------------------------------------------- main
 def respawn(args):
     """`python bench.py --gpus N` (N > 1) outside torchrun: launch one rank per GPU ourselves."""
@@ -200,7 +303,7 @@ def respawn(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 300 frames for --config predict)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="train", choices=["train", "long004", "predict"])
     ap.add_argument("--batch", type=int, default=4)
@@ -212,6 +315,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--torch-step", action="store_true", help="torch's focal loss + torch.optim.AdamW(fused=True) instead of mds.train")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 300 if args.config == "predict" else 20
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn(args)
@@ -230,8 +335,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     if args.config == "predict":
-        from tools import predict_bench
-        return predict_bench.bench_line(args, dev, rank, world)
+        return bench_predict(args, dev, rank, world)
 
     import mds
     from mds import parallel

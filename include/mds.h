@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 105
+#define MDS_VERSION 106
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -184,6 +184,16 @@ int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream);
 
 /* ---- stem: 3x3 stride-2 TF-SAME convolution of the fp32 frame triple (Cin = stack_size = 3
  * planes, NCHW as produced by x.view(b*S, 3, h, w), multidim_stacker.py:214) -> channels-last.  */
+/* optional fused ingest (src/frames.py:7-31 + kornia hflip in src/predictors.py:63-64): the frame
+ * triple is read from raw uint8 frames [nsrc][3][src_h][src_w]; constant-0 padding to H x W (pad_top / pad_left as
+ * pad_to_frames computes them), /255 normalisation and — for images n >= nsrc, which re-read image n - nsrc —
+ * the horizontal flip of test-time augmentation all happen in the gather of the im2col fragment.        */
+typedef struct {
+  const unsigned char* u8;  /* NULL: read x (fp32) as before */
+  int nsrc, src_h, src_w;
+  int pad_top, pad_left;
+  float scale;              /* 1/255 */
+} mds_ingest_t;
 typedef struct {
   int dtype;
   int N, H, W, OH, OW, Cout; /* Cout <= 32 */
@@ -192,6 +202,7 @@ typedef struct {
   const void* w;  /* [Cout][32] packed: k = plane*9 + ky*3 + kx, zero padded to 32 */
   void* y;        /* [N][OH][OW][Cout]   */
   float* stats;
+  mds_ingest_t ingest;
 } mds_stem_fwd_args;
 int mds_stem_fwd(const mds_stem_fwd_args* a, mds_stream_t stream);
 
@@ -260,6 +271,20 @@ typedef struct {
   float* out;          /* [4][C] */
 } mds_bn_finalize_args;
 int mds_bn_finalize(const mds_bn_finalize_args* a, mds_stream_t stream);
+
+/* eval-mode BatchNorm for a whole network in ONE launch: a device-resident table of layers, each turned into
+ * out = [4][C] {scale, shift, mean, rstd} from its running statistics (what mds_bn_finalize does per layer with
+ * training == 0; 72 launches per forward otherwise — the sliding-window predictor is launch-bound).          */
+typedef struct {
+  const float* gamma;
+  const float* beta;
+  const float* running_mean;
+  const float* running_var;
+  float* out;
+  float eps;
+  int C;
+} mds_bn_eval_job;
+int mds_bn_eval_table(const mds_bn_eval_job* jobs_dev, int njobs, int max_c, mds_stream_t stream);
 
 /* y_out = act(bn(y)) * mask[row / rows_per_group] + shortcut     (block output materialisation:
  * BN3 + DropPath + residual, multidim_stacker.py:121-133 / timm blocks; or BN+SiLU of a projection) */

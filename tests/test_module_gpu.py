@@ -206,6 +206,13 @@ def test_rccl_world1_gradient_allreduce_path():
         assert calls == [6_770_547]                      # ONE collective over the whole flat gradient arena
         assert relerr(lp, lr) < 1e-3
         assert grad_errors(gp, gr)[0][0] < 1e-3          # mean over a world of one == the local gradient
+        # the default path: slices of the arena all-reduced from the communication stream while backward still runs
+        prod._grad_sync = sync
+        lp2, gp2 = step(prod, x.to(DEV), tgt.to(DEV))
+        torch.cuda.synchronize()
+        assert len(sync.buckets) >= 3 and sync.buckets[0][1] == 6_770_547 and sync.buckets[-1][0] == 0
+        assert relerr(lp2, lp, 1e-6) < 1e-4     # BN running statistics moved between the two steps, logits of the same weights agree
+        assert grad_errors(gp2, gr)[0][0] < 1e-3
         t = torch.ones(4, device=DEV)
         dist.all_reduce(t)
         assert t.sum().item() == 4.0
