@@ -200,7 +200,11 @@ class Plan:
         self.need_grad = need_grad
         self.enc_grad = enc_grad and need_grad
         self.m = module
-        self.fuse_bn_bwd = os.environ.get("MDS_FUSE_BN_BWD", "0") == "1"   # developer switch. Measured (round 2): folding BN backward into the register-staged GEMMs costs more than the reduce/apply passes it removes (227 vs 244 windows/s) — off until the GEMM core can absorb it
+        # 0: reduce / finalize / apply kernels everywhere; 1: BN backward folded into every 1x1 GEMM that touches it;
+        # 2: only the NARROW layers (the projections' BN3 / BN2: dy formed on load from two narrow tensors, sums in the
+        #    epilogue of a GEMM with a narrow output) — the wide ones keep their streaming apply pass.
+        self.fuse_mode = int(os.environ.get("MDS_FUSE_BN_BWD", "0"))
+        self.fuse_bn_bwd = self.fuse_mode >= 1   # developer switch. Measured (round 2): folding BN backward into the register-staged GEMMs costs more than the reduce/apply passes it removes (227 vs 244 windows/s) — off until the GEMM core can absorb it
         self.in_flight = False
         self.generation = 0      # bumped by every grad-enabled forward: a stale autograd node must not run
         self.profile = None      # list -> run() brackets every launch with HIP events
@@ -443,7 +447,7 @@ class Plan:
             self.op(seg, "dw_bwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
                     pad_l=pl, kt=kt, x=y1, dy=dy2, w=wdw, g=g1, dw=self.f32(mid * kt * 9) if frozen else self.grad(blk.conv_dw.weight),
                     pro=bn1.pro(), mean=bn1.mean, rstd=bn1.rstd, stats=bn1.bstats)
-            if fuse:
+            if fuse and self.fuse_mode == 1:
                 dy1 = bn1.backward_fused(self, seg, gsrc(G_PLAIN, g1), y1, reduce=False, frozen=frozen)
             else:
                 dy1 = self.act(Min, mid)
@@ -566,15 +570,18 @@ class Plan:
                 return None
             g2 = gsrc(G_MASK, dout.buf, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout.buf)
             dya = self.act(M, mid)
-            if fuse:
+            if fuse and self.fuse_mode == 1:
                 # BN2 (narrow) backward folded into the projection's weight / data gradient; that data-gradient GEMM
                 # stores g_a = u_a*silu'(z_a) and takes BN1's sums over it, so BN1's apply reads a PLAIN source
                 dyb = bn2.backward_fused(self, seg, g2, yb, reduce=dout.reduced is not bn2)
                 ga = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True, head=bn1.head(ya, POST_SILU))
                 bn1.backward(self, seg, gsrc(G_PLAIN, ga.buf), ya, dya, reduce=False)
             else:
-                dyb = self.act(M, cout)
-                bn2.backward(self, seg, g2, yb, dyb)
+                if fuse:      # mode 2: only the narrow BN2 is folded (sums possibly taken by the producer of dout)
+                    dyb = bn2.backward_fused(self, seg, g2, yb, reduce=dout.reduced is not bn2)
+                else:
+                    dyb = self.act(M, cout)
+                    bn2.backward(self, seg, g2, yb, dyb)
                 ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
                 bn1.backward(self, seg, gsrc(G_SILU, ua.buf), ya, dya)
             self._conv_wgrad(seg, xin, pro_in, N, IH, IW, cin, OH, OW, mid, blk.stride, pads, dya, blk.conv_exp.weight)

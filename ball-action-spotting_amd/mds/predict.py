@@ -66,97 +66,146 @@ class StreamPredictor:
         dev = frame.device
         h, w = frame.shape[-2:]
         assert frame.dtype == torch.uint8 and h <= self.H and w <= self.W, "raw uint8 frames no larger than the padded size"
+        self.frames = torch.zeros(self.nframes, h, w, dtype=torch.uint8, device=dev)
+        self.plans = {}          # chunk size n -> dict(p2d, ptail, graphs, index caches)
+        self.store = None
+        self._built = (h, w, dev)
+
+    def _chunk(self, n: int):
+        """plans / graphs for chunks of n consecutive frames: one 2D-encoder pass over n (x2 with TTA) new stacks,
+        one tail pass over n (x2) windows"""
+        c = self.plans.get(n)
+        if c is not None:
+            return c
+        h, w, dev = self._built
         m, b = self.m, (2 if self.tta else 1)
         saved = m.compute_dtype
         if self.compute_dtype is not None:
             m.compute_dtype = self.compute_dtype
         try:
             with torch.no_grad():
-                self.p2d = m._plan(frame, "2d", b, self.ss, self.H, self.W, False, ingest=(h, w, 1))
-                self.ptail = m._plan(frame, "tail", b, self.S * self.ss, self.p2d.h, self.p2d.w, False)
+                probe = self.frames[0]
+                p2d = m._plan(probe, "2d", n * b, self.ss, self.H, self.W, False, ingest=(h, w, n))
+                ptail = m._plan(probe, "tail", n * b, self.S * self.ss, p2d.h, p2d.w, False)
         finally:
             m.compute_dtype = saved
-        self.p2d.in_flight = self.ptail.in_flight = True     # owned by this predictor: never handed out to another caller
-        fh, fw, cf = self.p2d.h, self.p2d.w, m.num_3d_features
-        self.frames = torch.zeros(self.nframes, h, w, dtype=torch.uint8, device=dev)
-        self.fsize = b * fh * fw * cf
-        self.store = torch.zeros(self.nfeat, self.fsize, dtype=self.p2d.tdt, device=dev)
-        self.tail_feat = self.ptail.feat.tensor.view(b, self.S, fh * fw * cf)
-        self.graph2d = self.graphtail = None
-        self._built = (h, w, dev)
-        self._warm = 0
-        self._sel, self._slots = {}, {}
+        p2d.in_flight = ptail.in_flight = True      # owned by this predictor: never handed out to another caller
+        f = p2d.h * p2d.w * m.num_3d_features
+        if self.store is None:
+            self.f, self.tdt = f, p2d.tdt
+            self.store = torch.zeros(self.nfeat, b, f, dtype=p2d.tdt, device=dev)      # [slot][orig | flipped][h*w*c]
+        c = self.plans[n] = dict(p2d=p2d, ptail=ptail, g2d=None, gtail=None, warm=0, cache={})
+        return c
 
-    def _run2d(self):
-        p = self.p2d
-        p.begin_forward(None)
-        p.run("f2d")
+    def _replay(self, c, which):
+        """eager for the first calls (kernel attribute opt-ins, allocator warm-up), then one hipGraph replay"""
+        plan = c["p2d"] if which == "2d" else c["ptail"]
 
-    def _runtail(self):
-        p = self.ptail
-        p.begin_forward(None)
-        p.run("f3d"); p.run("fhead")
-
-    def _replay(self, which):
-        """eager for the first two calls (kernel attribute opt-ins, allocator warm-up), then one hipGraph replay"""
-        fn = self._run2d if which == "2d" else self._runtail
-        plan = self.p2d if which == "2d" else self.ptail
+        def fn():
+            plan.begin_forward(None)
+            if which == "2d":
+                plan.run("f2d")
+            else:
+                plan.run("f3d"); plan.run("fhead")
+        key = "g2d" if which == "2d" else "gtail"
         if not self.use_graphs or plan.device.type != "cuda":
             return fn()
-        g = self.graph2d if which == "2d" else self.graphtail
-        if g is None:
-            if self._warm < 4:
-                self._warm += 1
+        if c[key] is None:
+            if c["warm"] < 4:
+                c["warm"] += 1
                 return fn()
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(plan.device)
             with torch.cuda.graph(g):
                 fn()
-            if which == "2d":
-                self.graph2d = g
-            else:
-                self.graphtail = g
-        g.replay()
+            c[key] = g
+        c[key].replay()
+
+    def _window_ready(self, index):
+        return all(self.frame_tag[i % self.nframes] == i for i in self.idx.make_stack_indexes(index - self._predict_offset))
+
+    def _idx(self, c, key, rows, dev):
+        t = c["cache"].get(key)
+        if t is None:
+            t = c["cache"][key] = torch.tensor(rows, device=dev)
+        return t
 
     # ------------------------------------------------------------------ the reference's API
     @torch.no_grad()
     def predict(self, frame: torch.Tensor, index: int):
         """frame: (h, w) uint8 (any device; moved to the module's device like src/predictors.py:52)"""
+        out = self.predict_batch(frame[None], index)
+        return out[0]
+
+    @torch.no_grad()
+    def predict_batch(self, frames: torch.Tensor, first_index: int):
+        """n consecutive frames (n, h, w) uint8 with indexes first_index .. first_index + n - 1 -> the n results
+        ``predict`` would return one by one, from ONE pass of the 2D encoder over the n new stacks and ONE pass of the
+        tail over the n windows (offline prediction of a whole half has every frame at hand: src/predictors.py is
+        latency-bound at batch 1-2)."""
         dev = next(self.m.parameters()).device
-        frame = frame.to(device=dev)
-        if self._built is None or self._built != (frame.shape[-2], frame.shape[-1], dev):
-            self._build(frame)
+        frames = frames.to(device=dev)
+        if self._built is None or self._built != (frames.shape[-2], frames.shape[-1], dev):
+            self._build(frames[0])
             self.reset_buffers()
-        with self.p2d.device_guard():
-            slot = index % self.nframes
-            self.frames[slot].copy_(frame)
-            self.frame_tag[slot] = index
-            predict_index = index - self._predict_offset
-            predict_indexes = self.idx.make_stack_indexes(predict_index)
-            if not all(self.frame_tag[i % self.nframes] == i for i in predict_indexes):
-                return None, predict_index
-            b = 2 if self.tta else 1
-            slots = []
-            for s in range(self.S):
-                stack = predict_indexes[s * self.ss:(s + 1) * self.ss]
-                end = stack[-1]
-                fslot = end % self.nfeat
-                if self.feat_tag[fslot] != tuple(stack):      # in steady state only the newest stack
-                    key = stack[0] % self.nframes
-                    sel = self._sel.get(key)
-                    if sel is None:
-                        sel = self._sel[key] = torch.tensor([i % self.nframes for i in stack], device=dev)
-                    torch.index_select(self.frames, 0, sel, out=self.p2d.x_u8.tensor.view(self.ss, *self.frames.shape[1:]))
-                    self._replay("2d")
-                    self.store[fslot].copy_(self.p2d.feat.tensor.view(-1))
-                    self.feat_tag[fslot] = tuple(stack)
-                slots.append(fslot)
-            st = self._slots.get(slots[-1])
-            if st is None:
-                st = self._slots[slots[-1]] = torch.tensor(slots, device=dev)
-            gathered = self.store.index_select(0, st)                                           # [S][b*fh*fw*cf]
-            self.tail_feat.copy_(gathered.view(self.S, b, -1).transpose(0, 1))
-            self._replay("tail")
-            logits = self.ptail.logits.tensor.view(b, -1)
-            prediction = torch.sigmoid(logits).mean(dim=0)       # prediction_transform = nn.Sigmoid, then the TTA mean
-            return prediction, predict_index
+        n = frames.shape[0]
+        with torch.cuda.device(dev) if dev.type == "cuda" else _Null():
+            results, ready = [], []
+            for j in range(n):
+                index = first_index + j
+                slot = index % self.nframes
+                self.frame_tag[slot] = index
+                results.append((None, index - self._predict_offset))
+            # ring update (n <= ring length; the frames of one chunk land in distinct slots)
+            assert n <= self.nframes - 2 * self._predict_offset, "chunk longer than the frame ring allows"
+            self.frames[torch.arange(first_index, first_index + n, device=dev) % self.nframes] = frames
+            for j in range(n):
+                if self._window_ready(first_index + j):
+                    ready.append(j)
+            if not ready:
+                return results
+            if len(ready) != n:           # a chunk that straddles the start of the stream: frame by frame for its ready part
+                if n == 1:
+                    return results
+                for j in ready:
+                    results[j] = self._run_chunk([first_index + j])[0]
+                return results
+            for j, r in enumerate(self._run_chunk([first_index + j for j in range(n)])):
+                results[j] = r
+            return results
+
+    def _run_chunk(self, indexes):
+        n = len(indexes)
+        c = self._chunk(n)
+        p2d, ptail = c["p2d"], c["ptail"]
+        dev, b = p2d.device, (2 if self.tta else 1)
+        wins = [self.idx.make_stack_indexes(i - self._predict_offset) for i in indexes]
+        stacks = [[tuple(w_[s * self.ss:(s + 1) * self.ss]) for s in range(self.S)] for w_ in wins]
+        # stacks whose features are not in the store yet; in steady state exactly the newest stack of every frame
+        missing = [[st for st in sts if self.feat_tag[st[-1] % self.nfeat] != st] for sts in stacks]
+        rounds = max(len(m_) for m_ in missing)
+        for r in range(rounds):           # > 1 only right after a (re)start of the stream
+            todo = [m_[min(len(m_) - 1 - r, len(m_) - 1)] if len(m_) > r else stacks[j][-1] for j, m_ in enumerate(missing)]
+            sel = self._idx(c, ("sel", tuple(st[0] % self.nframes for st in todo)), [i % self.nframes for st in todo for i in st], dev)
+            torch.index_select(self.frames, 0, sel, out=p2d.x_u8.tensor.view(n * self.ss, *self.frames.shape[1:]))
+            self._replay(c, "2d")
+            fslots = [st[-1] % self.nfeat for st in todo]
+            si = self._idx(c, ("fs", tuple(fslots)), fslots, dev)
+            self.store[si] = p2d.feat.tensor.view(b, n, self.f).transpose(0, 1)      # images: n originals, then their n mirrored copies
+            for st, fs in zip(todo, fslots):
+                self.feat_tag[fs] = st
+        slots = [[st[-1] % self.nfeat for st in sts] for sts in stacks]
+        gi = self._idx(c, ("g", tuple(s_[-1] for s_ in slots)), slots, dev)              # [n][S]
+        gathered = self.store[gi]                                                          # [n][S][b][f]
+        ptail.feat.tensor.view(n, b, self.S, self.f).copy_(gathered.permute(0, 2, 1, 3))
+        self._replay(c, "tail")
+        probs = torch.sigmoid(ptail.logits.tensor.view(n, b, -1)).mean(dim=1)              # nn.Sigmoid, then the TTA mean
+        return [(probs[j], indexes[j] - self._predict_offset) for j in range(n)]
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

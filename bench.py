@@ -210,17 +210,29 @@ def bench_predict(args, dev, rank, world):
     pool = torch.randint(0, 256, (64, 720, 1280), dtype=torch.uint8, device=dev, generator=torch.Generator(dev).manual_seed(99 + rank))
     K, Wm = args.steps, max(args.warmup, 40)          # the first 28 frames only fill the window
 
-    def run(tta, cdt, graphs=True):
+    CH = args.chunk
+
+    def run(tta, cdt, graphs=True, chunk=CH):
+        """K frames through the predictor, `chunk` consecutive frames per call (1 = the reference's frame-by-frame API)"""
         sp = StreamPredictor(model, frame_size=(1280, 736), tta=tta, compute_dtype=cdt, use_graphs=graphs)
         idx = 0
-        for _ in range(Wm):
-            sp.predict(pool[idx % 64], idx); idx += 1
+
+        def feed(nfr):
+            nonlocal idx
+            out = None
+            done = 0
+            while done < nfr:
+                c = min(chunk, nfr - done)
+                sel = torch.arange(idx, idx + c, device=dev) % 64
+                out = sp.predict_batch(pool[sel], idx)[-1][0]
+                idx += c; done += c
+            return out
+        feed(max(Wm, 28 + 6 * chunk))
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(K):
-            out, _ = sp.predict(pool[idx % 64], idx); idx += 1
+        out = feed(K)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -255,7 +267,11 @@ def bench_predict(args, dev, rank, world):
     extra = {}
     if rank == 0 and world == 1:
         extra = {"fp32_tta_frames_per_s": round(K / run(True, None), 1), "bf16_frames_per_s": round(K / run(False, "bf16"), 1),
-                 "bf16_tta_frames_per_s": round(K / run(True, "bf16"), 1), "fp32_no_graph_frames_per_s": round(K / run(False, None, graphs=False), 1),
+                 "bf16_tta_frames_per_s": round(K / run(True, "bf16"), 1),
+                 "frame_by_frame_api": {"fp32_frames_per_s": round(K / run(False, None, chunk=1), 1),
+                                        "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1), 1),
+                                        "bf16_frames_per_s": round(K / run(False, "bf16", chunk=1), 1),
+                                        "fp32_no_graph_frames_per_s": round(K / run(False, None, graphs=False, chunk=1), 1)},
                  "round1_module_call_path_frames_per_s": round(module_path(False), 1)}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -278,7 +294,8 @@ def bench_predict(args, dev, rank, world):
         out = {"metric": "frames/sec, sliding-window inference (src/predictors.py) on raw 720x1280 frames padded to 736x1280", "value": round(fps, 2),
                "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(t_frame * 1e3, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "sliding-window predictor: 1 new uint8 frame per step, 15-frame window stride 2, no TTA, fp32; one independent stream per GPU",
+               "config": {"workload": f"sliding-window predictor over a stream of raw uint8 frames, 15-frame window stride 2, no TTA, fp32, {CH} consecutive "
+                                      "frames per call (offline prediction of a half; a step = one frame); one independent stream per GPU",
                           "parallelism": f"replicas x{world}"},
                "roofline": {"bound": "mfma", "frac_whole_path": round(max(35.9e9 / (MFMA_PEAK_TFLOPS * 1e12), 0.12e9 / (HBM_PEAK_GBS * 1e9)) / t_frame, 5),
                             "definition": "SURVEY.md 8(d) config 5: 35.9 GFLOP, 0.12 GB per frame; launch-latency bound in practice",
@@ -313,6 +330,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child runs that measure roofline.traffic")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--chunk", type=int, default=8, help="--config predict: consecutive frames per predictor call")
     ap.add_argument("--torch-step", action="store_true", help="torch's focal loss + torch.optim.AdamW(fused=True) instead of mds.train")
     args = ap.parse_args()
     if args.steps is None:

@@ -52,25 +52,35 @@ def test_stream_predictor_matches_reference_logic(be, tta):
     kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
     ref = fill_deterministic(orc.MultiDimStacker(**kw), 5, scale=0.05)
     g = torch.Generator().manual_seed(1)
-    for bn in ref.modules():                                   # realistic running statistics for eval mode
+    size = (96, 64)                                            # (width, height) like configs' frames_processor
+    # Every frame = one base picture + small noise, and the running statistics come from a window of such frames: eval
+    # mode is then as well conditioned as on real footage.  (With arbitrary running statistics the eval network amplifies
+    # 1-ulp differences of exp/rcp between CPU and GPU to 1e-2 on the probabilities — measured.)
+    base = torch.randint(20, 236, (58, 90), generator=g)
+
+    def new_frame():
+        return (base + torch.randint(-12, 13, (58, 90), generator=g)).clamp(0, 255).to(torch.uint8)
+    for bn in ref.modules():
         if isinstance(bn, torch.nn.modules.batchnorm._BatchNorm):
             bn.momentum = 1.0
     ref.train()
+    rp0 = RefPredictor(ref, size, tta)
     with torch.no_grad():
-        ref(torch.rand(1, 15, 64, 96, generator=g))
+        ref(torch.stack([rp0.process(new_frame()[None, None])[0, 0] for _ in range(15)])[None])
     prod = mds.MultiDimStacker(**kw)
     prod.load_state_dict(ref.state_dict())
     prod = prod.to(be.device)
     if be.name == "emu":
         prod._lib = be.lib
-    size = (96, 64)                                            # (width, height) like configs' frames_processor
     rp = RefPredictor(ref, size, tta)
     sp = StreamPredictor(prod, frame_size=size, tta=tta)
     n = 31 if be.name == "emu" else 48
-    got = 0
+    got, all_frames, refs = 0, [], []
     for index in range(n):
-        frame = torch.randint(0, 256, (58, 90), generator=g, dtype=torch.uint8)      # smaller than the padded size: real padding
+        frame = new_frame()                                   # smaller than the padded size: real padding
+        all_frames.append(frame)
         pr, ir = rp.predict(frame, index)
+        refs.append(pr)
         pp, ip = sp.predict(frame, index)
         assert ir == ip
         assert (pr is None) == (pp is None), index
@@ -80,6 +90,17 @@ def test_stream_predictor_matches_reference_logic(be, tta):
             err = (pp.float().cpu() - pr).abs().max().item()
             assert err < 2e-3, (index, err, pr, pp)
     assert got == n - 28
+    live = torch.stack([r for r in refs if r is not None])
+    assert ((live > 0.01) & (live < 0.99)).any(), "saturated probabilities would make this comparison vacuous"
+    # chunked offline prediction: the same stream three frames at a time (one 2D pass over 3 new stacks, one tail pass
+    # over 3 windows), including the chunk that straddles the first complete window
+    sb = StreamPredictor(prod, frame_size=size, tta=tta)
+    for first in range(0, n - n % 3, 3):
+        outs = sb.predict_batch(torch.stack(all_frames[first:first + 3]), first)
+        for j, (pp, ip) in enumerate(outs):
+            assert ip == first + j - 14 and (pp is None) == (refs[first + j] is None)
+            if pp is not None:
+                assert (pp.float().cpu() - refs[first + j]).abs().max().item() < 2e-3
     # a gap in the stream: the window is incomplete again until 15 fresh frames (stride 2) are there
     sp2 = StreamPredictor(prod, frame_size=size, tta=tta)
     for index in list(range(0, 30)) + [40]:
