@@ -51,8 +51,9 @@ class StreamPredictor:
         self.step = frame_stack_step
         self._predict_offset = self.idx.make_stack_indexes(0)[-1]
         self.span = self.ss * self.step                  # frames between the ends of consecutive stacks of one window
-        self.nframes = 2 * self._predict_offset + 4      # raw-frame ring (>= window length)
-        self.nfeat = self.S * self.span                  # feature store: one slot per stack END index modulo S*span
+        self.max_chunk = 32
+        self.nframes = 2 * self._predict_offset + 1 + self.max_chunk + 3     # raw-frame ring: a window behind every frame of a chunk
+        self.nfeat = (self.S - 1) * self.span + self.max_chunk + 8          # feature store: one slot per stack END index (mod)
         self.use_graphs = use_graphs
         self._built = None
         self.reset_buffers()
@@ -157,7 +158,7 @@ class StreamPredictor:
                 self.frame_tag[slot] = index
                 results.append((None, index - self._predict_offset))
             # ring update (n <= ring length; the frames of one chunk land in distinct slots)
-            assert n <= self.nframes - 2 * self._predict_offset, "chunk longer than the frame ring allows"
+            assert n <= self.max_chunk, "chunk longer than the frame ring allows"
             self.frames[torch.arange(first_index, first_index + n, device=dev) % self.nframes] = frames
             for j in range(n):
                 if self._window_ready(first_index + j):

@@ -126,3 +126,28 @@ def test_stem_fwd_wgrad(be, dt, N, H, W):
     assert_close(s[0], yr.sum((0, 1, 2)), dt, scale=cnt ** 0.5, msg="sum")
     assert_close(s[1], (yr * yr).sum((0, 1, 2)), dt, scale=cnt ** 0.5, msg="sumsq")
     assert_close(dw, wq.grad, dt, scale=cnt ** 0.5, msg="dw")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_stem_fwd_uint8_ingest(be, dt):
+    """raw uint8 frames -> constant pad (src/frames.py:12-31) -> /255 -> kornia hflip for the TTA copies, all
+    inside the stem's gather, against the reference's pipeline followed by the convolution."""
+    code, tdt = DT[dt]
+    g = gen(77)
+    nsrc, sh, sw, H, W = 2, 21, 38, 26, 44                      # padded size larger than the frames in both directions
+    u8 = torch.randint(0, 256, (nsrc, 3, sh, sw), generator=g, dtype=torch.uint8)
+    w = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    hp, wp_ = H - sh, W - sw
+    fr = F.pad(u8, [wp_ // 2, wp_ - wp_ // 2, hp // 2, hp - hp // 2], mode="constant", value=0).to(torch.float32) / 255.0
+    x = torch.cat([fr, torch.flip(fr, dims=[-1])], dim=0)         # images 0..nsrc-1, then their mirrored copies
+    N = 2 * nsrc
+    OH, OW, pt, pl = geo.conv_geometry(H, W, 2)
+    (pt_, pb), (pl_, pr) = geo.same_pad(H, 2), geo.same_pad(W, 2)
+    yref = F.conv2d(F.pad(x.to(tdt).float(), (pl_, pr, pt_, pb)), w.to(tdt).float(), None, 2).permute(0, 2, 3, 1)
+    wp = torch.zeros(32, 32); wp[:, :27] = w.view(32, 27)
+    y = torch.full((N, OH, OW, 32), float("nan")).to(tdt).to(be.device)
+    ing = cabi.make("mds_ingest_t", u8=be.t(u8), nsrc=nsrc, src_h=sh, src_w=sw, pad_top=hp // 2, pad_left=wp_ // 2, scale=1.0 / 255.0)
+    be.call("stem_fwd", cabi.make("mds_stem_fwd_args", dtype=code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
+                                  x=None, w=be.t(wp.to(tdt)), y=y, stats=None, ingest=ing))
+    be.sync()
+    assert_close(y, yref, dt, msg="y")

@@ -49,24 +49,27 @@ class RefPredictor:
 
 @pytest.mark.parametrize("tta", [False, True])
 def test_stream_predictor_matches_reference_logic(be, tta):
+    if be.name == "emu" and tta:
+        pytest.skip("TTA doubles the simulated work: covered on the GPU; the flip itself by test_stem_fwd_uint8_ingest")
     kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
-    ref = fill_deterministic(orc.MultiDimStacker(**kw), 5, scale=0.05)
+    # Conditioning: with the usual deterministic fill (scale 0.05) the eval-mode logits of this random network are ~1e5 and
+    # every probability is exactly 0 or 1 (a vacuous comparison; 1-ulp exp/rcp differences between hosts get amplified to
+    # 1e-2).  Small weights + running statistics taken from 8 windows of the same frame distribution keep it contractive;
+    # the logits then move by ~1e-2 from window to window, so the bar is set RELATIVE TO THAT SPREAD: a wrong frame, stack
+    # order or flip shows up as an error of the size of the spread, fp32 rounding is 1000x below it.
+    ref = fill_deterministic(orc.MultiDimStacker(**kw), 5, scale=0.02)
     g = torch.Generator().manual_seed(1)
     size = (96, 64)                                            # (width, height) like configs' frames_processor
-    # Every frame = one base picture + small noise, and the running statistics come from a window of such frames: eval
-    # mode is then as well conditioned as on real footage.  (With arbitrary running statistics the eval network amplifies
-    # 1-ulp differences of exp/rcp between CPU and GPU to 1e-2 on the probabilities — measured.)
-    base = torch.randint(20, 236, (58, 90), generator=g)
 
     def new_frame():
-        return (base + torch.randint(-12, 13, (58, 90), generator=g)).clamp(0, 255).to(torch.uint8)
+        return torch.randint(0, 256, (58, 90), generator=g).to(torch.uint8)   # smaller than the padded size: real padding
     for bn in ref.modules():
         if isinstance(bn, torch.nn.modules.batchnorm._BatchNorm):
             bn.momentum = 1.0
     ref.train()
     rp0 = RefPredictor(ref, size, tta)
     with torch.no_grad():
-        ref(torch.stack([rp0.process(new_frame()[None, None])[0, 0] for _ in range(15)])[None])
+        ref(torch.stack([torch.stack([rp0.process(new_frame()[None, None])[0, 0] for _ in range(15)]) for _ in range(8)]))
     prod = mds.MultiDimStacker(**kw)
     prod.load_state_dict(ref.state_dict())
     prod = prod.to(be.device)
@@ -74,33 +77,39 @@ def test_stream_predictor_matches_reference_logic(be, tta):
         prod._lib = be.lib
     rp = RefPredictor(ref, size, tta)
     sp = StreamPredictor(prod, frame_size=size, tta=tta)
-    n = 31 if be.name == "emu" else 48
-    got, all_frames, refs = 0, [], []
+    n = 32 if be.name == "emu" else 52
+    all_frames, refs, outs = [], [], []
     for index in range(n):
-        frame = new_frame()                                   # smaller than the padded size: real padding
+        frame = new_frame()
         all_frames.append(frame)
         pr, ir = rp.predict(frame, index)
-        refs.append(pr)
         pp, ip = sp.predict(frame, index)
-        assert ir == ip
-        assert (pr is None) == (pp is None), index
-        if pr is not None:
-            got += 1
-            assert pp.shape == pr.shape
-            err = (pp.float().cpu() - pr).abs().max().item()
-            assert err < 2e-3, (index, err, pr, pp)
-    assert got == n - 28
-    live = torch.stack([r for r in refs if r is not None])
-    assert ((live > 0.01) & (live < 0.99)).any(), "saturated probabilities would make this comparison vacuous"
+        assert ir == ip == index - 14
+        assert (pr is None) == (pp is None) == (index < 28), index
+        refs.append(pr); outs.append(None if pp is None else pp.float().cpu())
+    live = torch.stack([r for r in refs if r is not None]).double()
+    assert ((live > 0.05) & (live < 0.95)).all(), "saturated probabilities would make this comparison vacuous"
+    lref = torch.logit(live)
+    spread = (lref.max(0).values - lref.min(0).values).min().item()
+    assert spread > 1e-3, spread
+    tol = 0.03 * spread
+
+    def check(got, tag):
+        lg = torch.logit(torch.stack(got).double())
+        err = (lg - lref[:len(got)]).abs().max().item()
+        assert err < tol, (tag, err, spread)
+    check([o for o in outs if o is not None], "frame by frame")
     # chunked offline prediction: the same stream three frames at a time (one 2D pass over 3 new stacks, one tail pass
     # over 3 windows), including the chunk that straddles the first complete window
     sb = StreamPredictor(prod, frame_size=size, tta=tta)
+    got = []
     for first in range(0, n - n % 3, 3):
-        outs = sb.predict_batch(torch.stack(all_frames[first:first + 3]), first)
-        for j, (pp, ip) in enumerate(outs):
+        res = sb.predict_batch(torch.stack(all_frames[first:first + 3]), first)
+        for j, (pp, ip) in enumerate(res):
             assert ip == first + j - 14 and (pp is None) == (refs[first + j] is None)
             if pp is not None:
-                assert (pp.float().cpu() - refs[first + j]).abs().max().item() < 2e-3
+                got.append(pp.float().cpu())
+    check(got, "chunks of 3")
     # a gap in the stream: the window is incomplete again until 15 fresh frames (stride 2) are there
     sp2 = StreamPredictor(prod, frame_size=size, tta=tta)
     for index in list(range(0, 30)) + [40]:
