@@ -206,49 +206,64 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
 }
 
 // ------------------------------------------------------------------------------------ persistent forward
-// Thin layers (K = ntaps*Cin <= 14 k-steps, the whole input patch of a tile in LDS) are latency-,
-// not bandwidth-bound with one tile per block: every block restaged the filter and waited out a
-// full memory latency.  Here a block keeps its 64-output-channel filter slab RESIDENT in LDS
-// ([n][k = tap*Cin + ch], one 16-byte fragment read per MFMA operand), walks a contiguous range of
-// tiles with the next tile's patch loads in flight under the current tile's MFMAs, and carries the
-// BatchNorm partial sums in registers until the end.  The k index is flattened over (tap, channel),
-// so Cin = 16 needs 5 k-steps for 9 taps instead of 9 half-empty ones.
-// LDS row pitch (elements): the next byte pitch that is 32 (mod 64) — conflict-free for ds_read_b128
+// Layers whose filter slab (all taps x Cin of an N-tile of 16*NFR output channels) and one whole-channel input
+// patch fit in LDS.  These layers stream 150-450 MB at 100-600 FLOP/B: the bound is HBM, and what decides
+// whether a CU gets its share of it is the number of bytes it keeps IN FLIGHT (Little: ~13 B/clk x ~5000 clk).
+// So a block keeps its filter slab RESIDENT ([n][k = tap*Cin + ch], one 16-byte fragment read per MFMA
+// operand), walks a contiguous range of tiles, and holds the raw patches of the NEXT TWO tiles in two register
+// sets while the MFMAs of the current one run; nothing else in the loop touches vmcnt (prologue coefficients
+// come from an LDS table, there is no residual operand here), so the in-order counter never drains a prefetch.
+// The k index is flattened over (tap, channel): Cin = 16 needs 5 k-steps for 9 taps instead of 9 half-empty ones.
+// Tap GROUPS (stride-2 data gradient): the 1+2+2+4 taps of the four output parities are evaluated from ONE
+// staged patch of dy and written to their own output sub-grids - one read of dy instead of four.
+// LDS row pitch (elements): the next byte pitch that is 32 (mod 64) - conflict-free for ds_read_b128
 MDS_DEV int cvp_pitch(int elems, int esz) { const int b = elems * esz; return (b + ((96 - b % 64) % 64)) / esz; }
 static inline int cvp_pitch_h(int elems, int esz) { const int b = elems * esz; return (b + ((96 - b % 64) % 64)) / esz; }
 
-template <typename T, int PRO, int IS, int MAXX>
-__global__ __launch_bounds__(256, 2) void conv_fwd_p_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW,
-                                                            int tiles_a, int tiles_b, int tiles_per_block, int KS) {
+#define CVQ_MAXX 6   // patch vectors (8 channels of one pixel) a thread holds per register set
+struct CvqGeom {
+  int dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS;
+  int ng;                 // tap groups (1 = plain conv)
+  int gks[5];             // k-steps [gks[g], gks[g+1]) belong to group g
+  int goy[4], gox[4], gA[4], gB[4];
+};
+
+template <typename T, int MF, int NFR> struct CvqOcc { static const int v = (sizeof(T) == 4 || MF * NFR >= 8 || NFR == 4) ? 2 : 3; };
+
+template <typename T, bool HASPRO, int IS, int MF, int NFR>
+__global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kernel(mds_conv_fwd_args a, CvqGeom gq) {
   typedef typename Frag<T>::type frag_t;
-  constexpr int MF = (IS == 1) ? 4 : 2, TA = 4 * MF;  // MAXX: patch vectors a thread keeps in flight
+  constexpr int TA = 4 * MF, BNQ = 16 * NFR, MAXX = CVQ_MAXX;
   MDS_DYN_SMEM(smem);
-  const int Cin = a.Cin, Cout = a.Cout, K = a.ntaps * Cin;
+  const int Cin = a.Cin, Cout = a.Cout, K = a.ntaps * Cin, KS = gq.KS, TW = gq.TW;
   const int LDX = cvp_pitch(Cin, sizeof(T)), LDW = cvp_pitch(KS * 32, sizeof(T));
-  const int npix = TH * TW, cpp = Cin >> 3, nitems = npix * cpp;
+  const int npix = gq.TH * TW, cpp = Cin >> 3, nitems = npix * cpp;
   T* xs = (T*)smem;                        // [npix][LDX]
-  T* ws = xs + npix * LDX;                 // [64][LDW]
-  float* st_s = (float*)(ws + CV_BN * LDW);  // [CV_BN]
-  float* st_ss = st_s + CV_BN;
-  int* ktab = (int*)(st_ss + CV_BN);       // [KS*4] LDS offset (tap shift + channel) of each 8-wide k chunk
+  T* ws = xs + npix * LDX;                 // [BNQ][LDW]
+  float* st_s = (float*)(ws + BNQ * LDW);  // [BNQ]
+  float* st_ss = st_s + BNQ;
+  float* psc = st_ss + BNQ;                // [Cin] prologue scale / shift
+  float* psh = psc + Cin;
+  int* ktab = (int*)(psh + Cin);           // [KS*4] LDS offset (tap shift + channel) of each 8-wide k chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.y * CV_BN;
-  const int nfr = (Cout - n0 >= CV_BN) ? 4 : ((Cout - n0) >> 4);
+  const int n0 = blockIdx.y * BNQ;
+  const int nfr = (Cout - n0 >= BNQ) ? NFR : ((Cout - n0) >> 4);
   const T* w = (const T*)a.w;
   T* y = (T*)a.y;
   const float rTW = 1.0f / (float)TW, rcpp = 1.0f / (float)cpp;
+  const int tiles_ab = gq.tiles_a * gq.tiles_b;
 
   for (int c = tid; c < KS * 4; c += 256) {
     const int k = 8 * c;
     int off = 0;
     if (k < K) {
       const int t = k / Cin, ch = k - t * Cin;
-      off = ((a.dy[t] - dymin) * TW + (a.dx[t] - dxmin)) * LDX + ch;
+      off = ((a.dy[t] - gq.dymin) * TW + (a.dx[t] - gq.dxmin)) * LDX + ch;
     }
     ktab[c] = off;
   }
-  for (int e = tid; e < CV_BN * KS * 4; e += 256) {
+  for (int e = tid; e < BNQ * KS * 4; e += 256) {
     const int n = e / (KS * 4), c = e - n * (KS * 4), k = 8 * c;
     RawV8<T> r;
     r.zero();
@@ -258,70 +273,62 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_p_kernel(mds_conv_fwd_args a,
     }
     r.st(ws + n * LDW + k);
   }
-  if (tid < CV_BN) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
+  if (tid < BNQ) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
+  if (HASPRO) {
+    for (int c = tid; c < Cin; c += 256) { psc[c] = a.pro.scale[c]; psh[c] = a.pro.shift[c]; }
+  }
+  const bool silu = a.pro.mode == MDS_PRO_BN_SILU;
 
-  const long total_tiles = (long)a.N * tiles_a * tiles_b;
-  long tl = (long)blockIdx.x * tiles_per_block;
-  long tl_end = tl + tiles_per_block;
+  const long total_tiles = (long)a.N * tiles_ab;
+  long tl = (long)blockIdx.x * gq.tpb;
+  long tl_end = tl + gq.tpb;
   if (tl_end > total_tiles) tl_end = total_tiles;
   int xbase[MF];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) xbase[mf] = ((MF * wave + mf) * IS * TW + i * IS) * LDX;
   const int wbase = i * LDW + 8 * q;
 
-  RawV8<T> rx[MAXX];
-  unsigned okx = 0;
   auto origin = [&](long t, int& img, int& a0, int& b0) {
-    img = (int)(t / (tiles_a * tiles_b));
-    const int rem = (int)(t - (long)img * tiles_a * tiles_b);
-    a0 = (rem / tiles_b) * TA; b0 = (rem % tiles_b) * CV_TB;
+    img = (int)(t / tiles_ab);
+    const int rem = (int)(t - (long)img * tiles_ab);
+    a0 = (rem / gq.tiles_b) * TA; b0 = (rem % gq.tiles_b) * CV_TB;
   };
-  auto issue = [&](long t) {
+  // every issue() executes the same number of loads (tiles past the end re-read the last one): the compiler's
+  // vmcnt bookkeeping then never has a path with fewer loads outstanding, i.e. never waits on the younger set
+  auto issue = [&](long t, RawV8<T>(&rx)[MAXX], unsigned& okx) {
     int img, a0, b0;
-    origin(t, img, a0, b0);
+    origin(t < tl_end ? t : tl_end - 1, img, a0, b0);
     const T* x = (const T*)a.x + (long)img * a.IH * a.IW * Cin;
     okx = 0;
 #pragma unroll
     for (int l = 0; l < MAXX; ++l) {
-      const int it = tid + 256 * l;
-      if (it < nitems) {
-        const int pix = fdiv(it, rcpp), c8 = it - pix * cpp;
-        const int ty = fdiv(pix, rTW), tx = pix - ty * TW;
-        const int iy = a0 * IS + dymin + ty, ix = b0 * IS + dxmin + tx;
-        const bool ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-        okx |= (ok ? 1u : 0u) << l;
-        const int cy = iy < 0 ? 0 : (iy >= a.IH ? a.IH - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.IW ? a.IW - 1 : ix);
-        rx[l].ld(x + ((long)cy * a.IW + cx) * Cin + 8 * c8);
-      }
+      const int it0 = tid + 256 * l, it = it0 < nitems ? it0 : nitems - 1;
+      const int pix = fdiv(it, rcpp), c8 = it - pix * cpp;
+      const int ty = fdiv(pix, rTW), tx = pix - ty * TW;
+      const int iy = a0 * IS + gq.dymin + ty, ix = b0 * IS + gq.dxmin + tx;
+      const bool ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+      okx |= (ok ? 1u : 0u) << l;
+      const int cy = iy < 0 ? 0 : (iy >= a.IH ? a.IH - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.IW ? a.IW - 1 : ix);
+      rx[l].ld(x + ((long)cy * a.IW + cx) * Cin + 8 * c8);
     }
   };
-  float ps[16], pss[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
-
-  if (tl < tl_end) issue(tl);
-  for (; tl < tl_end; ++tl) {
-    int img, a0, b0;
-    origin(tl, img, a0, b0);
-    __syncthreads();  // the previous tile's fragment reads are done (first pass: filter slab staged)
+  auto stage = [&](RawV8<T>(&rx)[MAXX], unsigned okx) {
 #pragma unroll
     for (int l = 0; l < MAXX; ++l) {
       const int it = tid + 256 * l;
       if (it < nitems) {
         const int pix = fdiv(it, rcpp), c8 = it - pix * cpp;
         const bool ok = (okx >> l) & 1u;
-        if (PRO == MDS_PRO_NONE) {
+        if (!HASPRO) {
           if (!ok) rx[l].zero();
           rx[l].st(xs + pix * LDX + 8 * c8);
         } else {
-          float v[8], sc[8], sh[8];
+          float v[8];
           rx[l].get(v);
-          load8f(a.pro.scale + 8 * c8, sc);
-          load8f(a.pro.shift + 8 * c8, sh);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float z = v[j] * sc[j] + sh[j];
-            z = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+            float z = v[j] * psc[8 * c8 + j] + psh[8 * c8 + j];
+            z = silu ? siluf_(z) : z;
             v[j] = ok ? z : 0.f;  // zero padding AFTER the activation
           }
           store8(xs + pix * LDX + 8 * c8, v);
@@ -329,63 +336,90 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_p_kernel(mds_conv_fwd_args a,
         }
       }
     }
-    __syncthreads();
-    if (tl + 1 < tl_end) issue(tl + 1);  // next patch flies under this tile's MFMAs
+  };
+  float ps[4 * NFR], pss[4 * NFR];
+#pragma unroll
+  for (int e = 0; e < 4 * NFR; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
 
-    f32x4 acc[MF][4];
+  auto compute = [&](long t) {
+    int img, a0, b0;
+    origin(t, img, a0, b0);
+    for (int g = 0; g < gq.ng; ++g) {
+      f32x4 acc[MF][NFR];
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf)
+      for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int xo_next = ktab[q];
-    for (int s = 0; s < KS; ++s) {
-      const int xo = xo_next;   // the tap-offset lookup of step s+1 is issued a step ahead: the fragment
-      xo_next = ktab[4 * (s + 1 < KS ? s + 1 : s) + q];   // addresses no longer wait for two LDS round trips
-      frag_t xf[MF], wf[4];
+        for (int nf = 0; nf < NFR; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int s0 = gq.gks[g], s1 = gq.gks[g + 1];
+      int xo_next = ktab[4 * s0 + q];
+      for (int s = s0; s < s1; ++s) {
+        const int xo = xo_next;   // the tap-offset lookup of step s+1 is issued a step ahead
+        xo_next = ktab[4 * (s + 1 < s1 ? s + 1 : s) + q];
+        frag_t xf[MF], wf[NFR];
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) xf[mf] = ld_frag(xs + xbase[mf] + xo);
+        for (int mf = 0; mf < MF; ++mf) xf[mf] = ld_frag(xs + xbase[mf] + xo);
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
-        if (nf < nfr) wf[nf] = ld_frag(ws + wbase + 16 * nf * LDW + 32 * s);
+        for (int nf = 0; nf < NFR; ++nf)
+          if (nf < nfr) wf[nf] = ld_frag(ws + wbase + 16 * nf * LDW + 32 * s);
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        if (nf < nfr) {
+        for (int nf = 0; nf < NFR; ++nf) {
+          if (nf < nfr) {
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) mma16(wf[nf], xf[mf], acc[mf][nf]);
+            for (int mf = 0; mf < MF; ++mf) mma16(wf[nf], xf[mf], acc[mf][nf]);
+          }
+        }
+      }
+      const int gA = gq.gA[g], gB = gq.gB[g], goy = gq.goy[g], gox = gq.gox[g];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int aa = a0 + MF * wave + mf, bb = b0 + i;
+        const bool valid = aa < gA && bb < gB;
+        const long row = ((long)img * a.OH + (goy + aa * a.os)) * a.OW + (gox + bb * a.os);
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) {
+          if (nf < nfr && valid) {
+            const int n = n0 + 16 * nf + 4 * q;
+            float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
+            store4(y + row * Cout + n, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[r]; pss[nf * 4 + r] += v[r] * v[r]; }
+          }
         }
       }
     }
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      const int aa = a0 + MF * wave + mf, bb = b0 + i;
-      const bool valid = aa < a.A && bb < a.B;
-      const long row = ((long)img * a.OH + (a.oy0 + aa * a.os)) * a.OW + (a.ox0 + bb * a.os);
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        if (nf < nfr && valid) {
-          const int n = n0 + 16 * nf + 4 * q;
-          float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
-          if (a.residual) {
-            float rr[4];
-            load4((const T*)a.residual + row * Cout + n, rr);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rr[r];
-          }
-          store4(y + row * Cout + n, v);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[r]; pss[nf * 4 + r] += v[r] * v[r]; }
-        }
-      }
+  };
+
+  RawV8<T> rA[MAXX], rB[MAXX];
+  unsigned okA = 0, okB = 0;
+  issue(tl, rA, okA);
+  issue(tl + 1, rB, okB);
+  for (; tl < tl_end; tl += 2) {
+    __syncthreads();          // the previous tile's fragment reads are done (first pass: slab + tables staged)
+    stage(rA, okA);
+    __syncthreads();
+    issue(tl + 2, rA, okA);   // two tiles ahead: a full tile period (+ the other set's) to land
+    compute(tl);
+    if (tl + 1 < tl_end) {
+      __syncthreads();
+      stage(rB, okB);
+      __syncthreads();
+      issue(tl + 3, rB, okB);
+      compute(tl + 1);
     }
   }
   if (a.stats) {
-    const int e = reduce_scatter16(ps, i);
-    reduce_scatter16(pss, i);
+    float p16[16], q16[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { p16[e] = e < 4 * NFR ? ps[e < 4 * NFR ? e : 0] : 0.f; q16[e] = e < 4 * NFR ? pss[e < 4 * NFR ? e : 0] : 0.f; }
+    const int e = reduce_scatter16(p16, i);
+    reduce_scatter16(q16, i);
     const int nl = 16 * (e >> 2) + 4 * q + (e & 3);
-    atomicAdd(&st_s[nl], ps[0]);
-    atomicAdd(&st_ss[nl], pss[0]);
+    if (nl < BNQ) {
+      atomicAdd(&st_s[nl], p16[0]);
+      atomicAdd(&st_ss[nl], q16[0]);
+    }
     __syncthreads();
-    if (tid < CV_BN && n0 + tid < Cout) {
+    if (tid < BNQ && n0 + tid < Cout) {
       float* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * Cout;
       atomicAdd(st + n0 + tid, st_s[tid]);
       atomicAdd(st + Cout + n0 + tid, st_ss[tid]);
@@ -413,37 +447,83 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
   const int eh = tap_extent(a->dy, a->ntaps, &dymin), ew = tap_extent(a->dx, a->ntaps, &dxmin);
   const int TA = a->is == 1 ? 16 : 8;
   const int TH = (TA - 1) * a->is + eh + 1, TW = (CV_TB - 1) * a->is + ew + 1;
-  dim3 grid(cdiv(a->B, CV_TB), cdiv(a->A, TA), a->N), block(256);
-  {  // persistent variant when the filter slab + one whole-channel input patch fit in LDS
+  dim3 block(256);
+  const int ng = a->ngroups > 1 ? a->ngroups : 1;
+  MDS_REQUIRE(ng <= 4, "conv_fwd: at most 4 tap groups");
+  if (ng > 1) {
+    int nt_ = 0;
+    for (int g = 0; g < ng; ++g) {
+      MDS_REQUIRE(a->g_ntaps[g] >= 1 && (a->g_ntaps[g] * a->Cin) % 32 == 0, "conv_fwd: a tap group needs ntaps*Cin %% 32 == 0");
+      MDS_REQUIRE(a->g_A[g] > 0 && a->g_B[g] > 0 && a->g_oy0[g] + (a->g_A[g] - 1) * a->os < a->OH && a->g_ox0[g] + (a->g_B[g] - 1) * a->os < a->OW,
+                  "conv_fwd: group sub-grid exceeds output");
+      nt_ += a->g_ntaps[g];
+    }
+    MDS_REQUIRE(nt_ == a->ntaps && a->is == 1 && !a->residual && !a->stats, "conv_fwd: tap groups partition the tap list (is = 1, no residual / statistics)");
+  }
+  if (!a->residual && !mds_switch(MDS_SW_CONV_OLD)) {  // persistent variant when a filter slab + one whole-channel input patch fit in LDS
     const int KS = cdiv(a->ntaps * a->Cin, 32);
-    const size_t esz = a->dtype == MDS_BF16 ? 2 : 4;
-    const size_t smem = ((size_t)TH * TW * cvp_pitch_h(a->Cin, (int)esz) + (size_t)CV_BN * cvp_pitch_h(KS * 32, (int)esz)) * esz + 2 * CV_BN * sizeof(float) + (size_t)KS * 16;
-    if (TH * TW * (a->Cin / 8) <= 10 * 256 && smem <= 76 * 1024 && !mds_switch(MDS_SW_CONV_OLD)) {  // two blocks per CU (measured: one resident block loses to the tile-per-block kernel)
-      const int tiles_a = cdiv(a->A, TA), tiles_b = cdiv(a->B, CV_TB);
-      const long total = (long)a->N * tiles_a * tiles_b;
-      const int nt = cdiv(a->Cout, CV_BN);
-      long want = (long)256 * 2 * 2 / nt;  // two balanced rounds of the chip at two blocks per CU
+    const int esz = a->dtype == MDS_BF16 ? 2 : 4;
+    const int co16 = a->Cout / 16;
+    const int nfr_try[3] = {co16 >= 3 ? 4 : co16, co16 >= 3 ? 2 : (co16 == 2 ? 1 : 0), co16 >= 3 ? 1 : 0};
+    const int mf_try[3] = {a->is == 1 ? 4 : 2, a->is == 1 ? 2 : 1, a->is == 1 ? 1 : 0};
+    int MFs = 0, NFRs = 0, THq = 0, TWq = 0;
+    size_t smem = 0;
+    for (int lim = 0; lim < (ng > 1 ? 2 : 1) && !MFs; ++lim) {   // tap groups have no other kernel: they may take the whole LDS
+      for (int ni = 0; ni < 3 && !MFs; ++ni) {
+        for (int mi = 0; mi < 3 && !MFs; ++mi) {
+          const int nf = nfr_try[ni], mf = mf_try[mi];
+          if (!nf || !mf) continue;
+          const int th = (4 * mf - 1) * a->is + eh + 1, tw = (CV_TB - 1) * a->is + ew + 1;
+          const size_t sm = ((size_t)th * tw * cvp_pitch_h(a->Cin, esz) + (size_t)16 * nf * cvp_pitch_h(KS * 32, esz)) * esz +
+                            2 * 16 * nf * sizeof(float) + 2 * (size_t)a->Cin * sizeof(float) + (size_t)KS * 16;
+          if (th * tw * (a->Cin / 8) <= CVQ_MAXX * 256 && sm <= (lim ? 160 : 76) * 1024) { MFs = mf; NFRs = nf; THq = th; TWq = tw; smem = sm; }
+        }
+      }
+    }
+    MDS_REQUIRE(MFs || ng == 1, "conv_fwd: tap groups need a filter slab + patch that fit in LDS (Cin=%d Cout=%d)", a->Cin, a->Cout);
+    if (MFs) {
+      CvqGeom gq;
+      gq.dymin = dymin; gq.dxmin = dxmin; gq.TH = THq; gq.TW = TWq; gq.KS = KS; gq.ng = ng;
+      int Amax = 0, Bmax = 0, k0 = 0;
+      for (int g = 0; g < ng; ++g) {
+        gq.gks[g] = k0;
+        if (ng > 1) { gq.goy[g] = a->g_oy0[g]; gq.gox[g] = a->g_ox0[g]; gq.gA[g] = a->g_A[g]; gq.gB[g] = a->g_B[g]; k0 += a->g_ntaps[g] * a->Cin / 32; }
+        else { gq.goy[g] = a->oy0; gq.gox[g] = a->ox0; gq.gA[g] = a->A; gq.gB[g] = a->B; k0 = KS; }
+        Amax = gq.gA[g] > Amax ? gq.gA[g] : Amax; Bmax = gq.gB[g] > Bmax ? gq.gB[g] : Bmax;
+      }
+      gq.gks[ng] = k0;
+      for (int g = ng; g < 4; ++g) { gq.gks[g + 1] = k0; gq.goy[g] = gq.gox[g] = gq.gA[g] = gq.gB[g] = 0; }
+      gq.tiles_a = cdiv(Amax, 4 * MFs); gq.tiles_b = cdiv(Bmax, CV_TB);
+      const long total = (long)a->N * gq.tiles_a * gq.tiles_b;
+      const int nt = cdiv(a->Cout, 16 * NFRs);
+      int occ = (esz == 4 || MFs * NFRs >= 8 || NFRs == 4) ? 2 : 3;
+      while (occ > 1 && smem * occ > 160 * 1024) --occ;
+      long want = (long)256 * occ * 2 / nt;  // two balanced rounds of the chip
+      if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) want = mds_knob(MDS_KNOB_CONV_BLOCKS);
       if (want < 1) want = 1;
-      const int tpb = (int)cdiv(total, want < total ? want : total);
-      dim3 pgrid(cdiv(total, tpb), nt);
-      const bool small = TH * TW * (a->Cin / 8) <= 6 * 256;
-#define CVP_GO(T, PRO)                                                                                              \
-  do {                                                                                                              \
-    if (a->is == 1 && small) MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 1, 6>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
-    else if (a->is == 1) MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 1, 10>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
-    else MDS_LAUNCH((conv_fwd_p_kernel<T, PRO, 2, 10>), pgrid, block, smem, stream, *a, dymin, dxmin, TH, TW, tiles_a, tiles_b, tpb, KS); \
+      gq.tpb = (int)cdiv(total, want < total ? want : total);
+      dim3 pgrid(cdiv(total, gq.tpb), nt);
+#define CVQ_GO3(T, HP, IS_, MF_, NF_) MDS_LAUNCH((conv_fwd_q_kernel<T, HP, IS_, MF_, NF_>), pgrid, block, smem, stream, *a, gq)
+#define CVQ_GO2(T, HP, IS_, MF_) do { if (NFRs == 4) CVQ_GO3(T, HP, IS_, MF_, 4); else if (NFRs == 2) CVQ_GO3(T, HP, IS_, MF_, 2); else CVQ_GO3(T, HP, IS_, MF_, 1); } while (0)
+#define CVQ_GO(T, HP)                                                                   \
+  do {                                                                                  \
+    if (a->is == 1 && MFs == 4) CVQ_GO2(T, HP, 1, 4);                                   \
+    else if (a->is == 1 && MFs == 2) CVQ_GO2(T, HP, 1, 2);                              \
+    else if (a->is == 1) CVQ_GO2(T, HP, 1, 1);                                          \
+    else if (MFs == 2) CVQ_GO2(T, HP, 2, 2);                                            \
+    else CVQ_GO2(T, HP, 2, 1);                                                          \
   } while (0)
       MDS_DISPATCH_DTYPE(a->dtype, T, {
-        switch (a->pro.mode) {
-          case MDS_PRO_NONE: CVP_GO(T, MDS_PRO_NONE); break;
-          case MDS_PRO_AFFINE: CVP_GO(T, MDS_PRO_AFFINE); break;
-          default: CVP_GO(T, MDS_PRO_BN_SILU); break;
-        }
+        if (a->pro.mode == MDS_PRO_NONE) CVQ_GO(T, false); else CVQ_GO(T, true);
       });
-#undef CVP_GO
+#undef CVQ_GO
+#undef CVQ_GO2
+#undef CVQ_GO3
       return mds_check_launch("conv_fwd");
     }
   }
+  MDS_REQUIRE(ng == 1, "conv_fwd: tap groups are not available with MDS_CONV_OLD / a residual operand");
+  dim3 grid(cdiv(a->B, CV_TB), cdiv(a->A, TA), a->N);
 #define CV_GO(T, PRO)                                                                                   \
   do {                                                                                                  \
     const int LD = CvLd<T>::v;                                                                          \

@@ -25,6 +25,14 @@ bool mds_switch(int id) {   // thread-safe one-time read (C++11 static initialis
                                        getenv("MDS_STEM_OLD") != 0};
   return id >= 0 && id < MDS_SW_COUNT && v[id];
 }
+#include <atomic>
+static std::atomic<int> g_knob[MDS_KNOB_COUNT];
+int mds_knob(int id) { return id >= 0 && id < MDS_KNOB_COUNT ? g_knob[id].load(std::memory_order_relaxed) : 0; }
+extern "C" int mds_dev_set(int knob, int value) {
+  MDS_REQUIRE(knob >= 0 && knob < MDS_KNOB_COUNT, "mds_dev_set: unknown knob %d", knob);
+  g_knob[knob].store(value, std::memory_order_relaxed);
+  return 0;
+}
 extern "C" int mds_version(void) { return MDS_VERSION; }
 extern "C" const char* mds_last_error(void) { return g_err; }
 

@@ -257,6 +257,7 @@ MDS_DEV float wave_sum(float v) {
 // They are read ONCE per process (k_misc.hip), never on the launch path.
 enum { MDS_SW_DW_OLD = 0, MDS_SW_CONV_OLD, MDS_SW_WG_OLD, MDS_SW_STEM_OLD, MDS_SW_COUNT };
 bool mds_switch(int id);
+int mds_knob(int id);   // mds_dev_set() values (0 = default), see include/mds.h
 
 // ------------------------------------------------------------------ error plumbing (C ABI)
 void mds_set_error(const char* fmt, ...);

@@ -109,6 +109,8 @@ class Lib:
             self.fn["se_bwd_reduce_blocks"].argtypes = [C.c_long, C.c_int]
         if "pack_weights" in self.fn:
             self.fn["pack_weights"].argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        if "dev_set" in self.fn:
+            self.fn["dev_set"].argtypes = [C.c_int, C.c_int]
         if "bn_eval_table" in self.fn:
             self.fn["bn_eval_table"].argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 

@@ -144,6 +144,10 @@ def op_cost(name, kw, es):
     if name == "pw_wgrad":
         M, K, N = g("M"), g("K"), g("N")
         return (M * K + M * N) * es + N * K * 4, 2 * M * K * N
+    if name == "conv_fwd" and g("ngroups"):
+        pts = [a_ * b_ for a_, b_ in zip(g("g_A"), g("g_B"))]
+        return (g("N") * g("IH") * g("IW") * g("Cin") + g("N") * sum(pts) * g("Cout")) * es + g("Cout") * g("wtaps") * g("Cin") * es, \
+            2 * g("N") * sum(p_ * t_ for p_, t_ in zip(pts, g("g_ntaps"))) * g("Cin") * g("Cout")
     if name == "conv_fwd":
         frac = 1.0 / (g("os") * g("os"))
         nin = g("N") * g("IH") * g("IW") * g("Cin") * frac
@@ -354,11 +358,21 @@ class Plan:
             self.op(seg, "conv_fwd", A=IH, B=IW, oy0=0, ox0=0, os=1, **{"is": 1}, ntaps=9, dy=dy, dx=dx, wi=wi, **common)
         else:
             assert residual is None
+            par = []
             for py in range(2):
                 for px in range(2):
                     dy, dx, wi = geo.taps_dgrad_s2(py, px, pads[0], pads[1])
                     A, B_ = (IH - py + 1) // 2, (IW - px + 1) // 2
                     assert dy and A > 0 and B_ > 0
+                    par.append((py, px, dy, dx, wi, A, B_))
+            if Cout % 32 == 0:       # the four parities as tap groups of ONE launch: dy is read once
+                self.op(seg, "conv_fwd", A=max(p[5] for p in par), B=max(p[6] for p in par), oy0=0, ox0=0, os=2, **{"is": 1},
+                        ntaps=sum(len(p[2]) for p in par), dy=sum((p[2] for p in par), []), dx=sum((p[3] for p in par), []),
+                        wi=sum((p[4] for p in par), []), ngroups=4, g_ntaps=[len(p[2]) for p in par],
+                        g_oy0=[p[0] for p in par], g_ox0=[p[1] for p in par], g_A=[p[5] for p in par], g_B=[p[6] for p in par],
+                        **common)
+            else:
+                for (py, px, dy, dx, wi, A, B_) in par:
                     self.op(seg, "conv_fwd", A=A, B=B_, oy0=py, ox0=px, os=2, **{"is": 1}, ntaps=len(dy), dy=dy, dx=dx,
                             wi=wi, **common)
         return dxb

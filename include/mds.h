@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 106
+#define MDS_VERSION 107
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -38,6 +38,11 @@ typedef void* mds_stream_t;
 
 int mds_version(void);
 const char* mds_last_error(void);
+/* Developer knobs (process-wide, 0 = default).  MDS_KNOB_CONV_BLOCKS caps the grid of the persistent convolution
+ * kernel so that the parity tests can drive its multi-tile software pipeline at small sizes. */
+#define MDS_KNOB_CONV_BLOCKS 0
+#define MDS_KNOB_COUNT 1
+int mds_dev_set(int knob, int value);
 
 /* ---- operand transforms ("prologues"): how a consumer reads a producer's raw conv output.
  * Train-mode BatchNorm needs batch statistics before it can normalise, so producers store the
@@ -144,8 +149,8 @@ int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream);
  *   y[n][oy0 + a*os][ox0 + b*os][:] = sum_t pro(x)[n][a*is + dy[t]][b*is + dx[t]][:] * w[:][wi[t]][:]
  * (out-of-image input pixels contribute 0 AFTER the prologue = zero padding of the activation).
  * Covers: stride-1 'same' conv (is=1), TF-SAME stride-2 conv (is=2, timm Conv2dSame), the
- * stride-1 data gradient (flipped taps) and the stride-2 data gradient (os=2, one launch per
- * output parity class).  replaces timm ConvBnAct.conv / EdgeResidual.conv_exp and their dgrads. */
+ * stride-1 data gradient (flipped taps) and the stride-2 data gradient (os=2; one launch per
+ * output parity class, or all four as tap groups of one launch).  replaces timm ConvBnAct.conv / EdgeResidual.conv_exp and their dgrads. */
 #define MDS_MAX_TAPS 9
 typedef struct {
   int dtype;
@@ -163,6 +168,12 @@ typedef struct {
   mds_pro_t pro;        /* modes NONE / AFFINE / BN_SILU                 */
   const void* residual; /* optional, same indexing as y                  */
   float* stats;         /* optional [SLOTS][2][Cout]                     */
+  /* tap groups (ngroups = 2..4; 0/1 = none): the tap list is the concatenation of the groups' taps, every group is
+   * evaluated from the SAME staged input patch and written to its own sub-grid (g_oy0 + a*os, g_ox0 + b*os), a < g_A,
+   * b < g_B — the four output parities of the stride-2 data gradient in one launch (one read of dy instead of
+   * four).  Needs is == 1, g_ntaps*Cin % 32 == 0, no residual / statistics; A, B = the largest g_A, g_B (oy0 = ox0 = 0). */
+  int ngroups;
+  int g_ntaps[4], g_oy0[4], g_ox0[4], g_A[4], g_B[4];
 } mds_conv_fwd_args;
 int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream);
 

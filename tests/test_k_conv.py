@@ -114,6 +114,58 @@ def test_conv_dgrad(be, dt, N, H, W, Cin, Cout, stride, mode):
     assert_close(dxo, ref, dt, msg="dx")
 
 
+GROUP_CASES = [  # N, H, W, Cin, Cout (of the forward stride-2 conv), persistent blocks (0 = default grid)
+    (2, 16, 34, 16, 64, 0),
+    (1, 11, 17, 32, 128, 0),      # odd sizes: the parities' sub-grids differ in extent
+    (2, 40, 70, 16, 64, 3),       # 3 blocks: each walks several tiles through both register sets (+ an odd tail)
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,blocks", GROUP_CASES)
+def test_conv_dgrad_s2_tap_groups(be, dt, N, H, W, Cin, Cout, blocks):
+    """the four output parities of the stride-2 data gradient as tap groups of ONE launch (engine._conv_dgrad)"""
+    code, tdt = DT[dt]
+    g = gen(H + W + Cout + 1)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(tdt)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, 2)
+    dyt = torch.randn(N, Cout, OH, OW, generator=g).to(tdt)
+    xx = torch.zeros(N, Cin, H, W, requires_grad=True)
+    ref_conv(xx, w.float(), 2).backward(dyt.float())
+    ref = nhwc(xx.grad)
+    dxo = torch.full((N, H, W, Cin), float("nan")).to(tdt).to(be.device)
+    par = []
+    for py in range(2):
+        for px in range(2):
+            dy, dx, wi = geo.taps_dgrad_s2(py, px, pt, pl)
+            par.append((py, px, dy, dx, wi, (H - py + 1) // 2, (W - px + 1) // 2))
+    args = cabi.make("mds_conv_fwd_args", dtype=code, N=N, IH=OH, IW=OW, Cin=Cout, OH=H, OW=W, Cout=Cin, wtaps=9,
+                     x=be.t(nhwc(dyt)), w=be.t(pack(w, "io", tdt)), y=dxo, pro=cabi.pro(0), residual=None, stats=None,
+                     A=max(p[5] for p in par), B=max(p[6] for p in par), oy0=0, ox0=0, os=2, **{"is": 1},
+                     ntaps=sum(len(p[2]) for p in par), dy=sum((p[2] for p in par), []), dx=sum((p[3] for p in par), []),
+                     wi=sum((p[4] for p in par), []), ngroups=4, g_ntaps=[len(p[2]) for p in par],
+                     g_oy0=[p[0] for p in par], g_ox0=[p[1] for p in par], g_A=[p[5] for p in par], g_B=[p[6] for p in par])
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        be.call("conv_fwd", args)
+        be.sync()
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+    assert_close(dxo, ref, dt, msg="dx")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,mode,blocks", [(2, 45, 50, 32, 16, 1, 2, 5), (1, 40, 70, 16, 64, 2, 2, 2),
+                                                               (1, 33, 40, 32, 128, 1, 0, 3), (1, 30, 37, 16, 32, 1, 1, 4)])
+def test_conv_fwd_persistent_pipeline(be, dt, N, H, W, Cin, Cout, stride, mode, blocks):
+    """few persistent blocks: every block walks many tiles through the two prefetch register sets (even / odd counts)"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        test_conv_fwd(be, dt, N, H, W, Cin, Cout, stride, mode)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("N,H,W,Cin,Cout,stride,mode", CASES)
 def test_conv_wgrad(be, dt, N, H, W, Cin, Cout, stride, mode):

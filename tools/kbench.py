@@ -115,6 +115,41 @@ def bench_conv(which):
             timeit(f"conv_wgrad {tag}", lambda: lib.call("conv_wgrad", a, stream()), (x.numel() + dyt.numel()) * 2, flops)
 
 
+DGRAD_SHAPES = [(20, 368, 640, 32, 16, 1, False, "b0.0 dgrad 16->32"), (20, 368, 640, 16, 64, 2, False, "b1.0 dgrad 64->16 s2"),
+                (20, 184, 320, 32, 128, 1, True, "b1.1 dgrad 128->32 +res"), (20, 184, 320, 32, 128, 2, False, "b2.0 dgrad 128->32 s2"),
+                (20, 92, 160, 48, 192, 1, True, "b2.1 dgrad 192->48 +res")]
+
+
+def bench_conv_dgrad():
+    """data gradients exactly as engine._conv_dgrad launches them (forward-conv shapes in the table)"""
+    for (N, H, W, Cin, Cout, s, res, tag) in DGRAD_SHAPES:
+        OH, OW, pt, pl = geo.conv_geometry(H, W, s)
+        dyb = rnd(N * OH * OW, Cout); w = rnd(Cin * 9 * Cout); dxb = torch.empty(N * H * W, Cin, device=dev, dtype=BF)
+        r = rnd(N * H * W, Cin) if res else None
+        common = dict(dtype=1, N=N, IH=OH, IW=OW, Cin=Cout, OH=H, OW=W, Cout=Cin, wtaps=9, x=dyb, w=w, y=dxb, pro=cabi.pro(0),
+                      residual=r, stats=None)
+        flops = 2 * N * OH * OW * 9 * Cin * Cout
+        nbytes = (dyb.numel() + dxb.numel() * (2 if res else 1)) * 2
+        if s == 1:
+            dy, dx, wi = geo.taps_dgrad_s1()
+            a = cabi.make("mds_conv_fwd_args", A=H, B=W, oy0=0, ox0=0, os=1, **{"is": 1}, ntaps=9, dy=dy, dx=dx, wi=wi, **common)
+            timeit(f"conv {tag}", lambda: lib.call("conv_fwd", a, stream()), nbytes, flops)
+            continue
+        par = []
+        for py in range(2):
+            for px in range(2):
+                dy, dx, wi = geo.taps_dgrad_s2(py, px, pt, pl)
+                par.append((py, px, dy, dx, wi, (H - py + 1) // 2, (W - px + 1) // 2))
+        one = cabi.make("mds_conv_fwd_args", A=max(p[5] for p in par), B=max(p[6] for p in par), oy0=0, ox0=0, os=2, **{"is": 1},
+                        ntaps=sum(len(p[2]) for p in par), dy=sum((p[2] for p in par), []), dx=sum((p[3] for p in par), []),
+                        wi=sum((p[4] for p in par), []), ngroups=4, g_ntaps=[len(p[2]) for p in par],
+                        g_oy0=[p[0] for p in par], g_ox0=[p[1] for p in par], g_A=[p[5] for p in par], g_B=[p[6] for p in par], **common)
+        four = [cabi.make("mds_conv_fwd_args", A=A, B=B_, oy0=py, ox0=px, os=2, **{"is": 1}, ntaps=len(dy), dy=dy, dx=dx, wi=wi, **common)
+                for (py, px, dy, dx, wi, A, B_) in par]
+        timeit(f"conv {tag} (tap groups)", lambda: lib.call("conv_fwd", one, stream()), nbytes, flops)
+        timeit(f"conv {tag} (4 launches)", lambda: [lib.call("conv_fwd", a4, stream()) for a4 in four], nbytes, flops)
+
+
 def bench_se():
     for (G, R, C) in [(20, 3680, 672), (20, 920, 1152), (20, 3680, 384), (4, 4600, 576)]:
         bench_se1(G, R, C)
@@ -170,5 +205,7 @@ if __name__ == "__main__":
             bench_dw(t)
         elif t.startswith("pw"):
             bench_pw(t)
+        elif t == "conv_dgrad":
+            bench_conv_dgrad()
         else:
             bench_conv(t)
