@@ -55,6 +55,18 @@ template <> struct RawV8<float> {
   MDS_DEV void st(float* p) const { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
 };
 
+template <typename T> struct RawV4;   // 4 consecutive elements as loaded
+template <> struct RawV4<bf16_t> {
+  u16x4 v;
+  MDS_DEV void ld(const bf16_t* p) { v = *(const u16x4*)p; }
+  MDS_DEV float get(int j) const { return bf2f(v[j]); }
+};
+template <> struct RawV4<float> {
+  f32x4 v;
+  MDS_DEV void ld(const float* p) { v = *(const f32x4*)p; }
+  MDS_DEV float get(int j) const { return v[j]; }
+};
+
 // exact a / b for 0 <= a < 2^22 with rb = 1.0f / b (cheap replacement for integer division)
 MDS_DEV int fdiv(int a, float rb) { return (int)(((float)a + 0.5f) * rb); }
 

@@ -19,22 +19,20 @@ template <typename T> struct CvLd;   // LDS pitch of one staged pixel / weight r
 template <> struct CvLd<bf16_t> { static const int v = 48; };   // 96 B: 32 B x odd (see PwCfg)
 template <> struct CvLd<float> { static const int v = 40; };     // 160 B
 
-template <typename T, int PRO, int IS>
+template <typename T, int PRO, int IS, int NFR>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW, int tg) {
   typedef typename Frag<T>::type frag_t;
-  constexpr int LD = CvLd<T>::v;
+  constexpr int LD = CvLd<T>::v, BN = 16 * NFR;
   constexpr int MF = (IS == 1) ? 4 : 2;        // 16-pixel row fragments per wave
   constexpr int TA = 4 * MF;                   // sub-grid rows per block
   constexpr int MAXX = (IS == 1) ? 6 : 9;      // input-patch vectors per thread (18x18 | 17x33 pixels x 4)
-  constexpr int MAXW = MDS_MAX_TAPS * CV_BN * 4 / 256;
+  constexpr int MAXW = (MDS_MAX_TAPS * BN * 4 + 255) / 256;
   MDS_DYN_SMEM(smem);
   const int npix = TH * TW;
   const float rTW = 1.0f / (float)TW;
   T* xs = (T*)smem;                                    // [npix][LD]   32-channel chunk of the patch
-  T* ws = xs + npix * LD;                              // [tg taps][CV_BN][LD]
-  float* st_s = (float*)(ws + tg * CV_BN * LD);        // [CV_BN]
-  float* st_ss = st_s + CV_BN;
-  int* toff = (int*)(st_ss + CV_BN);                   // [ntaps] LDS element offset of each tap
+  T* ws = xs + npix * LD;                              // [tg taps][BN][LD]
+  int* toff = (int*)(ws + tg * BN * LD);               // [ntaps] LDS element offset of each tap
   int* twi = toff + MDS_MAX_TAPS;                      // [ntaps] weight slot of each tap
 
   const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
@@ -54,57 +52,85 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
   for (int mf = 0; mf < MF; ++mf) xbase[mf] = ((MF * wave + mf) * IS * TW + i * IS) * LD + 8 * q;
   const int wbase = i * LD + 8 * q;
   const int nx = npix * 4;
+  const int ch = tid & 3;                       // this thread's 8-channel slice of every chunk (256 % 4 == 0)
 
-  for (int n0 = 0; n0 < Cout; n0 += CV_BN) {
-    const int nfr = (Cout - n0 >= CV_BN) ? 4 : ((Cout - n0) >> 4);
+  for (int n0 = 0; n0 < Cout; n0 += BN) {
+    const int nfr = (Cout - n0 >= BN) ? NFR : ((Cout - n0) >> 4);
     const int wrows = nfr * 16;
-    f32x4 acc[MF][4];
+    f32x4 acc[MF][NFR];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int nf = 0; nf < NFR; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Software pipeline over (k-chunk, tap group): the global loads of the NEXT stage - its weights, and the
+    // input patch when it opens a new chunk - are issued right after the current stage's LDS image is complete
+    // and fly under its MFMAs.  Addresses are clamped (always legal); masks are applied at the LDS store.
+    // per-thread element offsets (32-bit, relative to the wave-uniform image / filter base: one VGPR per load)
+    float sc[8], sh[8];
+    RawV8<T> rx[MAXX];
+    unsigned xoff[MAXX], okx = 0;
+#pragma unroll
+    for (int l = 0; l < MAXX; ++l) {
+      const int it = tid + 256 * l, pix = (it < nx ? it : nx - 1) >> 2;
+      const int ty = fdiv(pix, rTW), tx = pix - ty * TW;
+      const int iy = a0 * IS + dymin + ty, ix = b0 * IS + dxmin + tx;
+      okx |= ((iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) ? 1u : 0u) << l;
+      const int cy = iy < 0 ? 0 : (iy >= a.IH ? a.IH - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.IW ? a.IW - 1 : ix);
+      xoff[l] = (unsigned)((cy * a.IW + cx) * Cin) * (unsigned)sizeof(T);   // BYTE offsets: base(SGPR) + 32-bit VGPR addressing
+    }
+    bool kin = true;      // this thread's 8 channels of the staged chunk exist (Cin % 32 != 0 tails)
+    auto issue_x = [&](int kc) {
+      const int kk = kc + 8 * ch;
+      const unsigned kl = kk < Cin ? kk : 0;
+      kin = kk < Cin;
+      if (PRO != MDS_PRO_NONE) { load8f(a.pro.scale + kl, sc); load8f(a.pro.shift + kl, sh); }
+#pragma unroll
+      for (int l = 0; l < MAXX; ++l)
+        rx[l].ld((const T*)((const char*)x + (xoff[l] + kl * (unsigned)sizeof(T))));
+    };
+    RawV8<T> rw[MAXW];
+    unsigned woff[MAXW], okw = 0;
+    bool kinw = true;
+    auto plan_w = [&](int t0) {            // offsets / row masks of one tap group (once per N-tile when all taps fit)
+      const int tn = a.ntaps - t0 < tg ? a.ntaps - t0 : tg;
+      okw = 0;
+#pragma unroll
+      for (int l = 0; l < MAXW; ++l) {
+        const int it = tid + 256 * l, rr = (it < tn * BN * 4 ? it : 0) >> 2;   // rr = tl * BN + r
+        const int tl = rr / BN, r = rr - tl * BN;
+        okw |= ((it < tn * BN * 4 && r < wrows) ? 1u : 0u) << l;
+        woff[l] = (unsigned)(((n0 + (r < wrows ? r : 0)) * a.wtaps + twi[t0 + tl]) * Cin) * (unsigned)sizeof(T);
+      }
+    };
+    const bool one_group = tg >= a.ntaps;
+    plan_w(0);
+    auto issue_w = [&](int kc, int t0) {   // all weight loads of one tap group
+      const int kk = kc + 8 * ch;
+      const unsigned kl = kk < Cin ? kk : 0;
+      kinw = kk < Cin;
+      if (!one_group) plan_w(t0);
+      const int tn = a.ntaps - t0 < tg ? a.ntaps - t0 : tg;
+#pragma unroll
+      for (int l = 0; l < MAXW; ++l)
+        rw[l].ld((const T*)((const char*)w + (woff[l] + kl * (unsigned)sizeof(T))));
+    };
+    RawV4<T> rres[MF][NFR];
+    long orow[MF];        // output row of this lane's pixel per fragment (clamped: always a legal address)
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int aa = a0 + MF * wave + mf, bb = b0 + i;
+      orow[mf] = ((long)img * a.OH + (a.oy0 + (aa < a.A ? aa : a.A - 1) * a.os)) * a.OW + (a.ox0 + (bb < a.B ? bb : a.B - 1) * a.os);
+    }
+    auto load_res = [&]() {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) rres[mf][nf].ld((const T*)a.residual + (orow[mf] * Cout + (n0 + 16 * nf + 4 * q < Cout ? n0 + 16 * nf + 4 * q : 0)));
+    };
+    issue_x(0);
+    issue_w(0, 0);
     for (int kc = 0; kc < Cin; kc += 32) {
-      // ---- issue every global load of this (n-tile, k-chunk) first: input patch, then the weights of
-      //      the first tap group.  Addresses are clamped (always legal); masks are applied afterwards.
-      const int ch = tid & 3, kk = kc + 8 * ch;   // this thread's 8-channel slice of the chunk (256 % 4 == 0)
-      float sc[8], sh[8];
-      if (PRO != MDS_PRO_NONE) {
-        load8f(a.pro.scale + (kk < Cin ? kk : 0), sc);
-        load8f(a.pro.shift + (kk < Cin ? kk : 0), sh);
-      }
-      RawV8<T> rx[MAXX];
-      unsigned okx = 0;
-#pragma unroll
-      for (int l = 0; l < MAXX; ++l) {
-        const int it = tid + 256 * l;
-        if (it < nx) {
-          const int pix = it >> 2;
-          const int ty = fdiv(pix, rTW), tx = pix - ty * TW;
-          const int iy = a0 * IS + dymin + ty, ix = b0 * IS + dxmin + tx;
-          const bool ok = iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW && kk < Cin;
-          okx |= (ok ? 1u : 0u) << l;
-          const int cy = iy < 0 ? 0 : (iy >= a.IH ? a.IH - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.IW ? a.IW - 1 : ix);
-          rx[l].ld(x + ((long)cy * a.IW + cx) * Cin + (kk < Cin ? kk : 0));
-        }
-      }
-      RawV8<T> rw[MAXW];
-      unsigned okw = 0;
-      auto issue_w = [&](int t0) {   // all weight loads of one tap group
-        const int tn = a.ntaps - t0 < tg ? a.ntaps - t0 : tg;
-        okw = 0;
-#pragma unroll
-        for (int l = 0; l < MAXW; ++l) {
-          const int it = tid + 256 * l;
-          if (it < tn * CV_BN * 4) {
-            const int rr = it >> 2;                       // rr = tl * CV_BN + r
-            const int t = t0 + (rr >> 6), r = rr & (CV_BN - 1);
-            okw |= ((r < wrows && kk < Cin) ? 1u : 0u) << l;
-            if (r < wrows) rw[l].ld(w + ((long)(n0 + r) * a.wtaps + twi[t]) * Cin + (kk < Cin ? kk : 0));
-          }
-        }
-      };
-      issue_w(0);
       for (int t0 = 0; t0 < a.ntaps; t0 += tg) {
         const int tn = a.ntaps - t0 < tg ? a.ntaps - t0 : tg;
         __syncthreads();  // previous fragment reads are done
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
             const int it = tid + 256 * l;
             if (it < nx) {
               const int pix = it >> 2;
-              const bool ok = (okx >> l) & 1u;
+              const bool ok = ((okx >> l) & 1u) && kin;
               if (PRO == MDS_PRO_NONE) {
                 if (!ok) rx[l].zero();
                 rx[l].st(xs + pix * LD + 8 * ch);
@@ -136,36 +162,32 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
 #pragma unroll
         for (int l = 0; l < MAXW; ++l) {
           const int it = tid + 256 * l;
-          if (it < tn * CV_BN * 4) {
-            const int rr = it >> 2;
-            if ((rr & (CV_BN - 1)) < wrows) {
-              if (!((okw >> l) & 1u)) rw[l].zero();
-              rw[l].st(ws + rr * LD + 8 * ch);
-            }
+          if (it < tn * BN * 4) {
+            if (!(((okw >> l) & 1u) && kinw)) rw[l].zero();
+            rw[l].st(ws + (it >> 2) * LD + 8 * ch);
           }
         }
         __syncthreads();
-        if (t0 + tg < a.ntaps) issue_w(t0 + tg);   // next group's weights fly under this group's MFMAs
+        if (t0 + tg < a.ntaps) issue_w(kc, t0 + tg);
+        else if (kc + 32 < Cin) { issue_x(kc + 32); issue_w(kc + 32, 0); }
+        else if (a.residual && NFR <= 2) load_res();   // last stage of the tile: the residual operand flies under its MFMAs
         for (int tl = 0; tl < tn; ++tl) {
           const int xo = toff[t0 + tl];
-          const T* wt = ws + tl * CV_BN * LD + wbase;
-          frag_t xf[MF], wf[4];
+          const T* wt = ws + tl * BN * LD + wbase;
+          frag_t xf[MF], wf[NFR];   // all NFR fragments, no branch in this loop: rows past the layer's Cout are staged as zeros
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) xf[mf] = ld_frag(xs + xbase[mf] + xo);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf)
-            if (nf < nfr) wf[nf] = ld_frag(wt + 16 * nf * LD);
+          for (int nf = 0; nf < NFR; ++nf) wf[nf] = ld_frag(wt + 16 * nf * LD);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) {
-            if (nf < nfr) {
+          for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
-              for (int mf = 0; mf < MF; ++mf) mma16(wf[nf], xf[mf], acc[mf][nf]);
-            }
-          }
+            for (int mf = 0; mf < MF; ++mf) mma16(wf[nf], xf[mf], acc[mf][nf]);
         }
       }
     }
 
+    if (a.residual && NFR > 2) load_res();   // (register budget: with 3-4 column fragments the loads are batched here instead)
     float ps[16], pss[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
@@ -173,17 +195,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
     for (int mf = 0; mf < MF; ++mf) {
       const int aa = a0 + MF * wave + mf, bb = b0 + i;
       const bool valid = aa < a.A && bb < a.B;
-      const long row = ((long)img * a.OH + (a.oy0 + aa * a.os)) * a.OW + (a.ox0 + bb * a.os);
+      const long row = orow[mf];
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
+      for (int nf = 0; nf < NFR; ++nf) {
         if (nf < nfr && valid) {
           const int n = n0 + 16 * nf + 4 * q;
           float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
           if (a.residual) {
-            float rr[4];
-            load4((const T*)a.residual + row * Cout + n, rr);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            for (int r = 0; r < 4; ++r) v[r] += rres[mf][nf].get(r);
           }
           store4(y + row * Cout + n, v);
 #pragma unroll
@@ -195,13 +215,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
       const int e = reduce_scatter16(ps, i);
       reduce_scatter16(pss, i);
       const int n = n0 + 16 * (e >> 2) + 4 * q + (e & 3);
-      if (n < Cout) {
+      if (16 * (e >> 2) < BN && n < Cout) {
         const int slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7 + wave) % MDS_STAT_SLOTS;
         float* st = a.stats + (long)slot * 2 * Cout;
         atomicAdd(st + n, ps[0]);
         atomicAdd(st + Cout + n, pss[0]);
       }
     }
+    __syncthreads();  // the next N-tile restages LDS
   }
 }
 
@@ -359,15 +380,11 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) xf[mf] = ld_frag(xs + xbase[mf] + xo);
 #pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) wf[nf] = ld_frag(ws + wbase + 16 * nf * LDW + 32 * s);   // rows past Cout are zeros
+#pragma unroll
         for (int nf = 0; nf < NFR; ++nf)
-          if (nf < nfr) wf[nf] = ld_frag(ws + wbase + 16 * nf * LDW + 32 * s);
 #pragma unroll
-        for (int nf = 0; nf < NFR; ++nf) {
-          if (nf < nfr) {
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) mma16(wf[nf], xf[mf], acc[mf][nf]);
-          }
-        }
+          for (int mf = 0; mf < MF; ++mf) mma16(wf[nf], xf[mf], acc[mf][nf]);
       }
       const int gA = gq.gA[g], gB = gq.gB[g], goy = gq.goy[g], gox = gq.gox[g];
 #pragma unroll
@@ -524,15 +541,18 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
   }
   MDS_REQUIRE(ng == 1, "conv_fwd: tap groups are not available with MDS_CONV_OLD / a residual operand");
   dim3 grid(cdiv(a->B, CV_TB), cdiv(a->A, TA), a->N);
-#define CV_GO(T, PRO)                                                                                   \
+  const int co16 = a->Cout / 16;
+  const int NFRg = co16 <= 4 ? co16 : ((co16 % 4 == 0 || co16 % 3) ? 4 : 3);   // output channels per pass: all of them up to 64
+#define CV_GO2(T, PRO, NF)                                                                              \
   do {                                                                                                  \
     const int LD = CvLd<T>::v;                                                                          \
-    int tg = a->ntaps;  /* taps staged per barrier group: all of them unless LDS (160 KiB) says no */   \
-    while (tg > 1 && (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) > 76 * 1024) --tg;                          \
-    const size_t smem = (size_t)(TH * TW + tg * CV_BN) * LD * sizeof(T) + 2 * CV_BN * sizeof(float) + 2 * MDS_MAX_TAPS * sizeof(int); \
-    if (a->is == 1) MDS_LAUNCH((conv_fwd_kernel<T, PRO, 1>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
-    else MDS_LAUNCH((conv_fwd_kernel<T, PRO, 2>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
+    int tg = a->ntaps;  /* taps staged per barrier group: all of them unless LDS (two blocks per CU) says no */   \
+    while (tg > 1 && (size_t)(TH * TW + tg * 16 * NF) * LD * sizeof(T) > 76 * 1024) --tg;               \
+    const size_t smem = (size_t)(TH * TW + tg * 16 * NF) * LD * sizeof(T) + 2 * MDS_MAX_TAPS * sizeof(int); \
+    if (a->is == 1) MDS_LAUNCH((conv_fwd_kernel<T, PRO, 1, NF>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
+    else MDS_LAUNCH((conv_fwd_kernel<T, PRO, 2, NF>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
   } while (0)
+#define CV_GO(T, PRO) do { if (NFRg == 1) CV_GO2(T, PRO, 1); else if (NFRg == 2) CV_GO2(T, PRO, 2); else if (NFRg == 3) CV_GO2(T, PRO, 3); else CV_GO2(T, PRO, 4); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: CV_GO(T, MDS_PRO_NONE); break;
@@ -541,6 +561,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
     }
   });
 #undef CV_GO
+#undef CV_GO2
   return mds_check_launch("conv_fwd");
 }
 
