@@ -62,11 +62,8 @@ MDS_DEV void block_reduce_rows(float (&acc)[NV][8], const RowMap& m, float* red)
   }
 }
 
-// gradient-source evaluation (see mds_gsrc_t): g = f(u, z, gate, dpooled, mask)
-template <typename T>
-MDS_DEV void eval_g(const mds_gsrc_t& gs, long row, int c0, int C, const float (&z)[8], float (&g)[8]) {
-  float u[8];
-  load8((const T*)gs.u + row * (long)C + c0, u);
+// gradient-source evaluation (see mds_gsrc_t): g = f(u, z, gate, dpooled, mask); u already in registers
+MDS_DEV void eval_g_u(const mds_gsrc_t& gs, long row, int c0, int C, const float (&z)[8], const float (&u)[8], float (&g)[8]) {
   if (gs.mode == MDS_G_PLAIN) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = u[j];
@@ -85,6 +82,12 @@ MDS_DEV void eval_g(const mds_gsrc_t& gs, long row, int c0, int C, const float (
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = u[j] * mk;
   }
+}
+template <typename T>
+MDS_DEV void eval_g(const mds_gsrc_t& gs, long row, int c0, int C, const float (&z)[8], float (&g)[8]) {
+  float u[8];
+  load8((const T*)gs.u + row * (long)C + c0, u);
+  eval_g_u(gs, row, c0, C, z, u, g);
 }
 
 // prologue evaluation on 8 channels of one row (scale/shift already in registers)

@@ -254,7 +254,7 @@ MDS_DEV f32x2 sigmoid2(f32x2 z) {
   return (f32x2){fast_rcp(d[0]), fast_rcp(d[1])};
 }
 
-struct DwStrips { int nchunks, nseg, L, nbands, spt; long nstrips; };
+struct DwStrips { int nchunks, nseg, L, nbands, spt, swap; long nstrips; };
 
 template <typename T, int R>
 __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
   typedef typename P::raw_t raw_t;
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
+  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   const int mode = a.pro.mode;
   f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
     if (mode != MDS_PRO_NONE) { sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0); }
   }
   for (int k = 0; k < g.spt; ++k) {
-    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    const long strip = ((long)bx * g.spt + k) * 8 + sl;
     if (!cvalid || strip >= g.nstrips) continue;
     const int seg = (int)(strip % g.nseg);
     const long bt = strip / g.nseg;
@@ -310,30 +311,37 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
         win[j][2] = ok ? v : splat2(0.f);  // zero padding AFTER the activation
       }
     };
-    raw_t raw[NR], cur[NR];
+    // Three columns of raw loads are always in flight per thread (a ring of three register sets): at 4 bytes
+    // per lane and load, one column ahead kept ~24 KB per CU outstanding - a quarter of what HBM latency x
+    // bandwidth asks for.  Loads are never conditional (clamped addresses), so the in-order vmcnt counts stay exact.
+    raw_t raw[3][NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) { win[j][1] = splat2(0.f); win[j][2] = splat2(0.f); }
-    ldcol(ox0 - 1, raw); push(ox0 - 1, raw);
-    ldcol(ox0, raw); push(ox0, raw);
-    ldcol(ox0 + 1, raw);
-#pragma unroll 3
-    for (int o = 0; o < nout; ++o) {
+    ldcol(ox0 - 1, raw[0]); ldcol(ox0, raw[1]); ldcol(ox0 + 1, raw[2]);
+    push(ox0 - 1, raw[0]); ldcol(ox0 + 2, raw[0]);
+    push(ox0, raw[1]); ldcol(ox0 + 3, raw[1]);
+    auto step = [&](int o, raw_t (&rw)[NR]) {
+      push(ox0 + o + 1, rw);
+      ldcol(ox0 + o + 4, rw);   // (clamped: always a legal address)
+      if (o < nout) {
 #pragma unroll
-      for (int j = 0; j < NR; ++j) cur[j] = raw[j];
-      ldcol(ox0 + o + 2, raw);  // prefetch (clamped: always a legal address)
-      push(ox0 + o + 1, cur);
+        for (int r = 0; r < R; ++r) {
+          f32x2 acc = splat2(0.f);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        f32x2 acc = splat2(0.f);
+          for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) acc += win[r + ky][kx] * w[ky][kx];
-        if (oy0 + r < a.OH) {
-          P::st(yim + ((long)r * a.OW + ox0 + o) * C, acc);
-          s1 += acc; s2 += acc * acc;
+            for (int kx = 0; kx < 3; ++kx) acc += win[r + ky][kx] * w[ky][kx];
+          if (oy0 + r < a.OH) {
+            P::st(yim + ((long)r * a.OW + ox0 + o) * C, acc);
+            s1 += acc; s2 += acc * acc;
+          }
         }
       }
+    };
+    for (int o = 0; o < nout; o += 3) {
+      step(o, raw[2]);
+      step(o + 1, raw[0]);
+      step(o + 2, raw[1]);
     }
   }
   if (a.stats) {
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
       float t = 0.f;
 #pragma unroll
       for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-      if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
     }
   }
 }
@@ -360,7 +368,8 @@ __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwSt
   __shared__ float dwl[8][9][64];
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
+  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
   f32x2 w[3][3], dwacc[3][3], sc = splat2(0.f), sh = splat2(0.f), mu = splat2(0.f), rs = splat2(0.f);
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwSt
     mu = *(const f32x2*)(a.mean + c0); rs = *(const f32x2*)(a.rstd + c0);
   }
   for (int k = 0; k < g.spt; ++k) {
-    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    const long strip = ((long)bx * g.spt + k) * 8 + sl;
     if (!cvalid || strip >= g.nstrips) continue;
     const int seg = (int)(strip % g.nseg);
     const long bt = strip / g.nseg;
@@ -413,42 +422,47 @@ __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwSt
         dyw[j][2] = ok ? P::up(raw[j]) : splat2(0.f);
       }
     };
-    raw_t rdy[NR], cdy[NR], rx[R], cx[R];
+    // ring of three register sets: three columns of dy and x loads in flight per thread (see dw2_fwd_kernel)
+    raw_t rdy[3][NR], rx[3][R];
 #pragma unroll
     for (int j = 0; j < NR; ++j) { dyw[j][1] = splat2(0.f); dyw[j][2] = splat2(0.f); }
-    lddy(ix0 - 1, rdy); push(ix0 - 1, rdy);
-    lddy(ix0, rdy); push(ix0, rdy);
-    lddy(ix0 + 1, rdy); ldx(ix0, rx);
-#pragma unroll 3
-    for (int i = 0; i < ncol; ++i) {
-#pragma unroll
-      for (int j = 0; j < NR; ++j) cdy[j] = rdy[j];
-#pragma unroll
-      for (int r = 0; r < R; ++r) cx[r] = rx[r];
-      lddy(ix0 + i + 2, rdy); ldx(ix0 + i + 1, rx);  // prefetch (clamped)
+    lddy(ix0 - 1, rdy[0]); lddy(ix0, rdy[1]); lddy(ix0 + 1, rdy[2]); ldx(ix0, rx[2]);
+    push(ix0 - 1, rdy[0]); lddy(ix0 + 2, rdy[0]); ldx(ix0 + 1, rx[0]);
+    push(ix0, rdy[1]); lddy(ix0 + 3, rdy[1]); ldx(ix0 + 2, rx[1]);
+    auto step = [&](int i, raw_t (&cdy)[NR], raw_t (&cxr)[R]) {
       push(ix0 + i + 1, cdy);
+      f32x2 xv[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const bool rok = iy0 + r < a.IH;
-        const f32x2 xv = P::up(cx[r]);
-        const f32x2 z = xv * sc + sh;
-        const f32x2 sg = sigmoid2(z);
-        const f32x2 act = rok ? z * sg : splat2(0.f);
-        f32x2 da = splat2(0.f);
+      for (int r = 0; r < R; ++r) xv[r] = P::up(cxr[r]);
+      lddy(ix0 + i + 4, cdy); ldx(ix0 + i + 3, cxr);  // prefetch (clamped)
+      if (i < ncol) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int r = 0; r < R; ++r) {
+          const bool rok = iy0 + r < a.IH;
+          const f32x2 z = xv[r] * sc + sh;
+          const f32x2 sg = sigmoid2(z);
+          const f32x2 act = rok ? z * sg : splat2(0.f);
+          f32x2 da = splat2(0.f);
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const f32x2 d = dyw[r + 2 - ky][2 - kx];
-            da += d * w[ky][kx];
-            dwacc[ky][kx] += d * act;
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const f32x2 d = dyw[r + 2 - ky][2 - kx];
+              da += d * w[ky][kx];
+              dwacc[ky][kx] += d * act;
+            }
+          if (rok) {
+            const f32x2 gv = da * (sg * (splat2(1.0f) + z * (splat2(1.0f) - sg)));
+            P::st(gim + xoff[r] + (long)(ix0 + i) * C, gv);
+            s1 += gv; s2 += gv * (xv[r] - mu);
           }
-        if (rok) {
-          const f32x2 gv = da * (sg * (splat2(1.0f) + z * (splat2(1.0f) - sg)));
-          P::st(gim + xoff[r] + (long)(ix0 + i) * C, gv);
-          s1 += gv; s2 += gv * (xv - mu);
         }
       }
+    };
+    for (int i = 0; i < ncol; i += 3) {
+      step(i, rdy[2], rx[2]);
+      step(i + 1, rdy[0], rx[0]);
+      step(i + 2, rdy[1], rx[1]);
     }
   }
   s2 *= rs;
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwSt
     float t = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-    if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+    if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
   }
 }
 
@@ -489,7 +503,8 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
   __shared__ f32x2 wl[27][32];
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
+  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   const int mode = a.pro.mode;
   for (int e = tid; e < 27 * 32; e += 256) {
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
   if (cvalid && mode != MDS_PRO_NONE) { sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0); }
   const int tstr = a.IH * a.IW * C;   // slice stride (elements)
   for (int k = 0; k < g.spt; ++k) {
-    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    const long strip = ((long)bx * g.spt + k) * 8 + sl;
     if (!cvalid || strip >= g.nstrips) continue;
     const int seg = (int)(strip % g.nseg);
     const long bt = strip / g.nseg;
@@ -588,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
       float t = 0.f;
 #pragma unroll
       for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-      if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
     }
   }
 }
@@ -604,7 +619,8 @@ __global__ __launch_bounds__(256, 2) void dw3_bwd_kernel(mds_dw_bwd_args a, DwSt
   __shared__ float dwl[8][27][64];
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
+  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   for (int e = tid; e < 27 * 32; e += 256) {
     const int t = e >> 5, c = cbeg + 2 * (e & 31);
@@ -621,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void dw3_bwd_kernel(mds_dw_bwd_args a, DwSt
   }
   const int tstr = a.IH * a.IW * C;
   for (int k = 0; k < g.spt; ++k) {
-    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    const long strip = ((long)bx * g.spt + k) * 8 + sl;
     if (!cvalid || strip >= g.nstrips) continue;
     const int seg = (int)(strip % g.nseg);
     const long bt = strip / g.nseg;
@@ -733,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void dw3_bwd_kernel(mds_dw_bwd_args a, DwSt
     float t = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-    if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+    if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
   }
 }
 
@@ -747,7 +763,8 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
   typedef typename P::raw_t raw_t;
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
+  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   const int mode = a.pro.mode;
   f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
@@ -758,7 +775,7 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
     if (mode != MDS_PRO_NONE) { sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0); }
   }
   for (int k = 0; k < g.spt; ++k) {
-    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    const long strip = ((long)bx * g.spt + k) * 8 + sl;
     if (!cvalid || strip >= g.nstrips) continue;
     const int seg = (int)(strip % g.nseg);
     const long bt = strip / g.nseg;
@@ -828,7 +845,7 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
       float t = 0.f;
 #pragma unroll
       for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-      if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
     }
   }
 }
@@ -845,7 +862,8 @@ __global__ __launch_bounds__(256, 2) void dw2s_bwd_kernel(mds_dw_bwd_args a, DwS
   __shared__ float dwl[8][9][64];
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int C = a.C, cbeg = blockIdx.y * 64, c0 = cbeg + 2 * cp;
+  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
+  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
   f32x2 w[3][3], dwacc[3][3], sc = splat2(0.f), sh = splat2(0.f), mu = splat2(0.f), rs = splat2(0.f);
@@ -858,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void dw2s_bwd_kernel(mds_dw_bwd_args a, DwS
     mu = *(const f32x2*)(a.mean + c0); rs = *(const f32x2*)(a.rstd + c0);
   }
   for (int k = 0; k < g.spt; ++k) {
-    const long strip = ((long)blockIdx.x * g.spt + k) * 8 + sl;
+    const long strip = ((long)bx * g.spt + k) * 8 + sl;
     if (!cvalid || strip >= g.nstrips) continue;
     const int seg = (int)(strip % g.nseg);
     const long bt = strip / g.nseg;
@@ -966,7 +984,7 @@ __global__ __launch_bounds__(256, 2) void dw2s_bwd_kernel(mds_dw_bwd_args a, DwS
     float t = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-    if (cbeg + c < C) atomicAdd(a.stats + ((long)(blockIdx.x % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+    if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
   }
 }
 
@@ -984,7 +1002,16 @@ static DwStrips dw_strips(int images, int H, int W, int C, int R, int want_L = 0
   g.nseg = cdiv(W, g.L);
   g.nstrips = (long)images * g.nbands * g.nseg;
   g.spt = 1;   // strips per thread: 2 and 4 measured slower at every layer shape
+  // optional grid order (MDS_KNOB_DW_ORDER = 1): channel chunk fastest - the blocks in flight together then cover ALL
+  // chunks of the same pixels, so a pixel's whole channel row is fetched at about the same time
+  g.swap = mds_knob(MDS_KNOB_DW_ORDER) == 1 ? 1 : 0;   // (measured on MI355X: no difference - these kernels are bound by the SiLU prologue's transcendentals, not by HBM)
   return g;
+}
+
+static dim3 dw_grid(DwStrips& g) {
+  const int sb = cdiv(g.nstrips, 8 * g.spt);
+  if (sb >= 65536) g.swap = 0;   // grid.y limit
+  return g.swap ? dim3(g.nchunks, sb) : dim3(sb, g.nchunks);
 }
 
 extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
@@ -999,20 +1026,20 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_fwd: grid.z");
   if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE(a->pad_t == 1 && a->pad_l == 1 && a->OH == a->IH && a->OW == a->IW, "dw_fwd: stride-1 geometry");
-    const DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6);
-    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6);
+    dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
   if (a->kt == 1 && a->stride == 2 && !mds_switch(MDS_SW_DW_OLD)) {
-    const DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 3);
-    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 3);
+    dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw2s_fwd_kernel<T>, grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
   if (a->kt == 3 && a->T == DW3_T && !mds_switch(MDS_SW_DW_OLD)) {
     DwStrips g = dw_strips(a->N, a->OH, a->OW, a->C, 1, 20);   // strip length measured: 8/16/20/40 -> 38/39/36/63 us
-    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_fwd_kernel<T>, grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
@@ -1253,15 +1280,15 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_bwd: grid.z");
   if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE(a->OH == a->IH && a->OW == a->IW, "dw_bwd: stride-1 geometry");
-    const DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4);
-    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4);
+    dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_bwd_kernel<T, 4>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_bwd");
   }
   if (a->kt == 1 && a->stride == 2 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE((a->pad_t == 0 || a->pad_t == 1), "dw_bwd: pad_t");
-    const DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4, 16, true);
-    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4, 16, true);
+    dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, {
       if (a->pad_t == 0 && a->pad_l == 0) MDS_LAUNCH((dw2s_bwd_kernel<T, 0, 0>), grid, block, 0, stream, *a, g);
       else if (a->pad_t == 0) MDS_LAUNCH((dw2s_bwd_kernel<T, 0, 1>), grid, block, 0, stream, *a, g);
@@ -1272,7 +1299,7 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
   }
   if (a->kt == 3 && a->T == DW3_T && !mds_switch(MDS_SW_DW_OLD)) {
     DwStrips g = dw_strips(a->N, a->IH, a->IW, a->C, 1, 16);   // 8/16/20/40 -> 80/67/82/145 us
-    dim3 grid(cdiv(g.nstrips, 8 * g.spt), g.nchunks), block(256);
+    dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_bwd_kernel<T>, grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_bwd");
   }

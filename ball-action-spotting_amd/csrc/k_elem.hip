@@ -122,16 +122,16 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(mds_se_bwd_reduce_ar
     const T* y = (const T*)a.y + base;
     const T* u = (const T*)a.u + base;
     const long stride = (long)gridDim.x * m.rpb;
-    for (long r0 = (long)blockIdx.x * m.rpb + m.rsub; r0 < a.rows_per_group; r0 += 2 * stride) {
-      RawV8<T> rv[2], ru[2];   // two rows per trip, loads issued together
+    for (long r0 = (long)blockIdx.x * m.rpb + m.rsub; r0 < a.rows_per_group; r0 += 4 * stride) {
+      RawV8<T> rv[4], ru[4];   // four rows per trip, loads issued together
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < 4; ++k) {
         const long rr = r0 + k * stride < a.rows_per_group ? r0 + k * stride : r0;
         rv[k].ld(y + rr * a.C + c0);
         ru[k].ld(u + rr * a.C + c0);
       }
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < 4; ++k) {
         if (r0 + k * stride >= a.rows_per_group) break;
         float v[8], uu[8];
         rv[k].get(v);
@@ -200,16 +200,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_ar
     load8f(a.bn + 2 * a.C + c0, mu);
     load8f(a.bn + 3 * a.C + c0, rs);
     const T* y = (const T*)a.y;
-    for (long row = (long)blockIdx.x * m.rpb + m.rsub; row < a.M; row += (long)gridDim.x * m.rpb) {
-      float v[8], z[8], g[8];
-      load8(y + row * a.C + c0, v);
+    const T* ug = (const T*)a.g.u;
+    // 4 rows per trip, all 8 loads issued together: the grid is capped at 512 blocks (atomic tail), so a single
+    // row in flight per thread left 16 KB per CU outstanding - a latency-bound 3 TB/s
+    const long stride = (long)gridDim.x * m.rpb;
+    for (long row = (long)blockIdx.x * m.rpb + m.rsub; row < a.M; row += 4 * stride) {
+      RawV8<T> ry[4], ru[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) z[j] = v[j] * sc[j] + sh[j];
-      eval_g<T>(a.g, row, c0, a.C, z, g);
+      for (int k = 0; k < 4; ++k) {
+        const long rr = row + k * stride < a.M ? row + k * stride : row;
+        ry[k].ld(y + rr * a.C + c0);
+        ru[k].ld(ug + rr * a.C + c0);
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        acc[0][j] += g[j];
-        acc[1][j] += g[j] * ((v[j] - mu[j]) * rs[j]);
+      for (int k = 0; k < 4; ++k) {
+        const long rr = row + k * stride;
+        if (rr < a.M) {
+          float v[8], z[8], u[8], g[8];
+          ry[k].get(v);
+          ru[k].get(u);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) z[j] = v[j] * sc[j] + sh[j];
+          eval_g_u(a.g, rr, c0, a.C, z, u, g);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc[0][j] += g[j];
+            acc[1][j] += g[j] * ((v[j] - mu[j]) * rs[j]);
+          }
+        }
       }
     }
   }

@@ -41,7 +41,8 @@ const char* mds_last_error(void);
 /* Developer knobs (process-wide, 0 = default).  MDS_KNOB_CONV_BLOCKS caps the grid of the persistent convolution
  * kernel so that the parity tests can drive its multi-tile software pipeline at small sizes. */
 #define MDS_KNOB_CONV_BLOCKS 0
-#define MDS_KNOB_COUNT 1
+#define MDS_KNOB_DW_ORDER 1      /* 1: depthwise kernels take the channel chunk as the fast grid index (A/B switch) */
+#define MDS_KNOB_COUNT 2
 int mds_dev_set(int knob, int value);
 
 /* ---- operand transforms ("prologues"): how a consumer reads a producer's raw conv output.

@@ -193,6 +193,9 @@ def bench_copy():
 
 
 if __name__ == "__main__":
+    for knob, env in ((0, "KB_CONV_BLOCKS"), (1, "KB_DW_ORDER")):
+        if os.environ.get(env):
+            lib.check(lib.fn["dev_set"](knob, int(os.environ[env])), "dev_set")
     todo = sys.argv[1:] or ["copy", "dw_fwd", "dw_bwd", "pw_fwd", "pw_wgrad", "conv_fwd", "conv_wgrad"]
     for t in todo:
         if t == "copy":
