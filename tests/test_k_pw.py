@@ -35,6 +35,8 @@ def _apply_pro(x, mode, scale, shift, gate, rpg):
     (200, 112, 32, 3, False, True),
     (130, 16, 16, 1, True, False),
     (257, 192, 192, 0, True, False),
+    (150, 576, 48, 3, True, True),      # K >= 512 (bf16) / 256 (fp32): 512-byte K chunks, with a K tail (576 = 4.5 x 128)
+    (150, 1160, 192, 0, False, True),   # ... two n-tiles, K % 64 != 0
     (400300, 16, 144, 2, False, True),  # above 400 k rows: the 128-row tile path (GPU only: too slow to simulate)
 ])
 def test_pw_fwd(be, dt, M, K, N, mode, res, stats):
