@@ -43,10 +43,15 @@ class _PlanCache:
     def count(self):
         return sum(len(v) for v in self.plans.values())
 
+    def idle(self):
+        return sum(1 for v in self.plans.values() for p in v if not p.in_flight)
+
     def evict(self, keep_key):
-        """drop least-recently-used idle plans until at most MAX_PLANS remain"""
+        """drop least-recently-used IDLE plans until at most MAX_PLANS of them remain.  Plans that are in flight - held by
+        an autograd graph, or owned by a StreamPredictor for its lifetime - do not count against the budget: they cannot be
+        dropped, and counting them made every later shape of the module re-plan on each call once a predictor held eight."""
         for key in list(self.plans):
-            if self.count() <= MAX_PLANS:
+            if self.idle() <= MAX_PLANS:
                 break
             if key == keep_key:
                 continue

@@ -58,6 +58,21 @@ class StreamPredictor:
         self._built = None
         self.reset_buffers()
 
+    def close(self):
+        """hand the launch plans back to the module's cache (they stay pinned while the predictor lives)"""
+        for c in getattr(self, "plans", {}).values():
+            c["g2d"] = c["gtail"] = None
+            c["p2d"].in_flight = c["ptail"].in_flight = False
+        self.plans = {}
+        self.store = None
+        self._built = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter teardown
+            pass
+
     # ------------------------------------------------------------------ state
     def reset_buffers(self):
         self.frame_tag = [None] * self.nframes

@@ -184,3 +184,29 @@ def test_plan_cache_is_bounded():
     assert prod._cache.count() <= mod.MAX_PLANS
     prod.clear_plans()
     assert prod._cache.count() == 0
+
+
+def test_pinned_plans_do_not_count_against_the_lru_budget():
+    """plans held for a lifetime (a StreamPredictor's) must not make every other shape re-plan on each call"""
+    from mds import module as mod
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    _, prod = _pair(kw)
+    prod.eval()
+    with torch.no_grad():
+        pinned = []
+        for w in range(mod.MAX_PLANS + 2):               # more pinned plans than the whole budget
+            prod.forward_head(torch.rand(1, 1280, 1, 1 + w))
+        for pool in prod._cache.plans.values():
+            for p in pool:
+                p.in_flight = True
+                pinned.append(p)
+        x = torch.rand(1, 1280, 2, 3)
+        prod.forward_head(x)
+        first = [p for pool in prod._cache.plans.values() for p in pool if not p.in_flight]
+        prod.forward_head(x)
+        again = [p for pool in prod._cache.plans.values() for p in pool if not p.in_flight]
+        assert len(first) == 1 and again[0] is first[0], "the idle plan of a repeated shape must be reused, not rebuilt"
+        for p in pinned:                                  # released (StreamPredictor.close()): evictable again
+            p.in_flight = False
+        prod.forward_head(torch.rand(1, 1280, 3, 3))
+        assert prod._cache.idle() <= mod.MAX_PLANS
