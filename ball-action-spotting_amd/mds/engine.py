@@ -207,8 +207,12 @@ class Plan:
         # 0: reduce / finalize / apply kernels everywhere; 1: BN backward folded into every 1x1 GEMM that touches it;
         # 2: only the NARROW layers (the projections' BN3 / BN2: dy formed on load from two narrow tensors, sums in the
         #    epilogue of a GEMM with a narrow output) — the wide ones keep their streaming apply pass.
-        self.fuse_mode = int(os.environ.get("MDS_FUSE_BN_BWD", "0"))
-        self.fuse_bn_bwd = self.fuse_mode >= 1   # developer switch. Measured (round 2): folding BN backward into the register-staged GEMMs costs more than the reduce/apply passes it removes (227 vs 244 windows/s) — off until the GEMM core can absorb it
+        # MDS_FUSE_BN_BWD: 3 (default) = the data-gradient GEMM that produces a block's input gradient also takes the sums of the
+        # BatchNorm backward that consumes it (mds_poststat_t): 22 bn_bwd_reduce launches less, +0.5 % measured.  1 / 2 = dy formed
+        # on load in the GEMMs as well (all layers / narrow layers): measured a net loss in the register-staged GEMM (227 / 236
+        # vs 244 windows/s), kept with their tests.  0 = every reduce and apply is its own launch.
+        self.fuse_mode = int(os.environ.get("MDS_FUSE_BN_BWD", "3"))
+        self.fuse_bn_bwd = self.fuse_mode >= 1
         self.in_flight = False
         self.generation = 0      # bumped by every grad-enabled forward: a stale autograd node must not run
         self.profile = None      # list -> run() brackets every launch with HIP events
@@ -432,12 +436,12 @@ class Plan:
 
         def bwd(seg, dout, nxt_head):
             g3 = gsrc(G_MASK, dout.buf, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout.buf)
-            if fuse:
+            if fuse and self.fuse_mode != 3:
                 # BN3 backward: sums by the producer of dout when that was a 1x1 data-gradient GEMM, dy formed on load
                 dy3 = bn3.backward_fused(self, seg, g3, y3, reduce=dout.reduced is not bn3, frozen=frozen)
-            else:
+            else:       # (mode 3: only the sums move into the producer's epilogue; dy stays materialised)
                 dy3 = self.act(Mout, cout)
-                bn3.backward(self, seg, g3, y3, dy3, frozen=frozen)
+                bn3.backward(self, seg, g3, y3, dy3, reduce=dout.reduced is not bn3, frozen=frozen)
             u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen).buf
             dgate, dpool = self.zero_bwd(groups * mid), self.f32(groups * mid)
             nblk = self.lib.fn["se_bwd_reduce_blocks"](rpg, mid)
@@ -527,7 +531,10 @@ class Plan:
         xenc = cur
 
         def proj_bwd(seg, dfeat, nxt_head):
-            if dfeat.reduced is bnp:      # the 3D tail's last data-gradient GEMM stored g = dfeat*silu'(z) and took the sums
+            if dfeat.reduced is bnp and self.fuse_mode == 3:
+                dyp = self.act(M, cf)
+                bnp.backward(self, seg, gsrc(G_PLAIN, dfeat.buf), yp, dyp, reduce=False)
+            elif dfeat.reduced is bnp:    # the 3D tail's last data-gradient GEMM stored g = dfeat*silu'(z) and took the sums
                 dyp = bnp.backward_fused(self, seg, gsrc(G_PLAIN, dfeat.buf), yp, reduce=False)
             else:
                 dyp = self.act(M, cf)
@@ -591,11 +598,11 @@ class Plan:
                 ga = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True, head=bn1.head(ya, POST_SILU))
                 bn1.backward(self, seg, gsrc(G_PLAIN, ga.buf), ya, dya, reduce=False)
             else:
-                if fuse:      # mode 2: only the narrow BN2 is folded (sums possibly taken by the producer of dout)
+                if fuse and self.fuse_mode != 3:      # mode 2: only the narrow BN2 is folded (sums possibly taken by the producer of dout)
                     dyb = bn2.backward_fused(self, seg, g2, yb, reduce=dout.reduced is not bn2)
                 else:
                     dyb = self.act(M, cout)
-                    bn2.backward(self, seg, g2, yb, dyb)
+                    bn2.backward(self, seg, g2, yb, dyb, reduce=dout.reduced is not bn2)
                 ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
                 bn1.backward(self, seg, gsrc(G_SILU, ua.buf), ya, dya)
             self._conv_wgrad(seg, xin, pro_in, N, IH, IW, cin, OH, OW, mid, blk.stride, pads, dya, blk.conv_exp.weight)

@@ -92,6 +92,37 @@ def _step(model, x, tgt):
     return logits.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
 
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_bn_backward_fusion_modes_match_the_default_path(monkeypatch, mode):
+    """MDS_FUSE_BN_BWD 1 (dy formed on load + sums in the producers' epilogues) and 0 (every reduce / apply its own launch)
+    must give the gradients of the default path (3: only the sums move into the producers) - DropPath masks included"""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.3)
+    _, prod = _pair(kw)
+    prod.train()
+    x = torch.rand(1, 15, 32, 32, generator=torch.Generator().manual_seed(5))
+    tgt = torch.tensor([[0.0, 1.0]])
+    state = copy.deepcopy(prod.state_dict())
+
+    def run():
+        prod.load_state_dict(state)
+        prod.clear_plans()
+        prod._mask_override = None
+        plan = prod._plan(x, "full", 1, 15, 32, 32, True)
+        g = torch.Generator().manual_seed(9)
+        prod._mask_override = (torch.rand(plan._mask_total, generator=g) < plan.mask_keep).float() / plan.mask_keep
+        return _step(prod, x, tgt)
+
+    monkeypatch.delenv("MDS_FUSE_BN_BWD", raising=False)
+    l0, g0 = run()
+    monkeypatch.setenv("MDS_FUSE_BN_BWD", mode)
+    l1, g1 = run()
+    prod._mask_override = None
+    _cmp("logits", l1, l0, 1e-5, 1e-5)
+    floor = 1e-2 * float(np.median([v.abs().max().item() for v in g0.values()]))
+    worst = sorted(((g1[n] - g0[n]).abs().max().item() / max(g0[n].abs().max().item(), floor), n) for n in g0)[::-1]
+    assert worst[0][0] < 2e-3, f"mode {mode}: worst relative grad differences {worst[:6]}"
+
+
 def test_torch_compile_wrap_is_one_opaque_call():
     """scripts/ball_action/train.py:83-86 wraps nn_module in torch.compile: the hot path must stay ONE opaque
     call (no tracing into the planner, no recompiles) and give the eager result, forward and backward."""

@@ -150,6 +150,22 @@ def bench_conv_dgrad():
         timeit(f"conv {tag} (4 launches)", lambda: [lib.call("conv_fwd", a4, stream()) for a4 in four], nbytes, flops)
 
 
+def bench_pw_as_conv():
+    """the 1x1 expansion GEMMs through the persistent convolution kernel (one tap): slab-resident weights, streamed rows"""
+    for (M, K, N, mode, tag) in PW_SHAPES:
+        if mode not in (0, 2) or M % 16:
+            continue
+        x = rnd(M, K); w = rnd(N, K); y = torch.empty(M, N, device=dev, dtype=BF)
+        st = torch.zeros(SLOTS, 2, N, device=dev)
+        sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
+        a = cabi.make("mds_conv_fwd_args", dtype=1, N=1, IH=M // 16, IW=16, Cin=K, OH=M // 16, OW=16, Cout=N, A=M // 16, B=16, oy0=0,
+                      ox0=0, os=1, **{"is": 1}, ntaps=1, dy=[0], dx=[0], wi=[0], wtaps=1, x=x, w=w, y=y, pro=cabi.pro(mode, sc, sh),
+                      residual=None, stats=st)
+        timeit(f"pw via conv_q {tag}", lambda: lib.call("conv_fwd", a, stream()), (M * K + M * N + N * K) * 2, 2 * M * K * N)
+        a2 = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=cabi.pro(mode, sc, sh), residual=None, stats=st)
+        timeit(f"pw_fwd       {tag}", lambda: lib.call("pw_fwd", a2, stream()), (M * K + M * N + N * K) * 2, 2 * M * K * N)
+
+
 def bench_se():
     for (G, R, C) in [(20, 3680, 672), (20, 920, 1152), (20, 3680, 384), (4, 4600, 576)]:
         bench_se1(G, R, C)
@@ -193,7 +209,7 @@ def bench_copy():
 
 
 if __name__ == "__main__":
-    for knob, env in ((0, "KB_CONV_BLOCKS"), (1, "KB_DW_ORDER")):
+    for knob, env in ((0, "KB_CONV_BLOCKS"), (1, "KB_DW_ORDER"), (2, "KB_GEMM8")):
         if os.environ.get(env):
             lib.check(lib.fn["dev_set"](knob, int(os.environ[env])), "dev_set")
     todo = sys.argv[1:] or ["copy", "dw_fwd", "dw_bwd", "pw_fwd", "pw_wgrad", "conv_fwd", "conv_wgrad"]
@@ -206,6 +222,8 @@ if __name__ == "__main__":
             bench_se()
         elif t.startswith("dw"):
             bench_dw(t)
+        elif t == "pw_as_conv":
+            bench_pw_as_conv()
         elif t.startswith("pw"):
             bench_pw(t)
         elif t == "conv_dgrad":
