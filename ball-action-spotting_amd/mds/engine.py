@@ -603,8 +603,14 @@ class Plan:
                 else:
                     dyb = self.act(M, cout)
                     bn2.backward(self, seg, g2, yb, dyb, reduce=dout.reduced is not bn2)
-                ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
-                bn1.backward(self, seg, gsrc(G_SILU, ua.buf), ya, dya)
+                if fuse and self.fuse_mode == 3 and os.environ.get("MDS_POST_SILU", "0") == "1":
+                    # the projection's data-gradient GEMM stores g_a = u_a*silu'(z_a) and takes BN1's sums over it
+                    # (measured: +0.33 ms in the 4 GEMMs for -0.26 ms of reduce launches: a wash, off by default)
+                    ga = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True, head=bn1.head(ya, POST_SILU))
+                    bn1.backward(self, seg, gsrc(G_PLAIN, ga.buf), ya, dya, reduce=False)
+                else:
+                    ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
+                    bn1.backward(self, seg, gsrc(G_SILU, ua.buf), ya, dya)
             self._conv_wgrad(seg, xin, pro_in, N, IH, IW, cin, OH, OW, mid, blk.stride, pads, dya, blk.conv_exp.weight)
             return Grad(self._conv_dgrad(seg, dya, N, IH, IW, cin, mid, blk.stride, blk.conv_exp.weight, pads,
                                          dout.buf if has_skip else None))
