@@ -192,3 +192,29 @@ def test_conv_wgrad(be, dt, N, H, W, Cin, Cout, stride, mode):
                                     pro=cabi.pro(mode, be.t(scale), be.t(shift))))
     be.sync()
     assert_close(dw, ww.grad, dt, scale=(N * OH * OW) ** 0.5, msg="dw")
+
+
+def _rand_cases(n, seed):
+    import random
+    r = random.Random(seed)
+    out = []
+    for _ in range(n):
+        stride = r.choice([1, 1, 2])
+        out.append((r.randint(1, 3), r.randint(5, 70), r.randint(5, 90), 8 * r.randint(1, 17), 16 * r.randint(1, 13), stride, r.choice([0, 1, 2]),
+                    r.choice([0, 0, 3, 7])))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,mode,blocks", _rand_cases(16, 20260928))
+def test_conv_fwd_random_shapes(be, dt, N, H, W, Cin, Cout, stride, mode, blocks):
+    """seeded random layer shapes through whichever kernel the launcher picks (persistent: every N-tile / row-fragment
+    template, K tails; chunked: Cin % 32 != 0, Cout tails), default grid and a few-block grid"""
+    if be.name != "gpu":
+        pytest.skip("GPU only: the simulator is too slow for 32 random layers")
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        test_conv_fwd(be, dt, N, H, W, Cin, Cout, stride, mode)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
