@@ -132,6 +132,9 @@ def load() -> Lib:
     global _LIB
     if _LIB is None:
         _LIB = Lib(HIP_LIB)
+        for kv in filter(None, os.environ.get("MDS_KNOBS", "").split(",")):      # developer A/B switches: "knob=value,..."
+            k, v = kv.split("=")
+            _LIB.check(_LIB.fn["dev_set"](int(k), int(v)), "dev_set")
     return _LIB
 
 
