@@ -778,7 +778,7 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
   const int cot = cdiv(a->Cout, CW_COT);
   // one block per CU (the accumulators take the register file); every block ends with an atomic per
   // filter value, so: two rounds of the chip for the big layers, one for the small (measured)
-  long want = (total >= 4096 ? 512 : 256) / cot;
+  long want = (total >= 4096 ? 512 : 256) / cot;   // (re-measured inside the training step: 64 / 128 lose 12 % / 2 %, 256...1024 are flat)
   if (want < 1) want = 1;
   int tpb = (int)((total + want - 1) / want);
   if (tpb < 1) tpb = 1;

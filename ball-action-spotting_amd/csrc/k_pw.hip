@@ -695,11 +695,14 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   // 2 instead of 3-4 waves/SIMD): the re-reads are L2/Infinity-Cache hits and occupancy matters more.
   const int NT = 128, KT = 64;
   const int tiles = cdiv(a->N, NT) * cdiv(a->K, KT);
-  // Split-M blocks: every block ends with one atomic per output value, so fewer, longer blocks win
-  // until the chip runs dry — measured optimum ~400-500 blocks in total (1024: +25...50 %), except
-  // for the multi-million-row layers, which want <= 2048 rows per block.
-  long want_blocks = 448 / tiles;
+  // Split-M blocks: every block ends with one atomic per output value, so fewer, longer blocks win until the chip runs
+  // dry.  Timed ALONE the optimum is ~400-500 blocks in total (1024: +25...50 %) - but these launches run on the second
+  // stream beside the dependent chain, where every block they hold is a CU slot the critical kernel does not get:
+  // inside the training step 128 blocks in total measured best (448: +0.25 ms per step, 896: +0.8 ms, 32...224: flat).
+  // The multi-million-row layers still want <= 2048 rows per block.
+  long want_blocks = 128 / tiles;
   if (want_blocks < a->M / 2048) want_blocks = a->M / 2048;
+  if (want_blocks < 1) want_blocks = 1;
   long rpb = (a->M + want_blocks - 1) / want_blocks;
   rpb = ((rpb + WG_ROWS - 1) / WG_ROWS) * WG_ROWS;
   if (rpb < 4 * WG_ROWS) rpb = 4 * WG_ROWS;
