@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(mds_stem_wgrad_args a) 
 #define SW_ROWS 8
 #define SW_COLS 32
 #define SW_PITCH 48   // elements: 96 B = 32 B x odd (conflict-free for ds_read_b128 and the tr reads)
-__global__ __launch_bounds__(256, 3) void stem_wgrad_tiled_kernel(mds_stem_wgrad_args a, int tiles_a, int tiles_b, int tiles_per_block) {
+template <bool DYP>
+__global__ __launch_bounds__(256, DYP ? 2 : 3) void stem_wgrad_tiled_kernel(mds_stem_wgrad_args a, int tiles_a, int tiles_b, int tiles_per_block) {
   typedef bf16_t T;
   constexpr int IR = 2 * SW_ROWS + 1;                  // input rows of a tile
   constexpr int NX = IR * 3 * (SW_COLS / 8);           // x staging items: (input row, plane, 8-column group)
@@ -192,7 +193,18 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad_tiled_kernel(mds_stem_wgrad
   T* zrow = dys + SW_ROWS * SW_COLS * SW_PITCH;        // [SW_PITCH] zeros (k = 27..31)
   const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
-  const T* dy = (const T*)a.dy;
+  const T* dy = (const T*)(DYP ? a.dyp.g.u : a.dy);
+  const long ydiff = DYP ? (const T*)a.dyp.y - dy : 0;   // the BatchNorm input y has u's layout
+  // dy = A*g + B*y + D, g = u or u*silu'(y*scale + shift): this thread stages the same 8 channels of every pixel
+  float cA[8], cB[8], cD[8], csc[8], csh[8];
+  if (DYP) {
+    const int c = 8 * (tid & 3), C = a.Cout;
+    if (c < C) {
+      load8f(a.dyp.lin + c, cA); load8f(a.dyp.lin + C + c, cB); load8f(a.dyp.lin + 2 * C + c, cD);
+      load8f(a.dyp.bn + c, csc); load8f(a.dyp.bn + C + c, csh);
+    }
+  }
+  const bool gsilu = DYP && a.dyp.g.mode == MDS_G_SILU;
   if (tid < SW_PITCH) zrow[tid] = 0;
   // this lane's two taps n = 16g + i -> (plane, ky, kx): LDS element offset of its row within the tile image
   int noff[2];
@@ -213,7 +225,8 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad_tiled_kernel(mds_stem_wgrad
 
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 rx[9];
-  RawV8<T> ry[4];
+  RawV8<T> ry[4], ryy[DYP ? 4 : 1];
+  unsigned yok = 0;
   auto origin = [&](long t, int& img, int& oy0, int& ox0) {
     img = (int)(t / (tiles_a * tiles_b));
     const int rem = (int)(t - (long)img * tiles_a * tiles_b);
@@ -246,8 +259,15 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad_tiled_kernel(mds_stem_wgrad
     for (int p = 0; p < 4; ++p) {
       const int it = tid + 256 * p, px = it >> 2, ch = it & 3;
       const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
-      if (oy < a.OH && ox < a.OW && 8 * ch < a.Cout) ry[p].ld(dy + (((long)img * a.OH + oy) * a.OW + ox) * a.Cout + 8 * ch);
+      const bool ok = oy < a.OH && ox < a.OW && 8 * ch < a.Cout;
+      if (ok) ry[p].ld(dy + (((long)img * a.OH + oy) * a.OW + ox) * a.Cout + 8 * ch);
       else ry[p].zero();
+      if (DYP) {
+        if (p == 0) yok = 0;
+        yok |= (ok ? 1u : 0u) << p;
+        if (ok) ryy[p].ld(dy + ydiff + (((long)img * a.OH + oy) * a.OW + ox) * a.Cout + 8 * ch);
+        else ryy[p].zero();
+      }
     }
   };
   if (tl < tl_end) issue(tl);
@@ -264,7 +284,21 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad_tiled_kernel(mds_stem_wgrad
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int it = tid + 256 * p;
-      ry[p].st(dys + (it >> 2) * SW_PITCH + 8 * (it & 3));
+      if (!DYP) {
+        ry[p].st(dys + (it >> 2) * SW_PITCH + 8 * (it & 3));
+      } else {
+        float u[8], yv[8], v[8];
+        ry[p].get(u);
+        ryy[p].get(yv);
+        const bool ok = (yok >> p) & 1u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float g = u[j];
+          if (gsilu) g *= silu_gradf_(yv[j] * csc[j] + csh[j]);
+          v[j] = ok ? cA[j] * g + cB[j] * yv[j] + cD[j] : 0.f;   // pixels past the image contribute nothing (D != 0)
+        }
+        store8(dys + (it >> 2) * SW_PITCH + 8 * (it & 3), v);
+      }
     }
     __syncthreads();
     if (tl + 1 < tl_end) issue(tl + 1);
@@ -314,13 +348,20 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad_tiled_kernel(mds_stem_wgrad
 extern "C" int mds_stem_wgrad(const mds_stem_wgrad_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0, "stem_wgrad: bad dims");
   MDS_REQUIRE(a->Cout % 16 == 0 && a->Cout <= 32, "stem_wgrad: Cout=%d must be 16 or 32", a->Cout);
-  MDS_REQUIRE(a->x && a->dy && a->dw, "stem_wgrad: null pointer");
+  const bool dyp = a->dyp.mode != 0;
+  MDS_REQUIRE(a->x && (a->dy || dyp) && a->dw, "stem_wgrad: null pointer");
+  if (dyp) {
+    MDS_REQUIRE(a->dtype == MDS_BF16 && !mds_switch(MDS_SW_STEM_OLD), "stem_wgrad: the dy prologue is a bf16 feature");
+    MDS_REQUIRE(a->dyp.g.u && a->dyp.y && a->dyp.bn && a->dyp.lin && (a->dyp.g.mode == MDS_G_PLAIN || a->dyp.g.mode == MDS_G_SILU),
+                "stem_wgrad: dy prologue needs u, y, bn, lin and a PLAIN or SILU gradient source");
+  }
   if (a->dtype == MDS_BF16 && !mds_switch(MDS_SW_STEM_OLD)) {
     const int tiles_a = cdiv(a->OH, SW_ROWS), tiles_b = cdiv(a->OW, SW_COLS);
     const long total = (long)a->N * tiles_a * tiles_b;
     const int tpb = (int)cdiv(total, total < 768 ? total : 768);   // three blocks per CU
     const size_t smem = (size_t)((2 * SW_ROWS + 1) * 9 + SW_ROWS * SW_COLS + 1) * SW_PITCH * sizeof(bf16_t);
-    MDS_LAUNCH(stem_wgrad_tiled_kernel, dim3(cdiv(total, tpb)), dim3(256), smem, stream, *a, tiles_a, tiles_b, tpb);
+    if (dyp) MDS_LAUNCH(stem_wgrad_tiled_kernel<true>, dim3(cdiv(total, tpb)), dim3(256), smem, stream, *a, tiles_a, tiles_b, tpb);
+    else MDS_LAUNCH(stem_wgrad_tiled_kernel<false>, dim3(cdiv(total, tpb)), dim3(256), smem, stream, *a, tiles_a, tiles_b, tpb);
     return mds_check_launch("stem_wgrad");
   }
   const long ngroups = (long)a->N * a->OH * ((a->OW + 31) / 32);

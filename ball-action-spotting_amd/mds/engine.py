@@ -501,8 +501,18 @@ class Plan:
         def stem_bwd(seg, u0, nxt_head):
             if fr:
                 return None
+            g0 = gsrc(G_SILU, u0.buf)
+            if self.tdt == torch.bfloat16 and os.environ.get("MDS_STEM_DYP", "1") == "1":
+                # the stem has no data gradient: its BatchNorm-backward apply pass would only feed the weight gradient, which
+                # forms dy = A*u*silu'(z) + B*y + D on load instead (no 0.9 GB apply launch at the very end of the step)
+                bn0.bwd_reduce(self, seg, g0, y0)
+                bn0.bwd_finalize(self, seg)
+                self.op(seg, "stem_wgrad", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
+                        x=self.x_in, dy=None, dw=self.grad(enc.conv_stem.weight),
+                        dyp=dict(_struct="mds_dyp_t", mode=1, g=g0, y=y0, bn=bn0.buf, lin=bn0.lin))
+                return None
             dy0 = self.act(N * OH * OW, 32)
-            bn0.backward(self, seg, gsrc(G_SILU, u0.buf), y0, dy0)
+            bn0.backward(self, seg, g0, y0, dy0)
             self.op(seg, "stem_wgrad", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
                     x=self.x_in, dy=dy0, dw=self.grad(enc.conv_stem.weight))
             return None

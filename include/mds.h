@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 107
+#define MDS_VERSION 108
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -225,6 +225,9 @@ typedef struct {
   const float* x;
   const void* dy; /* [N][OH][OW][Cout] */
   float* dw;      /* [Cout][3][3][3] fp32 (OIHW) */
+  mds_dyp_t dyp;  /* dyp.mode == 1: dy is formed on load from the stem BatchNorm's backward inputs (`dy` ignored):
+                     dy = A*g + B*y + D with g = u (MDS_G_PLAIN) or u*silu'(y*scale + shift) (MDS_G_SILU) - the stem has no
+                     data gradient, so its BatchNorm-backward apply pass would only feed this kernel (bf16 path)          */
 } mds_stem_wgrad_args;
 int mds_stem_wgrad(const mds_stem_wgrad_args* a, mds_stream_t stream);
 

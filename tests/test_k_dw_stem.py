@@ -128,6 +128,39 @@ def test_stem_fwd_wgrad(be, dt, N, H, W):
     assert_close(dw, wq.grad, dt, scale=cnt ** 0.5, msg="dw")
 
 
+@pytest.mark.parametrize("gmode", [cabi.MDS_G_PLAIN, cabi.MDS_G_SILU])
+@pytest.mark.parametrize("N,H,W", [(2, 20, 36), (1, 17, 70)])
+def test_stem_wgrad_forms_dy_on_load(be, gmode, N, H, W):
+    """mds_stem_wgrad with a dy prologue (dy = A*g + B*y + D, g = u or u*silu'(y*scale + shift)) against the same kernel
+    fed the materialised dy (what mds_bn_bwd_apply would have written)"""
+    code, tdt = DT["bf16"]
+    g = gen(H * W + gmode)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, 2)
+    x = torch.rand(N, 3, H, W, generator=g)
+    u = torch.randn(N, OH, OW, 32, generator=g).to(tdt)
+    y = torch.randn(N, OH, OW, 32, generator=g).to(tdt)
+    bn = torch.randn(4, 32, generator=g) * 0.5
+    lin = torch.randn(3, 32, generator=g) * 0.5
+    z = y.float() * bn[0] + bn[1]
+    sg = torch.sigmoid(z)
+    gg = u.float() * (sg * (1 + z * (1 - sg))) if gmode == cabi.MDS_G_SILU else u.float()
+    dy = (lin[0] * gg + lin[1] * y.float() + lin[2]).to(tdt)
+    xd = be.t(x)
+    out = []
+    for fused in (False, True):
+        dw = torch.zeros(32, 3, 3, 3, device=be.device)
+        kw = dict(dtype=code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl, x=xd, dw=dw)
+        if fused:
+            kw.update(dy=None, dyp=cabi.make("mds_dyp_t", mode=1, g=cabi.gsrc(gmode, be.t(u)), y=be.t(y), bn=be.t(bn), lin=be.t(lin)))
+        else:
+            kw.update(dy=be.t(dy))
+        be.call("stem_wgrad", cabi.make("mds_stem_wgrad_args", **kw))
+        be.sync()
+        out.append(dw.cpu())
+    # the fused path multiplies unrounded fp32 dy, the other one bf16-rounded dy: bf16-level agreement
+    assert_close(out[1], out[0], "bf16", scale=(N * OH * OW) ** 0.5, msg="dw")
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_stem_fwd_uint8_ingest(be, dt):
     """raw uint8 frames -> constant pad (src/frames.py:12-31) -> /255 -> kornia hflip for the TTA copies, all
