@@ -17,6 +17,8 @@ def _mk_pro(be, mode, K, groups, g):
 def _apply_pro(x, mode, scale, shift, gate, rpg):
     if mode == 0:
         return x
+    if mode == 4:                      # MDS_PRO_GATE: x is the materialised activation, gate only
+        return x * gate.cpu()[torch.arange(x.shape[0]) // rpg]
     z = x * scale.cpu() + shift.cpu()
     if mode == 1:
         return z
@@ -77,6 +79,7 @@ def test_pw_fwd(be, dt, M, K, N, mode, res, stats):
     (333, 48, 144, 2),
     (700, 112, 32, 3),
     (64, 192, 16, 1),
+    (300, 200, 192, 4),     # 128 < N <= 256: one 256-wide tile (bf16), gate prologue, K tail
 ])
 def test_pw_wgrad(be, dt, M, K, N, mode):
     code, tdt = DT[dt]
