@@ -575,12 +575,22 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
     py[p] = dy + (mbeg + yr[p]) * N + (yok[p] ? n : 0);
   }
   const long xstep = (long)WG_ROWS * K, ystep = (long)WG_ROWS * N;
+  // the squeeze-excite gate row of every staged x item is requested WITH the item (same issue point): loaded inside the
+  // staging loop it cost one exposed L2 round trip per 64-row step - with <= 2 blocks per CU nothing hides it, and it was
+  // most of the gated projections' weight-gradient time (94 us per launch inside the step against 56 us ungated)
+  constexpr bool GATED = PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE;
+  float rg[GATED ? XI : 1][8];
   auto issue = [&](long mb) {
     const int left = (int)(mend - mb);   // rows of this step that exist
 #pragma unroll
     for (int p = 0; p < XI; ++p) {
       if (xok[p] && xr[p] < left) rx[p].ld(px[p]); else rx[p].zero();
       px[p] += xstep;
+      if (GATED) {
+        const long m = mb + xr[p];
+        const int kx = kt0 + 8 * ((tid + 256 * p) % XCH);
+        load8f(a.pro.gate + (long)((unsigned)(m < mend ? m : mbeg) / (unsigned)a.pro.rows_per_group) * K + (kx < K ? kx : 0), rg[p]);
+      }
     }
 #pragma unroll
     for (int p = 0; p < YI; ++p) {
@@ -615,11 +625,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
                 v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
               }
             }
-            if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
-              float g[8];
-              load8f(a.pro.gate + (long)((unsigned)m / (unsigned)a.pro.rows_per_group) * K + kx, g);
+            if (GATED) {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] *= g[j];
+              for (int j = 0; j < 8; ++j) v[j] *= rg[p][j];
             }
           }
           store8(xs + ml * LDX + 8 * xc, v);
