@@ -607,7 +607,7 @@ template <> struct CwCfg<bf16_t> {
 static inline int cw_ldx(int dtype, int Cin) { return dtype == MDS_BF16 ? (Cin == 32 ? 48 : Cin) : Cin + 2; }
 static inline int cw_ldy(int dtype) { return dtype == MDS_BF16 ? CW_COT + 16 : CW_COT + 2; }
 
-template <typename T, int PRO, int CIFR, int COFR>
+template <typename T, int PRO, int CIFR, int COFR, int XL>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, int dymin, int dxmin, int TH, int TW,
                                                          int tiles_a, int tiles_b, int tiles_per_block) {
   typedef typename Frag<T>::type frag_t;
@@ -619,16 +619,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
   T* xs = (T*)smem;            // [TH*TW][LDX]
   T* dys = xs + TH * TW * LDX;  // [128][LDY]
   float* flush = (float*)(dys + 128 * LDY);  // [16][Cin*wtaps] filter-gradient staging
+  float* psc = flush + 16 * Cin * a.wtaps;   // [Cin] prologue scale / shift (a load consumed inside the staging loop would
+  float* psh = psc + Cin;                    //       expose an L2 round trip per item: vmcnt retires in order)
   const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int co0 = blockIdx.y * CW_COT;
   const int cofr = (Cout - co0 >= 16 * COFR) ? COFR : ((Cout - co0) >> 4);
   const int cpp = Cin >> 3;  // 8-channel chunks per pixel
   const int npix = TH * TW;
-  const long total_tiles = (long)a.N * tiles_a * tiles_b;
+  const float rcpp = 1.0f / (float)cpp, rTW = 1.0f / (float)TW;
+  const int tiles_ab = tiles_a * tiles_b;
+  const long total_tiles = (long)a.N * tiles_ab;
   long tl = (long)blockIdx.x * tiles_per_block;
   long tl_end = tl + tiles_per_block;
   if (tl_end > total_tiles) tl_end = total_tiles;
+  if (PRO != MDS_PRO_NONE) {
+    for (int c = tid; c < Cin; c += 256) { psc[c] = a.pro.scale[c]; psh[c] = a.pro.shift[c]; }
+  }
   // unit u = wave + 4k -> (tap u / CIFR, fragment u % CIFR); tap offsets are wave-uniform scalars
   // read ONCE (a per-lane index into the kernel-argument arrays inside the loop compiles to a
   // dependent global load per tap — that alone was 2/3 of this kernel's time)
@@ -650,32 +657,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
 #pragma unroll
     for (int cf = 0; cf < COFR; ++cf) acc[k][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // Register software pipeline: the global loads of tile t+1 are in flight while tile t's MFMAs
-  // run (the kernel used to wait out a full memory latency per tile — it is latency-, not
-  // bandwidth-bound at these thin channel counts).
-  constexpr int XL = 9;  // staging items per thread: stride 2 -> 17x33 pixels x Cin/8 chunks / 256
-  RawV8<T> rx[XL], ry[4];
+  // Register software pipeline: the global loads of tile t+1 are in flight while tile t's MFMAs run.  Loads are never
+  // conditional (clamped addresses, masks applied at the LDS store) and XL is sized to the layer (3 items per thread
+  // for the stride-1 32-channel layers, 9 for the largest stride-2 patch).
   const int nitems = npix * cpp;
   auto tile_origin = [&](long t, int& img, int& a0, int& b0) {
-    img = (int)(t / (tiles_a * tiles_b));
-    const int rem = (int)(t - (long)img * tiles_a * tiles_b);
+    img = (int)(t / tiles_ab);
+    const int rem = (int)(t - (long)img * tiles_ab);
     a0 = (rem / tiles_b) * CV_TA; b0 = (rem % tiles_b) * CV_TB;
   };
-  auto issue = [&](long t) {
+  auto issue = [&](long t, RawV8<T>(&rx)[XL], RawV8<T>(&ry)[4], unsigned& okx, unsigned& oky) {
     int img, a0, b0;
-    tile_origin(t, img, a0, b0);
+    tile_origin(t < tl_end ? t : tl_end - 1, img, a0, b0);   // tiles past the end re-read the last one (never staged)
     const T* x = (const T*)a.x + (long)img * a.IH * a.IW * Cin;
     const T* dy = (const T*)a.dyt + (long)img * a.OH * a.OW * Cout;
+    okx = 0; oky = 0;
 #pragma unroll
     for (int l = 0; l < XL; ++l) {
-      const int it = tid + 256 * l;
-      if (it < nitems) {
-        const int pix = it / cpp, ch = it - pix * cpp;
-        const int ty = pix / TW, tx = pix - ty * TW;
-        const int iy = a0 * a.is + dymin + ty, ix = b0 * a.is + dxmin + tx;
-        if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) rx[l].ld(x + ((long)iy * a.IW + ix) * Cin + 8 * ch);
-        else rx[l].zero();
-      }
+      const int it0 = tid + 256 * l, it = it0 < nitems ? it0 : nitems - 1;
+      const int pix = fdiv(it, rcpp), ch = it - pix * cpp;
+      const int ty = fdiv(pix, rTW), tx = pix - ty * TW;
+      const int iy = a0 * a.is + dymin + ty, ix = b0 * a.is + dxmin + tx;
+      okx |= ((iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) ? 1u : 0u) << l;
+      const int cy = iy < 0 ? 0 : (iy >= a.IH ? a.IH - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.IW ? a.IW - 1 : ix);
+      rx[l].ld(x + (unsigned)((cy * a.IW + cx) * Cin + 8 * ch));
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -683,36 +688,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
       const int pt = it >> 3, ch = it & 7;
       const int aa = a0 + (pt >> 4), bb = b0 + (pt & 15);
       const int co = co0 + 8 * ch;
-      if (aa < a.OH && bb < a.OW && co < Cout) ry[p].ld(dy + ((long)aa * a.OW + bb) * Cout + co);
-      else ry[p].zero();
+      const bool ok = aa < a.OH && bb < a.OW && co < Cout;
+      oky |= (ok ? 1u : 0u) << p;
+      ry[p].ld(dy + (unsigned)(((aa < a.OH ? aa : a.OH - 1) * a.OW + (bb < a.OW ? bb : a.OW - 1)) * Cout + (co < Cout ? co : 0)));
     }
   };
-  if (tl < tl_end) issue(tl);
-  for (; tl < tl_end; ++tl) {
-    int img, a0, b0;
-    tile_origin(tl, img, a0, b0);
-    __syncthreads();
+  auto stage = [&](RawV8<T>(&rx)[XL], RawV8<T>(&ry)[4], unsigned okx, unsigned oky) {
 #pragma unroll
     for (int l = 0; l < XL; ++l) {
       const int it = tid + 256 * l;
       if (it < nitems) {
-        const int pix = it / cpp, ch = it - pix * cpp;
+        const int pix = fdiv(it, rcpp), ch = it - pix * cpp;
+        const bool ok = (okx >> l) & 1u;
         if (PRO == MDS_PRO_NONE) {
+          if (!ok) rx[l].zero();
           CwCfg<T>::putraw(xs + pix * LDX + 8 * ch, rx[l]);
         } else {
-          const int ty = pix / TW, tx = pix - ty * TW;
-          const int iy = a0 * a.is + dymin + ty, ix = b0 * a.is + dxmin + tx;
           float v[8];
           rx[l].get(v);
-          if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {  // zero padding stays zero
-            float sc[8], sh[8];
-            load8f(a.pro.scale + 8 * ch, sc);
-            load8f(a.pro.shift + 8 * ch, sh);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float z = v[j] * sc[j] + sh[j];
-              v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
-            }
+          for (int j = 0; j < 8; ++j) {
+            float z = v[j] * psc[8 * ch + j] + psh[8 * ch + j];
+            z = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
+            v[j] = ok ? z : 0.f;   // zero padding stays zero
           }
           CwCfg<T>::put8(xs + pix * LDX + 8 * ch, v);
         }
@@ -721,10 +719,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int it = tid + 256 * p;
+      if (!((oky >> p) & 1u)) ry[p].zero();
       CwCfg<T>::putraw(dys + (it >> 3) * LDY + 8 * (it & 7), ry[p]);
     }
-    __syncthreads();
-    if (tl + 1 < tl_end) issue(tl + 1);
+  };
+  auto compute = [&]() {
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
       // this 16-lane group's 8 output points: row al, columns ca..ca+3 and cb..cb+3
@@ -742,6 +741,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
           for (int cf = 0; cf < COFR; ++cf) mma16(yf[cf], xf, acc[k][cf]);  // acc[r] = dw[co = 4q + r][ci = i]
         }
       }
+    }
+  };
+  // two register sets when they fit (XL <= 5): the loads of tiles t+1 and t+2 fly while tile t computes
+  constexpr bool TWO = XL <= 5;
+  RawV8<T> rxA[XL], ryA[4], rxB[XL], ryB[4];
+  unsigned oxA = 0, oyA = 0, oxB = 0, oyB = 0;
+  if (TWO) {
+    issue(tl, rxA, ryA, oxA, oyA);
+    issue(tl + 1, rxB, ryB, oxB, oyB);
+    for (; tl < tl_end; tl += 2) {
+      __syncthreads();
+      stage(rxA, ryA, oxA, oyA);
+      __syncthreads();
+      issue(tl + 2, rxA, ryA, oxA, oyA);
+      compute();
+      if (tl + 1 < tl_end) {
+        __syncthreads();
+        stage(rxB, ryB, oxB, oyB);
+        __syncthreads();
+        issue(tl + 3, rxB, ryB, oxB, oyB);
+        compute();
+      }
+    }
+  } else {
+    issue(tl, rxA, ryA, oxA, oyA);
+    for (; tl < tl_end; ++tl) {
+      __syncthreads();
+      stage(rxA, ryA, oxA, oyA);
+      __syncthreads();
+      issue(tl + 1, rxA, ryA, oxA, oyA);
+      compute();
     }
   }
   // flush: per 16-output-channel slab, transpose the accumulators through LDS into the parameter's
@@ -776,6 +806,8 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
   const int TH = (CV_TA - 1) * a->is + eh + 1, TW = (CV_TB - 1) * a->is + ew + 1;
   const int tiles_a = cdiv(a->OH, CV_TA), tiles_b = cdiv(a->OW, CV_TB);
   MDS_REQUIRE(TH * TW * (a->Cin / 8) <= 9 * 256, "conv_wgrad: input patch %dx%dx%d exceeds the staging registers", TH, TW, a->Cin);
+  MDS_REQUIRE((long)a->IH * a->IW * a->Cin < 2147483647L && (long)a->OH * a->OW * a->Cout < 2147483647L, "conv_wgrad: one image must stay below 2^31 elements");
+  const int xl = cdiv(TH * TW * (a->Cin / 8), 256);
   const long total = (long)a->N * tiles_a * tiles_b;
   const int cot = cdiv(a->Cout, CW_COT);
   // one block per CU (the accumulators take the register file); every block ends with an atomic per
@@ -788,10 +820,11 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
   MDS_REQUIRE(a->ntaps <= 9, "conv_wgrad: at most 9 taps");
   const int cifr = a->Cin >> 4;
   const size_t smem_elems = (size_t)TH * TW * cw_ldx(a->dtype, a->Cin) + 128 * cw_ldy(a->dtype);
-  const size_t smem_flush = (size_t)16 * a->Cin * a->wtaps * 4;
-#define CW_GO4(T, PRO, CI, CO)                                                                         \
-  MDS_LAUNCH((conv_wgrad_kernel<T, PRO, CI, CO>), grid, block, smem_elems * sizeof(T) + smem_flush, stream, *a, dymin, \
+  const size_t smem_flush = (size_t)16 * a->Cin * a->wtaps * 4 + 2 * (size_t)a->Cin * 4;
+#define CW_GO5(T, PRO, CI, CO, XL_)                                                                    \
+  MDS_LAUNCH((conv_wgrad_kernel<T, PRO, CI, CO, XL_>), grid, block, smem_elems * sizeof(T) + smem_flush, stream, *a, dymin, \
              dxmin, TH, TW, tiles_a, tiles_b, tpb)
+#define CW_GO4(T, PRO, CI, CO) do { if (xl <= 3) CW_GO5(T, PRO, CI, CO, 3); else if (xl <= 5) CW_GO5(T, PRO, CI, CO, 5); else CW_GO5(T, PRO, CI, CO, 9); } while (0)
 #define CW_GO3(T, PRO, CI) do { if (a->Cout == 16) CW_GO4(T, PRO, CI, 1); else CW_GO4(T, PRO, CI, 4); } while (0)
 #define CW_GO(T, PRO) do { if (cifr == 1) CW_GO3(T, PRO, 1); else if (cifr == 2) CW_GO3(T, PRO, 2); else CW_GO3(T, PRO, 3); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
@@ -802,6 +835,7 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
     }
   });
 #undef CW_GO4
+#undef CW_GO5
 #undef CW_GO3
 #undef CW_GO
   return mds_check_launch("conv_wgrad");
