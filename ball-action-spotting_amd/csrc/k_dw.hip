@@ -254,6 +254,13 @@ MDS_DEV f32x2 sigmoid2(f32x2 z) {
   return (f32x2){fast_rcp(d[0]), fast_rcp(d[1])};
 }
 
+// eval-mode output transform of a channel pair (mds_epi_t): act(acc*scale + shift)
+MDS_DEV f32x2 epi2(f32x2 v, int mode, f32x2 sc, f32x2 sh) {
+  if (mode == MDS_EPI_NONE) return v;
+  v = v * sc + sh;
+  return mode == MDS_EPI_BN_SILU ? v * sigmoid2(v) : v;
+}
+
 struct DwStrips { int nchunks, nseg, L, nbands, spt, swap; long nstrips; };
 
 template <typename T, int R>
@@ -267,6 +274,9 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
   const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   const int mode = a.pro.mode;
+  const int emode = a.epi.mode;
+  f32x2 esc = splat2(1.f), esh = splat2(0.f);
+  if (emode != MDS_EPI_NONE && c0 < a.C) { esc = *(const f32x2*)(a.epi.scale + c0); esh = *(const f32x2*)(a.epi.shift + c0); }
   f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
   f32x2 w[3][3], sc = splat2(1.f), sh = splat2(0.f);
   if (cvalid) {
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) acc += win[r + ky][kx] * w[ky][kx];
           if (oy0 + r < a.OH) {
-            P::st(yim + ((long)r * a.OW + ox0 + o) * C, acc);
+            P::st(yim + ((long)r * a.OW + ox0 + o) * C, epi2(acc, emode, esc, esh));
             s1 += acc; s2 += acc * acc;
           }
         }
@@ -507,6 +517,9 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
   const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   const int mode = a.pro.mode;
+  const int emode = a.epi.mode;
+  f32x2 esc = splat2(1.f), esh = splat2(0.f);
+  if (emode != MDS_EPI_NONE && c0 < a.C) { esc = *(const f32x2*)(a.epi.scale + c0); esh = *(const f32x2*)(a.epi.shift + c0); }
   for (int e = tid; e < 27 * 32; e += 256) {
     const int t = e >> 5, c = cbeg + 2 * (e & 31);
     wl[t][e & 31] = c < C ? (f32x2){a.w[(long)c * 27 + t], a.w[(long)(c + 1) * 27 + t]} : splat2(0.f);
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
           }
 #pragma unroll
       for (int ot = 0; ot < TT; ++ot) {
-        P::st(yim + (long)ot * tstr + (long)(ox0 + o) * C, acc[ot]);
+        P::st(yim + (long)ot * tstr + (long)(ox0 + o) * C, epi2(acc[ot], emode, esc, esh));
         s1 += acc[ot]; s2 += acc[ot] * acc[ot];
       }
     }
@@ -767,6 +780,9 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
   const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   const int mode = a.pro.mode;
+  const int emode = a.epi.mode;
+  f32x2 esc = splat2(1.f), esh = splat2(0.f);
+  if (emode != MDS_EPI_NONE && c0 < a.C) { esc = *(const f32x2*)(a.epi.scale + c0); esh = *(const f32x2*)(a.epi.shift + c0); }
   f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
   f32x2 w[3][3], sc = splat2(1.f), sh = splat2(0.f);
   if (cvalid) {
@@ -831,7 +847,7 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) acc += win[2 * r + ky][kx] * w[ky][kx];
         if (oy0 + r < a.OH) {
-          P::st(yim + ((long)r * a.OW + ox0 + o) * C, acc);
+          P::st(yim + ((long)r * a.OW + ox0 + o) * C, epi2(acc, emode, esc, esh));
           s1 += acc; s2 += acc * acc;
         }
       }
@@ -1024,6 +1040,8 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "dw_fwd: prologue");
   MDS_REQUIRE(a->pro.mode != MDS_PRO_BN_SILU_GATE, "dw_fwd: gate prologue unsupported");
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_fwd: grid.z");
+  MDS_REQUIRE(a->epi.mode == MDS_EPI_NONE || (a->epi.scale && a->epi.shift && !a->stats && !mds_switch(MDS_SW_DW_OLD) && (a->kt == 1 || a->T == DW3_T)),
+              "dw_fwd: an output transform needs scale/shift, no statistics, and a sliding-window kernel (kt == 1, or T == %d)", DW3_T);
   if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE(a->pad_t == 1 && a->pad_l == 1 && a->OH == a->IH && a->OW == a->IW, "dw_fwd: stride-1 geometry");
     DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6);

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
   float acc[1][8] = {{0, 0, 0, 0, 0, 0, 0, 0}};
   if (m.valid) {
     float sc[8], sh[8];
-    load8f(a.scale + c0, sc);
-    load8f(a.shift + c0, sh);
+    const bool prebn = a.scale != 0;    // raw conv output: BN + SiLU here; else y already is the activation (mds_epi_t producer)
+    if (prebn) { load8f(a.scale + c0, sc); load8f(a.shift + c0, sh); }
     const T* y = (const T*)a.y + (long)blockIdx.y * a.rows_per_group * a.C;
     T* act = a.act ? (T*)a.act + (long)blockIdx.y * a.rows_per_group * a.C : (T*)0;
     // 4 rows per trip: the loads are issued together (a single 16-byte load in flight per thread
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
           float v[8];
           raw[k].get(v);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { v[j] = siluf_(v[j] * sc[j] + sh[j]); acc[0][j] += v[j]; }
+          for (int j = 0; j < 8; ++j) { if (prebn) v[j] = siluf_(v[j] * sc[j] + sh[j]); acc[0][j] += v[j]; }
           if (act) store8(act + rr * a.C + c0, v);
         }
       }

@@ -30,8 +30,10 @@ template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 // PRO == PW_PRO_DY: the x operand is dy = A*g + B*y + D formed on load (mds_dyp_t); POST: BatchNorm-backward
 // sums of the NEXT layer over the output tile in the epilogue (mds_poststat_t).
 #define PW_PRO_DY 5
-template <typename T, int PRO, int WN, int BM, bool POST>
-__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || POST ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+// TAIL: 0 = plain epilogue, 1 = POST (BatchNorm-backward sums of the next layer, mds_poststat_t), 2 = EPI (mds_epi_t)
+template <typename T, int PRO, int WN, int BM, int TAIL>
+__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || TAIL == 1 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+  constexpr bool POST = TAIL == 1, EPI = TAIL == 2;
   typedef typename Frag<T>::type frag_t;
   constexpr int KC = PwCfg<T>::KC, LD = PwCfg<T>::LD, VPR = KC / 8, RPP = 256 / VPR, NL = BM / RPP;
   constexpr int BN = 64 * WN, MFW = (WN == 2 ? BM / 32 : BM / 64), NLW = BN / RPP;   // tile columns, m-fragments per wave, filter rows per thread
@@ -193,6 +195,15 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       }
       __syncthreads();
     }
+    if (EPI) {                   // scale / shift of the tile's columns
+      __syncthreads();
+      if (tid < BN) {
+        const int n = n0 + tid;
+        pbn[tid] = n < N ? a.epi.scale[n] : 0.f;
+        pbn[BN + tid] = n < N ? a.epi.shift[n] : 0.f;
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int mf = 0; mf < MFW; ++mf) {
       const long m = m0 + 16 * MFW * wm + 16 * mf + i;
@@ -203,6 +214,18 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[nf][r] = acc[mf][nf][r];
+      if (EPI) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          const float* pc = pbn + 64 * wn + 16 * nf + 4 * q;
+          const f32x4 sc = *(const f32x4*)pc, sh = *(const f32x4*)(pc + BN);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = v[nf][r] * sc[r] + sh[r];
+            v[nf][r] = a.epi.mode == MDS_EPI_BN_SILU ? siluf_(z) : z;
+          }
+        }
+      }
       if (a.residual && ok) {
         const T* rrow = (const T*)a.residual + m * N + n0 + 64 * wn + 4 * q;
 #pragma unroll
@@ -281,6 +304,11 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
                 "pw_fwd: dy prologue takes PLAIN or MASK gradient sources (SILU is folded upstream by MDS_POST_SILU)");
   }
   const bool post = a->post.mode != MDS_POST_NONE;
+  const bool epi = a->epi.mode != MDS_EPI_NONE;
+  if (epi) {
+    MDS_REQUIRE(a->epi.scale && a->epi.shift && !a->stats && !post && !dy, "pw_fwd: an output transform needs scale/shift and excludes statistics, post statistics and the dy prologue");
+    MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE, "pw_fwd: an output transform takes the NONE or GATE prologue (its producer already applied BatchNorm + SiLU)");
+  }
   if (post) {
     MDS_REQUIRE(a->post.y && a->post.bn && a->post.stats && !a->stats, "pw_fwd: post statistics need y, bn, stats (and no forward stats)");
     MDS_REQUIRE(a->post.mode != MDS_POST_MASK || (a->post.mask && a->post.rows_per_group > 0), "pw_fwd: post mask");
@@ -298,19 +326,20 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   int gy = 1;
   if (nt > 1) { gy = cdiv(1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
   dim3 grid(mt, gy), block(256);
-#define PW_GO2(T, PRO, POST) \
+#define PW_GO2(T, PRO, TAIL_) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T); \
-       if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, POST>), grid, block, smem, stream, *a); \
-       else if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 128, POST>), grid, block, smem, stream, *a); \
-       else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1, 128, POST>), grid, block, smem, stream, *a); } while (0)
-#define PW_GO(T, PRO) PW_GO2(T, PRO, false)
-#define PW_GODY(T, POST) \
+       if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_>), grid, block, smem, stream, *a); \
+       else if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 128, TAIL_>), grid, block, smem, stream, *a); \
+       else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1, 128, TAIL_>), grid, block, smem, stream, *a); } while (0)
+#define PW_GO(T, PRO) PW_GO2(T, PRO, 0)
+#define PW_GODY(T, TAIL_) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T); \
-       if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 2, 64, POST>), grid, block, smem, stream, *a); \
-       else MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 1, 128, POST>), grid, block, smem, stream, *a); } while (0)
+       if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 2, 64, TAIL_>), grid, block, smem, stream, *a); \
+       else MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 1, 128, TAIL_>), grid, block, smem, stream, *a); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
-    if (dy) { if (post) PW_GODY(T, true); else PW_GODY(T, false); }
-    else if (post) PW_GO2(T, MDS_PRO_NONE, true);
+    if (dy) { if (post) PW_GODY(T, 1); else PW_GODY(T, 0); }
+    else if (post) PW_GO2(T, MDS_PRO_NONE, 1);
+    else if (epi) { if (a->pro.mode == MDS_PRO_GATE) PW_GO2(T, MDS_PRO_GATE, 2); else PW_GO2(T, MDS_PRO_NONE, 2); }
     else switch (a->pro.mode) {
       case MDS_PRO_NONE: PW_GO(T, MDS_PRO_NONE); break;
       case MDS_PRO_AFFINE: PW_GO(T, MDS_PRO_AFFINE); break;

@@ -31,6 +31,7 @@ from .cabi import MDS_STAT_SLOTS as SLOTS
 PRO_NONE, PRO_AFFINE, PRO_BN_SILU, PRO_BN_GATE, PRO_GATE = 0, 1, 2, 3, 4
 G_PLAIN, G_SILU, G_SE, G_MASK = 0, 1, 2, 3
 POST_NONE, POST_PLAIN, POST_MASK, POST_SILU = 0, 1, 2, 3
+EPI_NONE, EPI_AFFINE, EPI_BN_SILU = 0, 1, 2
 
 
 class Grad:
@@ -213,6 +214,8 @@ class Plan:
         # vs 244 windows/s), kept with their tests.  0 = every reduce and apply is its own launch.
         self.fuse_mode = int(os.environ.get("MDS_FUSE_BN_BWD", "3"))
         self.fuse_bn_bwd = self.fuse_mode >= 1
+        # inference plans (eval-mode BatchNorm, no gradient): producers store activated outputs (mds_epi_t)
+        self.eval_epilogues = (not training) and (not need_grad) and os.environ.get("MDS_EVAL_EPI", "1") == "1"
         self.in_flight = False
         self.generation = 0      # bumped by every grad-enabled forward: a stale autograd node must not run
         self.profile = None      # list -> run() brackets every launch with HIP events
@@ -401,6 +404,39 @@ class Plan:
                 residual=residual, stats=None, **extra)
         return Grad(dx, head["bn"] if head is not None else None)
 
+    def _ir_block_eval(self, fseg, blk, bn1, bn2, bn3, xin, N, T, IH, IW, OH, OW, pt, pl, stride, groups, has_skip, kt):
+        """Inference form of the inverted-residual block: the BatchNorm coefficients are known before any
+        producer runs, so every producer stores its ACTIVATED output (mds_epi_t) - no BN+SiLU prologue in the consumers
+        (the depthwise kernel re-evaluated it 1.33x per element), no activation copy in the pooling pass, no bn_res launch."""
+        cin, mid, cout = blk.cin, blk.mid, blk.cout
+        Min, Mout = N * T * IH * IW, N * T * OH * OW
+        rpg = Mout // groups
+        for bn in (bn1, bn2, bn3):
+            bn.finalize(self, fseg)         # -> the plan's eval-BatchNorm table (one launch per forward)
+        def epi(bn, mode):
+            return dict(_struct="mds_epi_t", mode=mode, scale=bn.scale, shift=bn.shift)
+        a1 = self.act(Min, mid)
+        self.op(fseg, "pw_fwd", dtype=self.code, M=Min, K=cin, N=mid, x=xin, w=self.pack(blk.conv_pw.weight, cabi.MDS_PACK_OI, mid, cin, 1),
+                y=a1, pro=dict(mode=0), residual=None, stats=None, epi=epi(bn1, EPI_BN_SILU))
+        a2 = self.act(Mout, mid)
+        self.op(fseg, "dw_fwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
+                pad_l=pl, kt=kt, x=a1, w=P(blk.conv_dw.weight), y=a2, pro=dict(mode=0), stats=None, epi=epi(bn2, EPI_BN_SILU))
+        R = blk.se.rd
+        pooled, hidden, gate = self.zero_fwd(groups * mid), self.f32(groups * R), self.f32(groups * mid)
+        self.op(fseg, "se_pool", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, y=a2, scale=None, shift=None,
+                pooled=pooled, act=None)
+        se = blk.se
+        w2t = self.pack(se.conv_expand.weight, cabi.MDS_PACK_IO_F32, mid, R, 1)
+        self.op(fseg, "se_fc_fwd", groups=groups, C=mid, R=R, pooled=pooled, w1=P(se.conv_reduce.weight),
+                b1=P(se.conv_reduce.bias), w2=P(se.conv_expand.weight), b2=P(se.conv_expand.bias), hidden=hidden, gate=gate,
+                w2t=w2t)
+        xout = self.act(Mout, cout)
+        self.op(fseg, "pw_fwd", dtype=self.code, M=Mout, K=mid, N=cout, x=a2,
+                w=self.pack(blk.conv_pwl.weight, cabi.MDS_PACK_OI, cout, mid, 1), y=xout,
+                pro=dict(mode=PRO_GATE, scale=None, shift=None, gate=gate, rows_per_group=rpg),
+                residual=xin if has_skip else None, stats=None, epi=epi(bn3, EPI_AFFINE))
+        return xout, OH, OW
+
     # -- inverted-residual block (2D: T=1, kt=1 ; 3D: kt=3), shared by encoder stages 3-5 and conv3d_encoder
     def _ir_block(self, fseg, recs, blk, bn1m, bn2m, bn3m, xin, N, T, IH, IW, stride, groups, has_skip, frozen):
         cin, mid, cout = blk.cin, blk.mid, blk.cout
@@ -409,6 +445,8 @@ class Plan:
         Min, Mout = N * T * IH * IW, N * T * OH * OW
         rpg = Mout // groups
         bn1, bn2, bn3 = BNL(self, bn1m, mid, Min), BNL(self, bn2m, mid, Mout), BNL(self, bn3m, cout, Mout)
+        if self.eval_epilogues and (kt == 1 or T == 5):
+            return self._ir_block_eval(fseg, blk, bn1, bn2, bn3, xin, N, T, IH, IW, OH, OW, pt, pl, stride, groups, has_skip, kt)
         y1 = self._pw(fseg, xin, Min, cin, mid, blk.conv_pw.weight, stats_bn=bn1)
         y2 = self.act(Mout, mid)
         wdw = P(blk.conv_dw.weight)

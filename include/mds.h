@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 108
+#define MDS_VERSION 109
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -112,6 +112,19 @@ typedef struct {
   float* stats;        /* [SLOTS][2][N] caller-zeroed: sum g, sum g*xhat */
 } mds_poststat_t;
 
+/* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
+ * the predictor): the producer stores act(acc*scale[c] + shift[c]) instead of the raw convolution output, so no consumer
+ * re-evaluates BN + SiLU while loading (the depthwise kernels do that 1.33x per element, halo included) and the
+ * block-output pass (mds_bn_res) disappears into the projection's epilogue.  mode 0 = raw output (training). */
+#define MDS_EPI_NONE 0
+#define MDS_EPI_AFFINE 1      /* y = acc*scale + shift (+ residual)          */
+#define MDS_EPI_BN_SILU 2     /* y = silu(acc*scale + shift) (+ residual)    */
+typedef struct {
+  int mode;
+  const float* scale; /* [C] */
+  const float* shift; /* [C] */
+} mds_epi_t;
+
 /* ---- K4: 1x1 convolution = GEMM  y[M][N] = pro(x)[M][K] * w[N][K]^T  (+ residual)
  * replaces nn.Conv2d/Conv3d k=1 at multidim_stacker.py:106,120,179-183,199-203 and timm
  * conv_pw/conv_pwl; also used as its own data-gradient (w = transposed pack).                  */
@@ -128,6 +141,7 @@ typedef struct {
   mds_dyp_t xdy;        /* data-gradient use: xdy.mode == 1 -> the x operand is dy formed on load
                            (channels = K; `x` ignored, pro must be NONE)                         */
   mds_poststat_t post;  /* data-gradient use: BN-backward sums of the NEXT layer in the epilogue */
+  mds_epi_t epi;        /* eval-mode output transform (no statistics, no post, no dy prologue with it) */
 } mds_pw_fwd_args;
 int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream);
 
@@ -246,6 +260,7 @@ typedef struct {
   void* y;
   mds_pro_t pro;
   float* stats;
+  mds_epi_t epi;       /* eval-mode output transform (sliding-window kernels: kt == 1, or kt == 3 with T == 5) */
 } mds_dw_fwd_args;
 int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream);
 
@@ -325,7 +340,7 @@ typedef struct {
   long rows_per_group;
   int C;
   const void* y;
-  const float* scale;
+  const float* scale;   /* NULL (with shift): y already IS the activation (producer with an mds_epi_t) */
   const float* shift;
   float* pooled;  /* [groups][C], caller-zeroed (atomic accumulation of sums/rows) */
   void* act;      /* optional [rows][C]: the activation silu(bn(y)) is also written out, so that the

@@ -96,6 +96,26 @@ def test_dw_fwd_bwd(be, dt, N, T, H, W, C, stride, kt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,T,H,W,C,stride,kt", [c for c in DW_CASES if c[6] == 1 or c[1] == 5])
+def test_dw_fwd_output_transform(be, dt, N, T, H, W, C, stride, kt):
+    """inference form: the input already is an activation (no prologue), the output is stored as silu(bn(y)) (mds_epi_t)"""
+    code, tdt = DT[dt]
+    g = gen(H * W + C + kt + 7)
+    x = torch.randn(N, C, T, H, W, generator=g).to(tdt)
+    w = torch.randn(C, 1, kt, 3, 3, generator=g) * 0.3
+    esc = 1 + 0.3 * torch.randn(C, generator=g); esh = 0.4 * torch.randn(C, generator=g)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
+    pads = (geo.same_pad(H, stride), geo.same_pad(W, stride)) if stride == 2 else ((1, 1), (1, 1))
+    ref = F.silu(dw_ref(x.float(), w, stride, kt, pads) * esc.view(1, -1, 1, 1, 1) + esh.view(1, -1, 1, 1, 1))
+    y = torch.full((N, T, OH, OW, C), float("nan")).to(tdt).to(be.device)
+    be.call("dw_fwd", cabi.make("mds_dw_fwd_args", dtype=code, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=stride, pad_t=pt,
+                                pad_l=pl, kt=kt, x=be.t(to_rows(x)), w=be.t(w.view(C, kt * 9)), y=y, pro=cabi.pro(0), stats=None,
+                                epi=cabi.make("mds_epi_t", mode=2, scale=be.t(esc), shift=be.t(esh))))
+    be.sync()
+    assert_close(y, to_rows(ref), dt, msg="y")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("N,H,W", [(2, 20, 36), (1, 17, 23), (3, 6, 70)])
 def test_stem_fwd_wgrad(be, dt, N, H, W):
     code, tdt = DT[dt]

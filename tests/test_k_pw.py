@@ -74,6 +74,35 @@ def test_pw_fwd(be, dt, M, K, N, mode, res, stats):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,N,pmode,emode,res", [(300, 48, 144, 0, 2, False), (200, 112, 32, 4, 1, True), (130, 192, 192, 0, 2, False)])
+def test_pw_fwd_output_transform(be, dt, M, K, N, pmode, emode, res):
+    """mds_epi_t: y = act(acc*scale + shift) (+ residual) - the inference plans' producers store activated outputs"""
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(M + N + emode)
+    rpg = 97
+    groups = (M + rpg - 1) // rpg
+    x = torch.randn(M, K, generator=g).to(tdt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(tdt)
+    scale, shift, gate = _mk_pro(be, pmode, K, groups, g)
+    esc = 1.0 + 0.3 * torch.randn(N, generator=g); esh = 0.5 * torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g).to(tdt) if res else None
+    y = torch.full((M, N), float("nan")).to(tdt).to(be.device)
+    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=be.t(x), w=be.t(w), y=y,
+                                pro=cabi.pro(pmode, scale, shift, gate, rpg), residual=be.t(r) if res else None, stats=None,
+                                epi=cabi.make("mds_epi_t", mode=emode, scale=be.t(esc), shift=be.t(esh))))
+    be.sync()
+    a = _apply_pro(x.float(), pmode, scale, shift, gate, rpg)
+    if dt == "bf16":
+        a = a.to(tdt).float()
+    ref = (a @ w.float().t()) * esc + esh
+    if emode == 2:
+        ref = F.silu(ref)
+    if res:
+        ref = ref + r.float()
+    assert_close(y, ref, dt, msg="y")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,K,N,mode", [
     (500, 32, 64, 0),
     (333, 48, 144, 2),
