@@ -307,7 +307,7 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   const bool epi = a->epi.mode != MDS_EPI_NONE;
   if (epi) {
     MDS_REQUIRE(a->epi.scale && a->epi.shift && !a->stats && !post && !dy, "pw_fwd: an output transform needs scale/shift and excludes statistics, post statistics and the dy prologue");
-    MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE, "pw_fwd: an output transform takes the NONE or GATE prologue (its producer already applied BatchNorm + SiLU)");
+    MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || a->pro.mode == MDS_PRO_BN_SILU, "pw_fwd: an output transform takes the NONE, GATE or BN_SILU prologue");
   }
   if (post) {
     MDS_REQUIRE(a->post.y && a->post.bn && a->post.stats && !a->stats, "pw_fwd: post statistics need y, bn, stats (and no forward stats)");
@@ -339,7 +339,7 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     if (dy) { if (post) PW_GODY(T, 1); else PW_GODY(T, 0); }
     else if (post) PW_GO2(T, MDS_PRO_NONE, 1);
-    else if (epi) { if (a->pro.mode == MDS_PRO_GATE) PW_GO2(T, MDS_PRO_GATE, 2); else PW_GO2(T, MDS_PRO_NONE, 2); }
+    else if (epi) { if (a->pro.mode == MDS_PRO_GATE) PW_GO2(T, MDS_PRO_GATE, 2); else if (a->pro.mode == MDS_PRO_BN_SILU) PW_GO2(T, MDS_PRO_BN_SILU, 2); else PW_GO2(T, MDS_PRO_NONE, 2); }
     else switch (a->pro.mode) {
       case MDS_PRO_NONE: PW_GO(T, MDS_PRO_NONE); break;
       case MDS_PRO_AFFINE: PW_GO(T, MDS_PRO_AFFINE); break;

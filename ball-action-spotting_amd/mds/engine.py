@@ -332,9 +332,16 @@ class Plan:
             self.dfeat = gout.buf if (self.kind == "tail" and gout is not None) else None   # gradient wrt the (b,S,h,w,192) features
 
     # -- helpers emitting a conv + its BN finalize
-    def _pw(self, seg, x, M, K, N_, wparam, pro=None, stats_bn=None, residual=None, wt=None):
+    def _pw(self, seg, x, M, K, N_, wparam, pro=None, stats_bn=None, residual=None, wt=None, epi_mode=None):
+        """epi_mode (inference plans only): the output is stored as act(bn(y)) (+ residual), mds_epi_t"""
         y = self.act(M, N_)
         w = wt if wt is not None else self.pack(wparam, cabi.MDS_PACK_OI, N_, K, 1)
+        if epi_mode is not None:
+            assert self.eval_epilogues and stats_bn is not None
+            stats_bn.finalize(self, seg)      # eval table
+            self.op(seg, "pw_fwd", dtype=self.code, M=M, K=K, N=N_, x=x, w=w, y=y, pro=pro or dict(mode=0), residual=residual,
+                    stats=None, epi=dict(_struct="mds_epi_t", mode=epi_mode, scale=stats_bn.scale, shift=stats_bn.shift))
+            return y
         self.op(seg, "pw_fwd", dtype=self.code, M=M, K=K, N=N_, x=x, w=w, y=y, pro=pro or dict(mode=0),
                 residual=residual, stats=stats_bn.stats if stats_bn is not None else None)
         if stats_bn is not None:
@@ -572,6 +579,9 @@ class Plan:
         M, cf = N * ch * cw, m.num_3d_features
         cenc = enc.feature_info[-1]["num_chs"]
         bnp = BNL(self, m.conv2d_projection[1], cf, M)
+        if self.eval_epilogues:          # inference: BN + SiLU in the projection's epilogue
+            feat = self._pw("f2d", cur, M, cenc, cf, m.conv2d_projection[0].weight, stats_bn=bnp, epi_mode=EPI_BN_SILU)
+            return feat, ch, cw
         yp = self._pw("f2d", cur, M, cenc, cf, m.conv2d_projection[0].weight, stats_bn=bnp)
         feat = self.act(M, cf)
         self.op("f2d", "bn_res", dtype=self.code, M=M, C=cf, y=yp, scale=bnp.scale, shift=bnp.shift, act=1, mask=None,
@@ -623,9 +633,13 @@ class Plan:
         ya, bn1, OH, OW, pads = self._conv("f2d", xin, pro_in, N, IH, IW, cin, mid, blk.stride, blk.conv_exp.weight, blk.bn1)
         M = N * OH * OW
         bn2 = BNL(self, blk.bn2, cout, M)
-        yb = self._pw("f2d", ya, M, mid, cout, blk.conv_pwl.weight, pro=bn1.pro(), stats_bn=bn2)
         has_skip = blk.has_skip
         assert not has_skip or xin_bn is None
+        if self.eval_epilogues:          # inference: BN2 + shortcut in the projection's epilogue, no bn_res launch
+            xout = self._pw("f2d", ya, M, mid, cout, blk.conv_pwl.weight, pro=bn1.pro(), stats_bn=bn2,
+                            residual=xin if has_skip else None, epi_mode=EPI_AFFINE)
+            return xout, OH, OW       # (inference plans have no backward closures)
+        yb = self._pw("f2d", ya, M, mid, cout, blk.conv_pwl.weight, pro=bn1.pro(), stats_bn=bn2)
         mask = self.mask(N, blk.dpr) if has_skip else None
         rpg = OH * OW
         xout = self.act(M, cout)
