@@ -13,6 +13,7 @@
 #include "gemm.h"
 
 #define CV_TB 16
+#define CV_TAPPAD 12  /* MDS_MAX_TAPS rounded up so the float tables after the tap tables stay 16-byte aligned */
 #define CV_BN 64
 
 template <typename T> struct CvLd;   // LDS pitch of one staged pixel / weight row: 32 channels + 16 B
@@ -33,7 +34,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
   T* xs = (T*)smem;                                    // [npix][LD]   32-channel chunk of the patch
   T* ws = xs + npix * LD;                              // [tg taps][BN][LD]
   int* toff = (int*)(ws + tg * BN * LD);               // [ntaps] LDS element offset of each tap
-  int* twi = toff + MDS_MAX_TAPS;                      // [ntaps] weight slot of each tap
+  int* twi = toff + CV_TAPPAD;                         // [ntaps] weight slot of each tap (tables padded: pes stays 16-byte aligned)
+  float* pes = (float*)(twi + CV_TAPPAD);              // [BN] output-transform scale / shift of the current N-tile (mds_epi_t)
+  float* peh = pes + BN;
+  const int emode = a.epi.mode;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
@@ -57,6 +61,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
   for (int n0 = 0; n0 < Cout; n0 += BN) {
     const int nfr = (Cout - n0 >= BN) ? NFR : ((Cout - n0) >> 4);
     const int wrows = nfr * 16;
+    if (emode != MDS_EPI_NONE && tid < BN) {   // (visible after the first stage barrier; the previous N-tile ended with one)
+      pes[tid] = n0 + tid < Cout ? a.epi.scale[n0 + tid] : 0.f;
+      peh[tid] = n0 + tid < Cout ? a.epi.shift[n0 + tid] : 0.f;
+    }
     f32x4 acc[MF][NFR];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
@@ -201,6 +209,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
         if (nf < nfr && valid) {
           const int n = n0 + 16 * nf + 4 * q;
           float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
+          if (emode != MDS_EPI_NONE) {
+            const f32x4 es = *(const f32x4*)(pes + 16 * nf + 4 * q), eh = *(const f32x4*)(peh + 16 * nf + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float z = v[r] * es[r] + eh[r];
+              v[r] = emode == MDS_EPI_BN_SILU ? siluf_(z) : z;
+            }
+          }
           if (a.residual) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rres[mf][nf].get(r);
@@ -265,7 +281,9 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
   float* st_ss = st_s + BNQ;
   float* psc = st_ss + BNQ;                // [Cin] prologue scale / shift
   float* psh = psc + Cin;
-  int* ktab = (int*)(psh + Cin);           // [KS*4] LDS offset (tap shift + channel) of each 8-wide k chunk
+  float* pes = psh + Cin;                  // [BNQ] output-transform scale / shift (mds_epi_t)
+  float* peh = pes + BNQ;
+  int* ktab = (int*)(peh + BNQ);           // [KS*4] LDS offset (tap shift + channel) of each 8-wide k chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.y * BNQ;
@@ -299,6 +317,11 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
     for (int c = tid; c < Cin; c += 256) { psc[c] = a.pro.scale[c]; psh[c] = a.pro.shift[c]; }
   }
   const bool silu = a.pro.mode == MDS_PRO_BN_SILU;
+  const int emode = a.epi.mode;
+  if (emode != MDS_EPI_NONE && tid < BNQ) {
+    pes[tid] = n0 + tid < Cout ? a.epi.scale[n0 + tid] : 0.f;
+    peh[tid] = n0 + tid < Cout ? a.epi.shift[n0 + tid] : 0.f;
+  }
 
   const long total_tiles = (long)a.N * tiles_ab;
   long tl = (long)blockIdx.x * gq.tpb;
@@ -397,6 +420,14 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
           if (nf < nfr && valid) {
             const int n = n0 + 16 * nf + 4 * q;
             float v[4] = {acc[mf][nf][0], acc[mf][nf][1], acc[mf][nf][2], acc[mf][nf][3]};
+            if (emode != MDS_EPI_NONE) {
+              const f32x4 es = *(const f32x4*)(pes + 16 * nf + 4 * q), eh = *(const f32x4*)(peh + 16 * nf + 4 * q);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float z = v[r] * es[r] + eh[r];
+                v[r] = emode == MDS_EPI_BN_SILU ? siluf_(z) : z;
+              }
+            }
             store4(y + row * Cout + n, v);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[r]; pss[nf * 4 + r] += v[r] * v[r]; }
@@ -460,6 +491,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_AFFINE || a->pro.mode == MDS_PRO_BN_SILU, "conv_fwd: prologue mode");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "conv_fwd: prologue needs scale/shift");
   MDS_REQUIRE(a->oy0 + (a->A - 1) * a->os < a->OH && a->ox0 + (a->B - 1) * a->os < a->OW, "conv_fwd: sub-grid exceeds output");
+  MDS_REQUIRE(a->epi.mode == MDS_EPI_NONE || (a->epi.scale && a->epi.shift && !a->stats), "conv_fwd: an output transform needs scale/shift and excludes statistics");
   int dymin, dxmin;
   const int eh = tap_extent(a->dy, a->ntaps, &dymin), ew = tap_extent(a->dx, a->ntaps, &dxmin);
   const int TA = a->is == 1 ? 16 : 8;
@@ -492,7 +524,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
           if (!nf || !mf) continue;
           const int th = (4 * mf - 1) * a->is + eh + 1, tw = (CV_TB - 1) * a->is + ew + 1;
           const size_t sm = ((size_t)th * tw * cvp_pitch_h(a->Cin, esz) + (size_t)16 * nf * cvp_pitch_h(KS * 32, esz)) * esz +
-                            2 * 16 * nf * sizeof(float) + 2 * (size_t)a->Cin * sizeof(float) + (size_t)KS * 16;
+                            4 * 16 * nf * sizeof(float) + 2 * (size_t)a->Cin * sizeof(float) + (size_t)KS * 16;
           if (th * tw * (a->Cin / 8) <= CVQ_MAXX * 256 && sm <= (lim ? 160 : 76) * 1024) { MFs = mf; NFRs = nf; THq = th; TWq = tw; smem = sm; }
         }
       }
@@ -550,7 +582,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
     const int LD = CvLd<T>::v;                                                                          \
     int tg = a->ntaps;  /* taps staged per barrier group: all of them unless LDS (two blocks per CU) says no */   \
     while (tg > 1 && (size_t)(TH * TW + tg * 16 * NF) * LD * sizeof(T) > 76 * 1024) --tg;               \
-    const size_t smem = (size_t)(TH * TW + tg * 16 * NF) * LD * sizeof(T) + 2 * MDS_MAX_TAPS * sizeof(int); \
+    const size_t smem = (size_t)(TH * TW + tg * 16 * NF) * LD * sizeof(T) + 2 * CV_TAPPAD * sizeof(int) + 2 * 16 * NF * sizeof(float); \
     if (a->is == 1) MDS_LAUNCH((conv_fwd_kernel<T, PRO, 1, NF>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
     else MDS_LAUNCH((conv_fwd_kernel<T, PRO, 2, NF>), grid, block, smem, stream, *a, dymin, dxmin, TH, TW, tg); \
   } while (0)

@@ -35,6 +35,18 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(mds_stem_fwd_args a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s_[e] = 0.f; ss_[e] = 0.f; }
   T* y = (T*)a.y;
+  const int emode = a.epi.mode;       // eval-mode output transform (mds_epi_t): this lane's 2 x 4 output channels
+  float es[2][4], eh[2][4];
+  if (emode != MDS_EPI_NONE) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int oc = 16 * f + 4 * q + rr;
+        es[f][rr] = oc < a.Cout ? a.epi.scale[oc] : 0.f;
+        eh[f][rr] = oc < a.Cout ? a.epi.shift[oc] : 0.f;
+      }
+  }
   for (long gi = gw; gi < ngroups; gi += nw) {
     const int gx = (int)(gi % gpr);
     long r = gi / gpr;
@@ -69,6 +81,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(mds_stem_fwd_args a) {
         const int oc = 16 * f + 4 * q;
         if (oc < a.Cout) {
           float v[4] = {acc[f][0], acc[f][1], acc[f][2], acc[f][3]};
+          if (emode != MDS_EPI_NONE) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const float z = v[rr] * es[f][rr] + eh[f][rr];
+              v[rr] = emode == MDS_EPI_BN_SILU ? siluf_(z) : z;
+            }
+          }
           store4(y + row * a.Cout + oc, v);
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) { s_[f * 4 + rr] += v[rr]; ss_[f * 4 + rr] += v[rr] * v[rr]; }

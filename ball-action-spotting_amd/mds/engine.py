@@ -349,14 +349,18 @@ class Plan:
         return y
 
     def _conv(self, seg, x, pro, N, IH, IW, Cin, Cout, stride, wparam, bn_mod):
+        """inference plans: the output is stored as silu(bn(y)) (mds_epi_t); consumers then read it without a prologue"""
         OH, OW, pt, pl = geo.conv_geometry(IH, IW, stride)
         bn = BNL(self, bn_mod, Cout, N * OH * OW)
         dy, dx, wi = geo.taps_fwd(pt, pl)
         y = self.act(N * OH * OW, Cout)
         w = self.pack(wparam, cabi.MDS_PACK_OI, Cout, Cin, 9)
+        extra = dict(stats=bn.stats)
+        if self.eval_epilogues:
+            extra = dict(stats=None, epi=dict(_struct="mds_epi_t", mode=EPI_BN_SILU, scale=bn.scale, shift=bn.shift))
         self.op(seg, "conv_fwd", dtype=self.code, N=N, IH=IH, IW=IW, Cin=Cin, OH=OH, OW=OW, Cout=Cout, A=OH, B=OW,
                 oy0=0, ox0=0, os=1, **{"is": stride}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9, x=x, w=w, y=y,
-                pro=pro or dict(mode=0), residual=None, stats=bn.stats)
+                pro=pro or dict(mode=0), residual=None, **extra)
         bn.finalize(self, seg)
         return y, bn, OH, OW, (pt, pl)
 
@@ -539,8 +543,12 @@ class Plan:
             self.x_u8 = self._own(nsrc * 3 * src_h * src_w, torch.uint8)
             extra["ingest"] = dict(_struct="mds_ingest_t", u8=self.x_u8, nsrc=nsrc, src_h=src_h, src_w=src_w,
                                    pad_top=(H - src_h) // 2, pad_left=(W - src_w) // 2, scale=1.0 / 255.0)
+        if self.eval_epilogues:
+            extra.update(stats=None, epi=dict(_struct="mds_epi_t", mode=EPI_BN_SILU, scale=bn0.scale, shift=bn0.shift))
+        else:
+            extra.update(stats=bn0.stats)
         self.op("f2d", "stem_fwd", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
-                x=None if self.ingest is not None else self.x_in, w=wst, y=y0, stats=bn0.stats, **extra)
+                x=None if self.ingest is not None else self.x_in, w=wst, y=y0, **extra)
         bn0.finalize(self, "f2d")
 
         def stem_bwd(seg, u0, nxt_head):
@@ -564,7 +572,7 @@ class Plan:
 
         stem_bwd.lo = self._lo(enc.conv_stem, enc.bn1)
         recs.append(stem_bwd)
-        cur, cur_bn, ch, cw = y0, bn0, OH, OW      # cur_bn != None: `cur` is a raw tensor read through BN+SiLU
+        cur, cur_bn, ch, cw = y0, (None if self.eval_epilogues else bn0), OH, OW      # cur_bn != None: `cur` is a raw tensor read through BN+SiLU
         for blk in enc.block_list():
             if blk.kind == "cn":
                 cur, cur_bn, ch, cw = self._cn_block(recs, blk, cur, cur_bn, N, ch, cw, fr)
@@ -605,9 +613,11 @@ class Plan:
         return feat, ch, cw
 
     def _cn_block(self, recs, blk, xin, xin_bn, N, IH, IW, fr):
-        assert not blk.has_skip and xin_bn is not None
-        y, bn1, OH, OW, pads = self._conv("f2d", xin, xin_bn.pro(), N, IH, IW, blk.cin, blk.cout, blk.stride,
-                                          blk.conv.weight, blk.bn1)
+        assert not blk.has_skip and (xin_bn is not None or self.eval_epilogues)
+        y, bn1, OH, OW, pads = self._conv("f2d", xin, xin_bn.pro() if xin_bn is not None else None, N, IH, IW, blk.cin, blk.cout,
+                                          blk.stride, blk.conv.weight, blk.bn1)
+        if self.eval_epilogues:
+            return y, None, OH, OW       # activated output, no backward
 
         def bwd(seg, u, nxt_head):
             if fr:
@@ -636,7 +646,7 @@ class Plan:
         has_skip = blk.has_skip
         assert not has_skip or xin_bn is None
         if self.eval_epilogues:          # inference: BN2 + shortcut in the projection's epilogue, no bn_res launch
-            xout = self._pw("f2d", ya, M, mid, cout, blk.conv_pwl.weight, pro=bn1.pro(), stats_bn=bn2,
+            xout = self._pw("f2d", ya, M, mid, cout, blk.conv_pwl.weight, pro=None, stats_bn=bn2,      # ya = silu(bn1(.)) already
                             residual=xin if has_skip else None, epi_mode=EPI_AFFINE)
             return xout, OH, OW       # (inference plans have no backward closures)
         yb = self._pw("f2d", ya, M, mid, cout, blk.conv_pwl.weight, pro=bn1.pro(), stats_bn=bn2)

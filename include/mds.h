@@ -45,6 +45,19 @@ const char* mds_last_error(void);
 #define MDS_KNOB_COUNT 2
 int mds_dev_set(int knob, int value);
 
+/* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
+ * the predictor): the producer stores act(acc*scale[c] + shift[c]) instead of the raw convolution output, so no consumer
+ * re-evaluates BN + SiLU while loading (the depthwise kernels do that 1.33x per element, halo included) and the
+ * block-output pass (mds_bn_res) disappears into the projection's epilogue.  mode 0 = raw output (training). */
+#define MDS_EPI_NONE 0
+#define MDS_EPI_AFFINE 1      /* y = acc*scale + shift (+ residual)          */
+#define MDS_EPI_BN_SILU 2     /* y = silu(acc*scale + shift) (+ residual)    */
+typedef struct {
+  int mode;
+  const float* scale; /* [C] */
+  const float* shift; /* [C] */
+} mds_epi_t;
+
 /* ---- operand transforms ("prologues"): how a consumer reads a producer's raw conv output.
  * Train-mode BatchNorm needs batch statistics before it can normalise, so producers store the
  * raw convolution output y (+ its per-channel sums) and every consumer applies
@@ -112,19 +125,6 @@ typedef struct {
   float* stats;        /* [SLOTS][2][N] caller-zeroed: sum g, sum g*xhat */
 } mds_poststat_t;
 
-/* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
- * the predictor): the producer stores act(acc*scale[c] + shift[c]) instead of the raw convolution output, so no consumer
- * re-evaluates BN + SiLU while loading (the depthwise kernels do that 1.33x per element, halo included) and the
- * block-output pass (mds_bn_res) disappears into the projection's epilogue.  mode 0 = raw output (training). */
-#define MDS_EPI_NONE 0
-#define MDS_EPI_AFFINE 1      /* y = acc*scale + shift (+ residual)          */
-#define MDS_EPI_BN_SILU 2     /* y = silu(acc*scale + shift) (+ residual)    */
-typedef struct {
-  int mode;
-  const float* scale; /* [C] */
-  const float* shift; /* [C] */
-} mds_epi_t;
-
 /* ---- K4: 1x1 convolution = GEMM  y[M][N] = pro(x)[M][K] * w[N][K]^T  (+ residual)
  * replaces nn.Conv2d/Conv3d k=1 at multidim_stacker.py:106,120,179-183,199-203 and timm
  * conv_pw/conv_pwl; also used as its own data-gradient (w = transposed pack).                  */
@@ -189,6 +189,7 @@ typedef struct {
    * four).  Needs is == 1, g_ntaps*Cin % 32 == 0, no residual / statistics; A, B = the largest g_A, g_B (oy0 = ox0 = 0). */
   int ngroups;
   int g_ntaps[4], g_oy0[4], g_ox0[4], g_A[4], g_B[4];
+  mds_epi_t epi;        /* eval-mode output transform (no statistics with it; applied before `residual` is added) */
 } mds_conv_fwd_args;
 int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream);
 
@@ -229,6 +230,7 @@ typedef struct {
   void* y;        /* [N][OH][OW][Cout]   */
   float* stats;
   mds_ingest_t ingest;
+  mds_epi_t epi;  /* eval-mode output transform */
 } mds_stem_fwd_args;
 int mds_stem_fwd(const mds_stem_fwd_args* a, mds_stream_t stream);
 

@@ -114,6 +114,33 @@ def test_conv_dgrad(be, dt, N, H, W, Cin, Cout, stride, mode):
     assert_close(dxo, ref, dt, msg="dx")
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,emode,res", [(2, 13, 21, 32, 16, 1, 2, False), (1, 16, 34, 16, 64, 2, 2, False),
+                                                             (1, 9, 18, 48, 192, 1, 1, True), (1, 12, 20, 128, 32, 1, 2, True)])
+def test_conv_fwd_output_transform(be, dt, N, H, W, Cin, Cout, stride, emode, res):
+    """mds_epi_t in both convolution kernels: y = act(acc*scale + shift) (+ residual); no prologue (activated input)"""
+    code, tdt = DT[dt]
+    g = gen(H * W + Cin + emode)
+    x = torch.randn(N, Cin, H, W, generator=g).to(tdt)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(tdt)
+    esc = 1 + 0.3 * torch.randn(Cout, generator=g); esh = 0.4 * torch.randn(Cout, generator=g)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
+    dy, dx, wi = geo.taps_fwd(pt, pl)
+    r = torch.randn(N, OH, OW, Cout, generator=g).to(tdt) if res else None
+    y = torch.full((N, OH, OW, Cout), float("nan")).to(tdt).to(be.device)
+    be.call("conv_fwd", cabi.make("mds_conv_fwd_args", dtype=code, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout, A=OH, B=OW,
+                                  oy0=0, ox0=0, os=1, **{"is": stride}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9, x=be.t(nhwc(x)),
+                                  w=be.t(pack(w, "oi", tdt)), y=y, pro=cabi.pro(0), residual=be.t(r) if res else None, stats=None,
+                                  epi=cabi.make("mds_epi_t", mode=emode, scale=be.t(esc), shift=be.t(esh))))
+    be.sync()
+    ref = nhwc(ref_conv(x.float(), w.float(), stride)) * esc + esh
+    if emode == 2:
+        ref = F.silu(ref)
+    if res:
+        ref = ref + r.float()
+    assert_close(y, ref, dt, msg="y")
+
+
 GROUP_CASES = [  # N, H, W, Cin, Cout (of the forward stride-2 conv), persistent blocks (0 = default grid)
     (2, 16, 34, 16, 64, 0),
     (1, 11, 17, 32, 128, 0),      # odd sizes: the parities' sub-grids differ in extent

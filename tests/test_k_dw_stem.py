@@ -148,6 +148,26 @@ def test_stem_fwd_wgrad(be, dt, N, H, W):
     assert_close(dw, wq.grad, dt, scale=cnt ** 0.5, msg="dw")
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_stem_fwd_output_transform(be, dt):
+    code, tdt = DT[dt]
+    N, H, W = 2, 18, 30
+    g = gen(5)
+    x = torch.rand(N, 3, H, W, generator=g)
+    w = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    esc = 1 + 0.3 * torch.randn(32, generator=g); esh = 0.4 * torch.randn(32, generator=g)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, 2)
+    (pt_, pb), (pl_, pr) = geo.same_pad(H, 2), geo.same_pad(W, 2)
+    ref = F.silu(F.conv2d(F.pad(x.to(tdt).float(), (pl_, pr, pt_, pb)), w.to(tdt).float(), None, 2).permute(0, 2, 3, 1) * esc + esh)
+    wp = torch.zeros(32, 32); wp[:, :27] = w.view(32, 27)
+    y = torch.full((N, OH, OW, 32), float("nan")).to(tdt).to(be.device)
+    be.call("stem_fwd", cabi.make("mds_stem_fwd_args", dtype=code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
+                                  x=be.t(x), w=be.t(wp.to(tdt)), y=y, stats=None,
+                                  epi=cabi.make("mds_epi_t", mode=2, scale=be.t(esc), shift=be.t(esh))))
+    be.sync()
+    assert_close(y, ref, dt, msg="y")
+
+
 @pytest.mark.parametrize("gmode", [cabi.MDS_G_PLAIN, cabi.MDS_G_SILU])
 @pytest.mark.parametrize("N,H,W", [(2, 20, 36), (1, 17, 70)])
 def test_stem_wgrad_forms_dy_on_load(be, gmode, N, H, W):
