@@ -16,6 +16,7 @@
 
 #define PW_BM 128
 #define PW_BN 128
+#define PW_SP 72   /* output staging pitch (elements): 64 columns + 16 bytes */
 
 template <typename T> struct PwCfg;
 // LDS row pitch = 160 B: with ds_read_b128's real lane groups ({0-3,12-15,20-27}, ...) a pitch of
@@ -40,6 +41,11 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
   MDS_DYN_SMEM(smem);
   T* xs = (T*)smem;                          // [BM][LD]
   T* ws = xs + BM * LD;                      // [BN][LD]
+  // bf16 output staging, a private [16][PW_SP] region per wave: in the MFMA layout a lane holds 4 columns (8 bytes) of
+  // 16 different rows, and stores issued that way write 32-byte pieces (~2.9 TB/s of output on every GEMM-shaped kernel
+  // here, fill reaches 6.9); through LDS a lane stores 16 bytes of a 128-byte row segment (k_pwr.hip measured it first)
+  constexpr bool STG = sizeof(T) == 2;
+  T* stg = ws + BN * LD + (threadIdx.x >> 6) * 16 * PW_SP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);   // scalar: "nf < nfr" must be a scalar branch, not an exec-mask dance per fragment
   const int i = lane & 15, q = lane >> 4;
@@ -263,7 +269,22 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
           }
         }
       }
-      if (ok) {
+      if (STG) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) store4(stg + i * PW_SP + 16 * nf + 4 * q, v[nf]);
+        wave_lds_sync();
+        T* ybase = y + (m0 + 16 * MFW * wm + 16 * mf) * N + n0 + 64 * wn;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int vv = lane + 64 * t, row = vv >> 3, c = vv & 7;
+          if (m0 + 16 * MFW * wm + 16 * mf + row < a.M && (c >> 1) < nfr) {
+            RawV8<T> o;
+            o.ld(stg + row * PW_SP + 8 * c);
+            o.st(ybase + (long)row * N + 8 * c);
+          }
+        }
+        wave_lds_sync();   // the next fragment row's staging writes come after these reads
+      } else if (ok) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
           if (nf < nfr) store4(yrow + 16 * nf, v[nf]);
@@ -291,6 +312,8 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
   }
 }
 
+int pw_fwd_wres_try(const mds_pw_fwd_args* a, mds_stream_t stream);   // k_pwr.hip: short-K wide-N layers; 1 = not taken
+
 extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_fwd: bad dims");
   MDS_REQUIRE(a->K % 8 == 0 && a->N % 16 == 0, "pw_fwd: K=%d must be a multiple of 8, N=%d of 16", a->K, a->N);
@@ -314,6 +337,7 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
     MDS_REQUIRE(a->post.mode != MDS_POST_MASK || (a->post.mask && a->post.rows_per_group > 0), "pw_fwd: post mask");
     MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE && a->M < 4294967295L, "pw_fwd: post statistics are a data-gradient feature (no forward prologue)");
   }
+  { const int rc = pw_fwd_wres_try(a, stream); if (rc <= 0) return rc; }
   // 128x64 tiles for the narrow projections (N <= 64: half of a 128-column tile would be padding;
   // 154 -> 119 us at 1.18 M x 128 -> 32); wider N measured 5-20 % slower with them despite 3 blocks/CU
   const int wn = a->N <= 64 ? 1 : 2;
@@ -327,13 +351,13 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   if (nt > 1) { gy = cdiv(1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
   dim3 grid(mt, gy), block(256);
 #define PW_GO2(T, PRO, TAIL_) \
-  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T); \
+  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
        if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_>), grid, block, smem, stream, *a); \
        else if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 128, TAIL_>), grid, block, smem, stream, *a); \
        else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1, 128, TAIL_>), grid, block, smem, stream, *a); } while (0)
 #define PW_GO(T, PRO) PW_GO2(T, PRO, 0)
 #define PW_GODY(T, TAIL_) \
-  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T); \
+  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
        if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 2, 64, TAIL_>), grid, block, smem, stream, *a); \
        else MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 1, 128, TAIL_>), grid, block, smem, stream, *a); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {

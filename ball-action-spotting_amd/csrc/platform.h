@@ -206,6 +206,14 @@ MDS_DEV u16x4 lds_tr4(const bf16_t* p) {
 }
 #endif
 
+// Orders one wave's own LDS traffic (lane A's write, lane B's read) without a block barrier: the LDS unit runs a wave's
+// DS instructions in order, so only the compiler (and the simulator's lane interleaving) must be held back.
+#ifndef MDS_EMU
+MDS_DEV void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#else
+MDS_DEV void wave_lds_sync() { hipemu::wave_barrier(); }
+#endif
+
 MDS_DEV void frag_from8(u16x8& f, const float (&v)[8]) { f = pack8(v); }
 MDS_DEV void frag_from8(f32x8& f, const float (&v)[8]) { f = (f32x8){v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}; }
 MDS_DEV void frag_zero(u16x8& f) { f = (u16x8){0, 0, 0, 0, 0, 0, 0, 0}; }

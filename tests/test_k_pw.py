@@ -246,3 +246,68 @@ def test_pw_wgrad_dy_prologue(be, dt, M, K, N, mode, gmode):
     if dt == "bf16":
         a, dyq = a.to(tdt).float(), dyq.to(tdt).float()
     assert_close(dw, dyq.t() @ a, dt, scale=M ** 0.5, msg="dw")
+
+
+@pytest.fixture
+def force_filter_resident(be):
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_WRES, 2), "dev_set")
+    yield
+    be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_WRES, 0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,N,res,stats,post", [
+    (1300, 192, 256, False, True, 0),    # 6 k-steps, 3 row tiles per block, ragged last tile
+    (650, 112, 192, False, True, 0),     # K % 32 != 0 (zero k-padding), 96-column tiles (N % 96 == 0)
+    (530, 96, 144, False, True, 0),      # ragged n-tile (128 + 16)
+    (600, 96, 128, False, False, 1),     # PLAIN post statistics
+    (1290, 192, 192, False, False, 2),   # MASK post statistics
+    (515, 80, 256, False, False, 3),     # SILU post statistics (g stored), K = 80 padded to 96
+    (2500, 96, 128, False, True, 0),     # 5 row tiles per block: the 3-deep register ring wraps and refills
+    (2300, 112, 192, False, False, 2),   # ... with the post.y fragments prefetched one tile ahead
+    (2560, 96, 144, False, True, 0),     # no ragged row tile: only the straight-line trips, plus a ragged n-tile block
+])
+def test_pw_fwd_filter_resident(be, force_filter_resident, dt, M, K, N, res, stats, post):
+    """k_pwr.hip: the short-K / wide-N kernel (filter tile resident in LDS, column sums once per block)"""
+    if dt == "f32" and K > 96:
+        pytest.skip("fp32 filter tile of K > 96 does not fit two blocks per CU: general kernel")
+    code, tdt = DT[dt]
+    g_ = torch.Generator().manual_seed(M + 3 * K + post)
+    rpg = 41
+    groups = (M + rpg - 1) // rpg
+    grp = torch.arange(M) // rpg
+    x = torch.randn(M, K, generator=g_).to(tdt)
+    w = (torch.randn(N, K, generator=g_) / K ** 0.5).to(tdt)
+    r = torch.randn(M, N, generator=g_).to(tdt)
+    out = torch.full((M, N), float("nan")).to(tdt).to(be.device)
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device)
+    kw = {}
+    if post:
+        ys = (torch.randn(M, N, generator=g_) * 1.2 - 0.2).to(tdt)
+        gamma2 = 1 + 0.2 * torch.randn(N, generator=g_); beta2 = 0.1 * torch.randn(N, generator=g_)
+        mask2 = (torch.rand(groups, generator=g_) < 0.6).float() / 0.6
+        bn2 = _bn_setup(be, ys, gamma2, beta2)
+        kw["post"] = cabi.poststat(post, be.t(ys), bn2, st, be.t(mask2), rpg)
+    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=be.t(x), w=be.t(w), y=out, pro=cabi.pro(0),
+                                residual=be.t(r) if res else None, stats=st if stats else None, **kw))
+    be.sync()
+    v = x.float() @ w.float().t() + (r.float() if res else 0.0)
+    if (stats or post) and M > 640:   # this kernel adds into 8 + 1 statistic slots (8 blocks per n-tile), the general one into M/64 + 1
+        assert int((st.abs().sum((1, 2)) > 0).sum()) <= 9, "the filter-resident kernel was not taken"
+    if post:
+        b2 = bn2.cpu()
+        zs = ys.float() * b2[0] + b2[1]
+        sg = torch.sigmoid(zs)
+        stored = v * (sg * (1 + zs * (1 - sg))) if post == 3 else v
+        assert_close(out, stored, dt, scale=2, msg="out")
+        gq = out.float().cpu() * (mask2[grp, None] if post == 2 else 1.0)
+        xh = (ys.float() - b2[2]) * b2[3]
+        s = st.sum(0).cpu()
+        assert_close(s[0], gq.sum(0), "f32", scale=50 * M ** 0.5, msg="post sum g")
+        assert_close(s[1], (gq * xh).sum(0), "f32", scale=50 * M ** 0.5, msg="post sum g*xhat")
+    else:
+        assert_close(out, v, dt, msg="y")
+        if stats:
+            s = st.sum(0).cpu()
+            assert_close(s[0], v.sum(0), dt, scale=M ** 0.5, msg="sum")
+            assert_close(s[1], (v * v).sum(0), dt, scale=M ** 0.5, msg="sumsq")

@@ -63,7 +63,7 @@ def bench_dw(which):
 
 PW_SHAPES = [  # M, K, N, pro, tag
     (20 * 184 * 320, 128, 32, 2, "b1.1 pwl 128->32"), (20 * 92 * 160, 48, 192, 0, "b3.0 pw 48->192"),
-    (20 * 46 * 80, 112, 672, 0, "b4.x pw 112->672"), (20 * 46 * 80, 672, 112, 3, "b4.x pwl 672->112"),
+    (20 * 46 * 80, 96, 384, 0, "b3.x pw 96->384"), (20 * 46 * 80, 112, 672, 0, "b4.x pw 112->672"), (20 * 46 * 80, 672, 112, 3, "b4.x pwl 672->112"),
     (20 * 23 * 40, 192, 1152, 0, "b5.x pw 192->1152"), (20 * 23 * 40, 1152, 192, 3, "b5.x pwl 1152->192"),
     (4 * 5 * 23 * 40, 192, 576, 0, "3d pw 192->576"), (4 * 5 * 23 * 40, 576, 192, 3, "3d pwl 576->192"),
 ]
@@ -209,7 +209,7 @@ def bench_copy():
 
 
 if __name__ == "__main__":
-    for knob, env in ((0, "KB_CONV_BLOCKS"), (1, "KB_DW_ORDER"), (2, "KB_GEMM8")):
+    for knob, env in ((0, "KB_CONV_BLOCKS"), (1, "KB_DW_ORDER"), (2, "KB_PW_WRES")):
         if os.environ.get(env):
             lib.check(lib.fn["dev_set"](knob, int(os.environ[env])), "dev_set")
     todo = sys.argv[1:] or ["copy", "dw_fwd", "dw_bwd", "pw_fwd", "pw_wgrad", "conv_fwd", "conv_wgrad"]
