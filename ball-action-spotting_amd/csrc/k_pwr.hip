@@ -278,7 +278,7 @@ int pw_fwd_wres_try(const mds_pw_fwd_args* a, mds_stream_t stream) {
   if (cap < 8) cap = 8;
   // too few row tiles per block to amortise the filter stage: measured inside the step, the 18400-row layers
   // (192 -> 1152, 192 -> 576: 5 tiles per block) lose 2-3 us to it, the 73600-row layers gain 10-30 %
-  if (!forced && MT < 6L * (512 / nt)) return 1;
+  if (!forced && MT < (knob == 3 ? 2L : 6L) * (512 / nt)) return 1;   // (knob 3: the lower bar, for A/B runs)
   const long tpb = cdiv(MT, cap);
   int gx = (int)((cdiv(MT, tpb) + 7) & ~7L);
   if (gx > cap) gx = cap;

@@ -116,7 +116,7 @@ def kernel_family(name):
     """'void dw2_bwd_kernel<unsigned short, 4>(...)' -> 'dw_bwd' ; variants of one entry point share a key"""
     fn = name.replace("void ", "").split("<")[0].split("(")[0]
     fn = re.sub(r"\d", "", fn)
-    for v in ("_tr_kernel", "_p_kernel", "_tiled_kernel", "_kernel"):
+    for v in ("_tr_kernel", "_p_kernel", "_tiled_kernel", "_wres_kernel", "_q_kernel", "_kernel"):
         if fn.endswith(v):
             fn = fn[: -len(v)]
             break

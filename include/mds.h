@@ -42,7 +42,7 @@ const char* mds_last_error(void);
  * kernel so that the parity tests can drive its multi-tile software pipeline at small sizes. */
 #define MDS_KNOB_CONV_BLOCKS 0
 #define MDS_KNOB_DW_ORDER 1      /* 1: depthwise kernels take the channel chunk as the fast grid index (A/B switch) */
-#define MDS_KNOB_PW_WRES 2     /* 1: mds_pw_fwd never takes the filter-resident kernel (A/B switch); 2: takes it at any M (tests) */
+#define MDS_KNOB_PW_WRES 2     /* 1: mds_pw_fwd never takes the filter-resident kernel (A/B switch); 2: takes it at any M (tests); 3: lower row bar */
 #define MDS_KNOB_COUNT 3
 int mds_dev_set(int knob, int value);
 
