@@ -86,6 +86,12 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     RawV8<T> rx[NL], rw[NLW], ry[PRO == PW_PRO_DY ? NL : 1];
+    // the squeeze-excite gate row of every staged x vector travels WITH it (same issue point): loaded inside the staging
+    // loop it was one exposed L2 round trip per K chunk - 18 of them in the 1152 -> 192 projections
+    // (the variants that would spill with 8 more registers per row keep the in-loop load: 128-row tiles, BN_SILU_GATE)
+    constexpr bool GATED = PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE;
+    constexpr bool GPRE = PRO == MDS_PRO_GATE && NL <= 2;
+    float rg[GPRE ? NL : 1][8];
     const T* wrow[NLW];   // this thread's filter rows of the n-tile (row pointers hoisted out of the k-loop)
     bool wok[NLW];
 #pragma unroll
@@ -100,6 +106,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       for (int l = 0; l < NL; ++l) {
         if (xok[l] && kok) rx[l].ld(xrow[l] + kc); else rx[l].zero();
         if (PRO == PW_PRO_DY) { if (xok[l] && kok) ry[l].ld(xrow[l] + ydiff + kc); else ry[l].zero(); }
+        if (GPRE) load8f(a.pro.gate + (long)grow[l] * K + (kok ? kc + 8 * svec : 0), rg[l]);   // grow is clamped: always legal
       }
 #pragma unroll
       for (int l = 0; l < NLW; ++l) {
@@ -152,7 +159,10 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
                 v[j] = (PRO == MDS_PRO_AFFINE) ? z : siluf_(z);
               }
             }
-            if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
+            if (GPRE) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] *= rg[l][j];
+            } else if (GATED) {
               float g[8];
               load8f(a.pro.gate + (long)grow[l] * K + kk, g);
 #pragma unroll
