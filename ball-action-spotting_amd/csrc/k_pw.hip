@@ -32,8 +32,16 @@ template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 // sums of the NEXT layer over the output tile in the epilogue (mds_poststat_t).
 #define PW_PRO_DY 5
 // TAIL: 0 = plain epilogue, 1 = POST (BatchNorm-backward sums of the next layer, mds_poststat_t), 2 = EPI (mds_epi_t)
-template <typename T, int PRO, int WN, int BM, int TAIL>
-__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || TAIL == 1 ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+// DEEP (opt-in through MDS_KNOB_PW_DEEP; K >= 4 chunks, 64-row tiles, NONE / GATE prologue): TWO K chunks in flight.  With 16 MFMAs per chunk and wave a chunk
+// is ~250 clocks of arithmetic against a ~2 us load, so the K-heavy projections (672 -> 112, 1152 -> 192 and their data
+// gradients) waited a full memory latency per chunk.  The ring follows k_pwr.hip's vmcnt discipline: every load is issued
+// unconditionally from a clamped address (zeroed in registers when staged), refills are never tested, and an odd chunk
+// count runs one all-zero phantom chunk instead of a branch.  Measured: the compiler still waits vmcnt(0) for the first set
+// (the second gets counted waits), the gated variant drops to two blocks per CU for registers, and the step is 1 % slower -
+// kept behind the knob with its tests as the starting point for a proper multi-stage K pipeline.
+template <typename T, int PRO, int WN, int BM, int TAIL, int DEEP = 0>
+__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || TAIL == 1 || (DEEP && PRO == MDS_PRO_GATE) ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+  static_assert(!DEEP || ((PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && BM == 64 && WN == 2 && TAIL != 2), "DEEP variants");
   constexpr bool POST = TAIL == 1, EPI = TAIL == 2;
   typedef typename Frag<T>::type frag_t;
   constexpr int KC = PwCfg<T>::KC, LD = PwCfg<T>::LD, VPR = KC / 8, RPP = 256 / VPR, NL = BM / RPP;
@@ -85,13 +93,14 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    RawV8<T> rx[NL], rw[NLW], ry[PRO == PW_PRO_DY ? NL : 1];
+    constexpr int NS = DEEP ? 2 : 1;
+    RawV8<T> rx[NS][NL], rw[NS][NLW], ry[PRO == PW_PRO_DY ? NL : 1];
     // the squeeze-excite gate row of every staged x vector travels WITH it (same issue point): loaded inside the staging
     // loop it was one exposed L2 round trip per K chunk - 18 of them in the 1152 -> 192 projections
     // (the variants that would spill with 8 more registers per row keep the in-loop load: 128-row tiles, BN_SILU_GATE)
     constexpr bool GATED = PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE;
     constexpr bool GPRE = PRO == MDS_PRO_GATE && NL <= 2;
-    float rg[GPRE ? NL : 1][8];
+    float rg[NS][GPRE ? NL : 1][8];
     const T* wrow[NLW];   // this thread's filter rows of the n-tile (row pointers hoisted out of the k-loop)
     bool wok[NLW];
 #pragma unroll
@@ -100,37 +109,50 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       wok[l] = n < N;
       wrow[l] = w + (long)(wok[l] ? n : 0) * K + 8 * svec;
     }
-    auto issue = [&](int kc) {  // all global loads of one K-chunk
+    auto issue = [&](int kc, RawV8<T> (&tx)[NL], RawV8<T> (&tw)[NLW], float (&tg)[GPRE ? NL : 1][8]) {  // all global loads of one K-chunk
       const bool kok = kc + 8 * svec < K;
+      if (DEEP) {   // straight-line: rows are clamped in xrow / wrow, channels past K read channel 0; zeroed when staged
+        const int ko = kok ? kc : -8 * svec;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          tx[l].ld(xrow[l] + ko);
+          if (GPRE) load8f(a.pro.gate + (long)grow[l] * K + (kok ? kc + 8 * svec : 0), tg[l]);
+        }
+#pragma unroll
+        for (int l = 0; l < NLW; ++l) tw[l].ld(wrow[l] + ko);
+        return;
+      }
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        if (xok[l] && kok) rx[l].ld(xrow[l] + kc); else rx[l].zero();
+        if (xok[l] && kok) tx[l].ld(xrow[l] + kc); else tx[l].zero();
         if (PRO == PW_PRO_DY) { if (xok[l] && kok) ry[l].ld(xrow[l] + ydiff + kc); else ry[l].zero(); }
-        if (GPRE) load8f(a.pro.gate + (long)grow[l] * K + (kok ? kc + 8 * svec : 0), rg[l]);   // grow is clamped: always legal
+        if (GPRE) load8f(a.pro.gate + (long)grow[l] * K + (kok ? kc + 8 * svec : 0), tg[l]);   // grow is clamped: always legal
       }
 #pragma unroll
       for (int l = 0; l < NLW; ++l) {
-        if (wok[l] && kok) rw[l].ld(wrow[l] + kc); else rw[l].zero();
+        if (wok[l] && kok) tw[l].ld(wrow[l] + kc); else tw[l].zero();
       }
     };
-    issue(0);
-    for (int kc = 0; kc < K; kc += KC) {
+    auto chunk = [&](int kc, RawV8<T> (&tx)[NL], RawV8<T> (&tw)[NLW], float (&tg)[GPRE ? NL : 1][8]) {
       const int kk = kc + 8 * svec;
+      const bool kin = kk < K;
       __syncthreads();  // previous chunk's fragment reads are done
       if (PRO == MDS_PRO_NONE) {
 #pragma unroll
-        for (int l = 0; l < NL; ++l) rx[l].st(xs + (srow + RPP * l) * LD + 8 * svec);
+        for (int l = 0; l < NL; ++l) {
+          if (DEEP && !(xok[l] && kin)) tx[l].zero();
+          tx[l].st(xs + (srow + RPP * l) * LD + 8 * svec);
+        }
       } else if (PRO == PW_PRO_DY) {
 #pragma unroll
-        for (int l = 0; l < NLW; ++l) rw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);   // frees the filter registers first
+        for (int l = 0; l < NLW; ++l) tw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);   // frees the filter registers first
         float cA[8], cB[8], cD[8];
-        const bool kin = kk < K;
         if (kin) { load8f(a.xdy.lin + kk, cA); load8f(a.xdy.lin + K + kk, cB); load8f(a.xdy.lin + 2 * K + kk, cD); }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
           const int r = srow + RPP * l;
           float u[8], yv[8];
-          rx[l].get(u);
+          tx[l].get(u);
           ry[l].get(yv);
           if (xok[l] && kin) {
             const float mk = gmode == MDS_G_MASK ? a.xdy.g.mask[grow[l]] : 1.0f;
@@ -144,14 +166,14 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
         }
       } else {
         float sc[8], sh[8];
-        if (PRO != MDS_PRO_GATE && kk < K) { load8f(a.pro.scale + kk, sc); load8f(a.pro.shift + kk, sh); }
+        if (PRO != MDS_PRO_GATE && kin) { load8f(a.pro.scale + kk, sc); load8f(a.pro.shift + kk, sh); }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
           const int r = srow + RPP * l;
           const long m = m0 + r;
           float v[8];
-          rx[l].get(v);
-          if (m < a.M && kk < K) {
+          tx[l].get(v);
+          if (m < a.M && kin) {
             if (PRO != MDS_PRO_GATE) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
@@ -161,27 +183,34 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
             }
             if (GPRE) {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] *= rg[l][j];
+              for (int j = 0; j < 8; ++j) v[j] *= tg[l][j];
             } else if (GATED) {
               float g[8];
               load8f(a.pro.gate + (long)grow[l] * K + kk, g);
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] *= g[j];
             }
+          } else if (DEEP) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
           }
           store8(xs + r * LD + 8 * svec, v);
         }
       }
       if (PRO != PW_PRO_DY) {
 #pragma unroll
-        for (int l = 0; l < NLW; ++l) rw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
+        for (int l = 0; l < NLW; ++l) {
+          if (DEEP && !(wok[l] && kin)) tw[l].zero();
+          tw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
+        }
       }
       __syncthreads();
-      if (kc + KC < K) issue(kc + KC);  // in flight while the MFMAs below run
-      const int ksteps = (K - kc >= KC) ? KC / 32 : ((K - kc + 31) >> 5);
+      if (DEEP) issue(kc + 2 * KC, tx, tw, tg);            // refill this set (past K: clamped reads, never staged as data)
+      else if (kc + KC < K) issue(kc + KC, tx, tw, tg);    // in flight while the MFMAs below run
+      const int ksteps = (K - kc >= KC) ? KC / 32 : ((K - kc + 31) >> 5);   // <= 0 for the phantom chunk of an odd count
 #pragma unroll
       for (int ks = 0; ks < KC / 32; ++ks) {
-        if (ks < ksteps) {
+        if (DEEP || ks < ksteps) {   // DEEP: no branch between a refill and its wait (channels past K are staged as zeros)
           frag_t xf[MFW];
 #pragma unroll
           for (int mf = 0; mf < MFW; ++mf) xf[mf] = ld_frag(xs + (16 * MFW * wm + 16 * mf + i) * LD + 32 * ks + 8 * q);
@@ -193,6 +222,16 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
           }
         }
       }
+    };
+    issue(0, rx[0], rw[0], rg[0]);
+    if (DEEP) {
+      issue(KC, rx[NS - 1], rw[NS - 1], rg[NS - 1]);
+      for (int kc = 0; kc < K; kc += 2 * KC) {
+        chunk(kc, rx[0], rw[0], rg[0]);
+        chunk(kc + KC, rx[NS - 1], rw[NS - 1], rg[NS - 1]);
+      }
+    } else {
+      for (int kc = 0; kc < K; kc += KC) chunk(kc, rx[0], rw[0], rg[0]);
     }
 
     // ---- epilogue: residual, store, statistics.  One row-validity test per m-fragment (not per
@@ -370,8 +409,18 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
        if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 2, 64, TAIL_>), grid, block, smem, stream, *a); \
        else MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 1, 128, TAIL_>), grid, block, smem, stream, *a); } while (0)
+#define PW_GODEEP(T, PRO, TAIL_) \
+  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
+       MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_, 1>), grid, block, smem, stream, *a); } while (0)
+  const bool deep0 = wn == 2 && bm == 64 && !dy && !epi && (a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE) &&
+                     mds_knob(MDS_KNOB_PW_DEEP) == 1;   // opt-in: measured 4 % SLOWER inside the step (2.87 -> 3.00 ms of pw_fwd)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
-    if (dy) { if (post) PW_GODY(T, 1); else PW_GODY(T, 0); }
+    if (deep0 && a->K >= 4 * PwCfg<T>::KC) {   // K-heavy layers: two K chunks in flight
+      if (post) PW_GODEEP(T, MDS_PRO_NONE, 1);
+      else if (a->pro.mode == MDS_PRO_GATE) PW_GODEEP(T, MDS_PRO_GATE, 0);
+      else PW_GODEEP(T, MDS_PRO_NONE, 0);
+    }
+    else if (dy) { if (post) PW_GODY(T, 1); else PW_GODY(T, 0); }
     else if (post) PW_GO2(T, MDS_PRO_NONE, 1);
     else if (epi) { if (a->pro.mode == MDS_PRO_GATE) PW_GO2(T, MDS_PRO_GATE, 2); else if (a->pro.mode == MDS_PRO_BN_SILU) PW_GO2(T, MDS_PRO_BN_SILU, 2); else PW_GO2(T, MDS_PRO_NONE, 2); }
     else switch (a->pro.mode) {

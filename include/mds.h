@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 110
+#define MDS_VERSION 111
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -43,7 +43,8 @@ const char* mds_last_error(void);
 #define MDS_KNOB_CONV_BLOCKS 0
 #define MDS_KNOB_DW_ORDER 1      /* 1: depthwise kernels take the channel chunk as the fast grid index (A/B switch) */
 #define MDS_KNOB_PW_WRES 2     /* 1: mds_pw_fwd never takes the filter-resident kernel (A/B switch); 2: takes it at any M (tests); 3: lower row bar */
-#define MDS_KNOB_COUNT 3
+#define MDS_KNOB_PW_DEEP 3     /* 1: mds_pw_fwd keeps TWO K chunks in flight for the K-heavy layers (study variant: slower inside the step) */
+#define MDS_KNOB_COUNT 4
 int mds_dev_set(int knob, int value);
 
 /* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /

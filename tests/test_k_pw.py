@@ -39,6 +39,8 @@ def _apply_pro(x, mode, scale, shift, gate, rpg):
     (257, 192, 192, 0, True, False),
     (150, 576, 48, 3, True, True),      # K >= 512 (bf16) / 256 (fp32): 512-byte K chunks, with a K tail (576 = 4.5 x 128)
     (150, 1160, 192, 0, False, True),   # ... two n-tiles, K % 64 != 0
+    (300, 320, 128, 4, False, True),    # gated projection, 5 K chunks: the two-chunk ring with its phantom chunk
+    (200, 704, 192, 4, True, False),    # ... 11 chunks, two n-tiles, residual
     (400300, 16, 144, 2, False, True),  # above 400 k rows: the 128-row tile path (GPU only: too slow to simulate)
 ])
 def test_pw_fwd(be, dt, M, K, N, mode, res, stats):
@@ -271,6 +273,35 @@ def test_pw_fwd_filter_resident(be, force_filter_resident, dt, M, K, N, res, sta
     """k_pwr.hip: the short-K / wide-N kernel (filter tile resident in LDS, column sums once per block)"""
     if dt == "f32" and K > 96:
         pytest.skip("fp32 filter tile of K > 96 does not fit two blocks per CU: general kernel")
+    _run_pw_plain(be, dt, M, K, N, res, stats, post, True)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,N,res,stats,post", [
+    (300, 320, 128, False, True, 0),     # 5 chunks (bf16): odd count -> one all-zero phantom chunk
+    (200, 704, 192, True, False, 1),     # 11 chunks, two n-tiles, residual, PLAIN post statistics
+    (130, 1096, 144, False, False, 3),   # K % 64 != 0, ragged n-tile, SILU post statistics
+])
+def test_pw_fwd_two_chunks_in_flight(be, dt, M, K, N, res, stats, post):
+    """the K-heavy study variant of the general kernel (MDS_KNOB_PW_DEEP: two K chunks in flight, straight-line clamped loads)"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 1), "dev_set")
+    try:
+        _run_pw_plain(be, dt, M, K, N, res, stats, post, False)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,N,res", [(300, 320, 128, False), (200, 704, 192, True)])
+def test_pw_fwd_two_chunks_in_flight_gated(be, dt, M, K, N, res):
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 1), "dev_set")
+    try:
+        test_pw_fwd.__wrapped__(be, dt, M, K, N, 4, res, True) if hasattr(test_pw_fwd, "__wrapped__") else test_pw_fwd(be, dt, M, K, N, 4, res, True)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 0)
+
+
+def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken):
     code, tdt = DT[dt]
     g_ = torch.Generator().manual_seed(M + 3 * K + post)
     rpg = 41
@@ -292,7 +323,7 @@ def test_pw_fwd_filter_resident(be, force_filter_resident, dt, M, K, N, res, sta
                                 residual=be.t(r) if res else None, stats=st if stats else None, **kw))
     be.sync()
     v = x.float() @ w.float().t() + (r.float() if res else 0.0)
-    if (stats or post) and M > 640:   # this kernel adds into 8 + 1 statistic slots (8 blocks per n-tile), the general one into M/64 + 1
+    if check_taken and (stats or post) and M > 640:   # this kernel adds into 8 + 1 statistic slots (8 blocks per n-tile), the general one into M/64 + 1
         assert int((st.abs().sum((1, 2)) > 0).sum()) <= 9, "the filter-resident kernel was not taken"
     if post:
         b2 = bn2.cpu()
