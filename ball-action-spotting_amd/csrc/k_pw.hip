@@ -93,6 +93,25 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // POST: the next BatchNorm's table entries and this lane's post.y fragments are requested HERE, ahead of the K loop
+    // (they were three exposed memory round trips in the epilogue: the table, then one per fragment row)
+    RawV4<T> rys[POST ? MFW : 1][4];
+    float pb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (POST) {
+      if (tid < BN && n0 + tid < N) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pb[k] = a.post.bn[(long)k * N + n0 + tid];
+      }
+      const int nfr_ = (N - n0 - 64 * wn) >> 4;
+#pragma unroll
+      for (int mf = 0; mf < (POST ? MFW : 1); ++mf) {
+        const long m = m0 + 16 * MFW * wm + 16 * mf + i;
+        const T* ysrow = (const T*)a.post.y + (m < a.M ? m : 0) * N + n0 + (nfr_ > 0 ? 64 * wn : 0) + 4 * q;   // clamped: finite values
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) rys[mf][nf].ld(ysrow + (nf < nfr_ ? 16 * nf : 0));
+      }
+    }
+
     constexpr int NS = DEEP ? 2 : 1;
     RawV8<T> rx[NS][NL], rw[NS][NLW], ry[PRO == PW_PRO_DY ? NL : 1];
     // the squeeze-excite gate row of every staged x vector travels WITH it (same issue point): loaded inside the staging
@@ -244,9 +263,8 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
     if (POST) {
       __syncthreads();           // every wave is done with the fragment reads of the last chunk
       if (tid < BN) {
-        const int n = n0 + tid;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pbn[k * BN + tid] = n < N ? a.post.bn[(long)k * N + n] : 0.f;
+        for (int k = 0; k < 4; ++k) pbn[k * BN + tid] = pb[k];
       }
       __syncthreads();
     }
@@ -295,13 +313,11 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       }
       if (POST) {
         // u of the next BatchNorm backward is this tile: g, sum g, sum g*xhat (rows past M: v == 0 -> g == 0)
-        const T* ysrow = (const T*)a.post.y + (ok ? m : 0) * N + n0 + 64 * wn + 4 * q;
         const float mk = (a.post.mode == MDS_POST_MASK) ? a.post.mask[(unsigned)(ok ? m : 0) / (unsigned)a.post.rows_per_group] : 1.0f;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
           if (nf < nfr) {
-            float ys[4];
-            load4(ysrow + 16 * nf, ys);
+            const float ys[4] = {rys[mf][nf].get(0), rys[mf][nf].get(1), rys[mf][nf].get(2), rys[mf][nf].get(3)};
             const float* pc = pbn + 64 * wn + 16 * nf + 4 * q;
             const f32x4 mu = *(const f32x4*)(pc + 2 * BN), rs = *(const f32x4*)(pc + 3 * BN);
             if (a.post.mode == MDS_POST_SILU) {
