@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
     // (they were three exposed memory round trips in the epilogue: the table, then one per fragment row)
     RawV4<T> rys[POST ? MFW : 1][4];
     float pb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI && tid < BN && n0 + tid < N) { pb[0] = a.epi.scale[n0 + tid]; pb[1] = a.epi.shift[n0 + tid]; }   // same for the output transform's table
     if (POST) {
       if (tid < BN && n0 + tid < N) {
 #pragma unroll
@@ -270,11 +271,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
     }
     if (EPI) {                   // scale / shift of the tile's columns
       __syncthreads();
-      if (tid < BN) {
-        const int n = n0 + tid;
-        pbn[tid] = n < N ? a.epi.scale[n] : 0.f;
-        pbn[BN + tid] = n < N ? a.epi.shift[n] : 0.f;
-      }
+      if (tid < BN) { pbn[tid] = pb[0]; pbn[BN + tid] = pb[1]; }
       __syncthreads();
     }
 #pragma unroll
