@@ -296,7 +296,7 @@ def test_pw_fwd_two_chunks_in_flight(be, dt, M, K, N, res, stats, post):
 def test_pw_fwd_two_chunks_in_flight_gated(be, dt, M, K, N, res):
     be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 1), "dev_set")
     try:
-        test_pw_fwd.__wrapped__(be, dt, M, K, N, 4, res, True) if hasattr(test_pw_fwd, "__wrapped__") else test_pw_fwd(be, dt, M, K, N, 4, res, True)
+        test_pw_fwd(be, dt, M, K, N, 4, res, True)   # gated projection (MDS_PRO_GATE) with statistics
     finally:
         be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 0)
 
