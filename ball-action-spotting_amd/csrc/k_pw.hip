@@ -641,24 +641,37 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
 // stores, and no bf16->fp32->bf16 round trip without a prologue); a fragment — 8 rows of one
 // channel — is two ds_read_b64_tr_b16.  Row pitches are odd multiples of 32 bytes so the 8 rows a
 // 32-lane LDS cycle touches sit in distinct bank groups.
-template <int PRO, int NF, int KF, bool DYP>
-__global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a, int rows_per_block) {
+// G > 1: the block is G groups of four waves.  Every group runs the same pipeline over its own 64-row steps of the block's
+// row range (step s belongs to group s % G) with its own staging buffers, and the G partial tiles are summed through LDS
+// before the atomics.  Why: ablation on MI355X (192 -> 1152, 18 400 rows) - 36 us = 10 skeleton + 16 exposed load latency +
+// 6 MFMA + 4 atomics at ~1 wave per SIMD; without atomics 4x the blocks ran in 19 us, with them in 40: the kernel wants
+// occupancy, the atomics want few blocks.  Groups give 4 waves per SIMD at the atomic count of one block.
+template <int PRO, int NF, int KF, bool DYP, int G>
+__global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a, int rows_per_block, int dbg) {
   typedef bf16_t T;
   constexpr int NT = 64 * NF, KT = 16 * KF, XCH = KT / 8, YCH = NT / 8;
   constexpr int LDX = KT + 16, LDY = NT + 16;           // elements; (KT+16)*2 B = odd * 32 B for KT % 32 == 0
   constexpr int XN = WG_ROWS * XCH, YN = WG_ROWS * YCH;  // staging items (rows x 8-channel chunks)
   constexpr int XI = (XN + 255) / 256, YI = (YN + 255) / 256;
   MDS_DYN_SMEM(smem);
-  T* xs = (T*)smem;            // [WG_ROWS][LDX]
-  T* ds = xs + WG_ROWS * LDX;  // [WG_ROWS][LDY]
-  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int grp = G > 1 ? MDS_UNIFORM((int)(threadIdx.x >> 8)) : 0;
+  T* xs = (T*)smem + grp * (WG_ROWS * (LDX + LDY));   // [WG_ROWS][LDX] of this group
+  T* ds = xs + WG_ROWS * LDX;                         // [WG_ROWS][LDY]
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int K = a.K, N = a.N;
   const int ntiles_k = (K + KT - 1) / KT;
-  const int n0 = (blockIdx.y / ntiles_k) * NT, kt0 = (blockIdx.y % ntiles_k) * KT;
-  const long mbeg = (long)blockIdx.x * rows_per_block;
+  // Block -> (row split, output tile), XCD-aware: consecutive block ids go to consecutive
+  // XCDs, so row split s and ALL its output tiles are given to XCD s % 8 - the tiles of one split re-read the same x / dy rows,
+  // which then come from that XCD's L2 once.  (Measured on 112 -> 672, 73 600 rows: 56 us when a split's 12 tiles were
+  // spread over the XCDs, 41 us when they shared one.)
+  const int ntiles = ntiles_k * ((N + NT - 1) / NT), slot = blockIdx.x >> 3;
+  const int tile_id = slot % ntiles, split_id = (int)(blockIdx.x & 7) + 8 * (slot / ntiles);
+  const int n0 = (tile_id / ntiles_k) * NT, kt0 = (tile_id % ntiles_k) * KT;
+  const long mbeg = (long)split_id * rows_per_block;
   long mend = mbeg + rows_per_block;
   if (mend > a.M) mend = a.M;
+  if (mbeg >= a.M) return;   // (row splits are rounded up to a multiple of 8; whole block, before any barrier)
   const T* x = (const T*)a.x;
   const T* dy = (const T*)(DYP ? a.dyp.g.u : a.dy);
   const long ydiff = DYP ? (const T*)a.dyp.y - dy : 0;
@@ -690,16 +703,16 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
     const int it = tid + 256 * p, kx = kt0 + 8 * (it % XCH);
     xr[p] = it / XCH;
     xok[p] = it < XN && kx < K;
-    px[p] = x + (mbeg + xr[p]) * K + (xok[p] ? kx : 0);
+    px[p] = x + (mbeg + WG_ROWS * grp + xr[p]) * K + (xok[p] ? kx : 0);
   }
 #pragma unroll
   for (int p = 0; p < YI; ++p) {
     const int it = tid + 256 * p, n = n0 + 8 * (it % YCH);
     yr[p] = it / YCH;
     yok[p] = it < YN && n < N;
-    py[p] = dy + (mbeg + yr[p]) * N + (yok[p] ? n : 0);
+    py[p] = dy + (mbeg + WG_ROWS * grp + yr[p]) * N + (yok[p] ? n : 0);
   }
-  const long xstep = (long)WG_ROWS * K, ystep = (long)WG_ROWS * N;
+  const long xstep = (long)WG_ROWS * G * K, ystep = (long)WG_ROWS * G * N;
   // the squeeze-excite gate row of every staged x item is requested WITH the item (same issue point): loaded inside the
   // staging loop it cost one exposed L2 round trip per 64-row step - with <= 2 blocks per CU nothing hides it, and it was
   // most of the gated projections' weight-gradient time (94 us per launch inside the step against 56 us ungated)
@@ -724,11 +737,12 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
       py[p] += ystep;
     }
   };
-  issue(mbeg);
+  issue(mbeg + WG_ROWS * grp);
   // fragment rows of a 32-row k-step: 16-lane group q reads rows ra..ra+3 and ra+8..ra+11
   const int ra = 16 * (q >> 1) + 4 * (q & 1);
   const int lrow = (i >> 2), lcol = 4 * (i & 3);  // this lane's part of the 4x16 block it helps to gather
-  for (long mb = mbeg; mb < mend; mb += WG_ROWS) {
+  for (long mb0 = mbeg; mb0 < mend; mb0 += WG_ROWS * G) {   // every group makes the same number of trips (block barriers)
+    const long mb = mb0 + WG_ROWS * grp;
     __syncthreads();  // previous step's fragment reads are done
 #pragma unroll
     for (int p = 0; p < XI; ++p) {
@@ -780,9 +794,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
       }
     }
     __syncthreads();
-    if (mb + WG_ROWS < mend) issue(mb + WG_ROWS);   // next step's loads fly under this step's MFMAs
+    if (mb0 + WG_ROWS * G < mend && !(dbg & 4)) issue(mb + WG_ROWS * G);   // next step's loads fly under this step's MFMAs (rows past mend: zeros)
 #pragma unroll
     for (int ks = 0; ks < WG_ROWS / 32; ++ks) {
+      if (dbg & 2) break;
       const int r0 = 32 * ks + ra + lrow;
       u16x8 yf[NF];
 #pragma unroll
@@ -803,6 +818,35 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
       }
     }
   }
+  if (G > 1) {
+    // sum the G partial tiles through LDS ([group][register][thread]: conflict-free both ways); group g then owns the
+    // fragments j with j % G == g, so every wave of the block issues 1/G of the tile's atomics
+    float* red = (float*)smem;
+    __syncthreads();   // the last step's fragment reads are done: the staging buffers are free
+#pragma unroll
+    for (int u = 0; u < NF; ++u)
+#pragma unroll
+      for (int v = 0; v < KF; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(grp * (NF * KF * 4) + (u * KF + v) * 4 + r) * 256 + tid] = acc[u][v][r];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NF; ++u)
+#pragma unroll
+      for (int v = 0; v < KF; ++v) {
+        if ((u * KF + v) % G != grp) continue;     // wave-uniform
+        const int k = kt0 + 16 * v + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = 0.f;
+#pragma unroll
+          for (int g2 = 0; g2 < G; ++g2) t += red[(g2 * (NF * KF * 4) + (u * KF + v) * 4 + r) * 256 + tid];
+          const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
+          if (n < N && k < K && !(dbg & 1)) atomicAdd(a.dw + (long)n * K + k, t);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < NF; ++u)
 #pragma unroll
@@ -811,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
-        if (n < N && k < K) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r]);
+        if (n < N && k < K && !(dbg & 1)) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r]);
       }
     }
 }
@@ -833,14 +877,28 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   // stream beside the dependent chain, where every block they hold is a CU slot the critical kernel does not get:
   // inside the training step 128 blocks in total measured best (448: +0.25 ms per step, 896: +0.8 ms, 32...224: flat).
   // The multi-million-row layers still want <= 2048 rows per block.
-  long want_blocks = 128 / tiles;
-  if (want_blocks < a->M / 2048) want_blocks = a->M / 2048;
+  const bool dyp = a->dyp.mode != 0;
+  const bool tr = a->dtype == MDS_BF16 && !mds_switch(MDS_SW_WG_OLD);
+  // Groups per block (bf16 kernel): 4 four-wave groups need <= 128 VGPRs (no dy prologue, not the BN+SiLU+gate form).
+  // ALONE four groups are 1.3-2x faster than one (MI355X: 192 -> 1152 at 18 400 rows 36.7 -> 26.1 us, 3D 192 -> 576 32.7 -> 16.8);
+  // INSIDE the training step these launches share the chip with the dependent chain, a 16-wave block with 128 KB of LDS owns
+  // its CU, and the step measured 14.23 ms against 14.04 - so the default stays one group (MDS_KNOB_WG_GROUPS selects 2 / 4).
+  int G = 1;
+  if (tr && !dyp && a->pro.mode != MDS_PRO_BN_SILU_GATE && (mds_knob(MDS_KNOB_WG_GROUPS) == 2 || mds_knob(MDS_KNOB_WG_GROUPS) == 4))
+    G = mds_knob(MDS_KNOB_WG_GROUPS);
+  long want_blocks = (mds_knob(MDS_KNOB_WG_BLOCKS) > 0 ? mds_knob(MDS_KNOB_WG_BLOCKS) : (G > 1 ? 256 : 128)) / tiles;
+  if (G == 1 && want_blocks < a->M / 2048) want_blocks = a->M / 2048;
+  if (G > 1 && want_blocks < a->M / 16384) want_blocks = a->M / 16384;
+  if (tr && !(mds_knob(MDS_KNOB_WG_DBG) & 32)) {   // row splits in multiples of 8: split s and all its output tiles run on XCD s % 8 (see the kernel)
+    want_blocks = (want_blocks + 4) / 8 * 8;
+    if (want_blocks < 8) want_blocks = 8;
+  }
   if (want_blocks < 1) want_blocks = 1;
   long rpb = (a->M + want_blocks - 1) / want_blocks;
-  rpb = ((rpb + WG_ROWS - 1) / WG_ROWS) * WG_ROWS;
+  rpb = ((rpb + WG_ROWS * G - 1) / (WG_ROWS * G)) * (WG_ROWS * G);
   if (rpb < 4 * WG_ROWS) rpb = 4 * WG_ROWS;
-  dim3 grid(cdiv(a->M, rpb), tiles), block(256);
-  const bool dyp = a->dyp.mode != 0;
+  dim3 grid(cdiv(a->M, rpb), tiles), block(256 * G);
+  if (tr) grid = dim3((unsigned)((cdiv(a->M, rpb) + 7) / 8 * 8 * tiles), 1);
   if (dyp) {
     MDS_REQUIRE(a->dyp.g.u && a->dyp.y && a->dyp.lin, "pw_wgrad: dy prologue needs u, y, lin");
     MDS_REQUIRE(a->dyp.g.mode == MDS_G_PLAIN || (a->dyp.g.mode == MDS_G_MASK && a->dyp.g.mask && a->dyp.g.rows_per_group > 0),
@@ -852,9 +910,11 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
        else MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4, false>), grid, block, smem_, stream, *a, (int)rpb); } while (0)
 #define WGT_GO(PRO) \
   do { const size_t smem_ = (size_t)WG_ROWS * (KT + 16 + NT + 16) * sizeof(bf16_t); \
-       if (dyp) MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4, true>), grid, block, smem_, stream, *a, (int)rpb); \
-       else MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4, false>), grid, block, smem_, stream, *a, (int)rpb); } while (0)
-  if (a->dtype == MDS_BF16 && !mds_switch(MDS_SW_WG_OLD)) {
+       if (dyp) MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4, true, 1>), grid, block, smem_, stream, *a, (int)rpb, mds_knob(MDS_KNOB_WG_DBG)); \
+       else if (G == 4) MDS_LAUNCH((pw_wgrad_tr_kernel<PRO == MDS_PRO_BN_SILU_GATE ? 0 : PRO, 2, 4, false, 4>), grid, block, (size_t)4 * 32 * 256 * 4, stream, *a, (int)rpb, mds_knob(MDS_KNOB_WG_DBG)); \
+       else if (G == 2) MDS_LAUNCH((pw_wgrad_tr_kernel<PRO == MDS_PRO_BN_SILU_GATE ? 0 : PRO, 2, 4, false, 2>), grid, block, (size_t)2 * 32 * 256 * 4 > 2 * smem_ ? (size_t)2 * 32 * 256 * 4 : 2 * smem_, stream, *a, (int)rpb, mds_knob(MDS_KNOB_WG_DBG)); \
+       else MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4, false, 1>), grid, block, smem_, stream, *a, (int)rpb, mds_knob(MDS_KNOB_WG_DBG)); } while (0)
+  if (tr) {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: WGT_GO(MDS_PRO_NONE); break;
       case MDS_PRO_AFFINE: WGT_GO(MDS_PRO_AFFINE); break;

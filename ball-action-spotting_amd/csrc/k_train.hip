@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(mds_adamw_args a) {
   float* m = a.exp_avg + T.soff;
   float* v = a.exp_avg_sq + T.soff;
   const float decay = 1.0f - a.lr * a.weight_decay, step = a.lr / a.bias1, rb2 = 1.0f / sqrtf(a.bias2);
+  const float inv_scale = a.grad_scale ? 1.0f / *a.grad_scale : 1.0f;    // GradScaler: unscale on load (torch multiplies by 1/scale too)
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    gg *= inv_scale;
     pp *= decay;
     mm = a.beta1 * mm + (1.0f - a.beta1) * gg;
     vv = a.beta2 * vv + (1.0f - a.beta2) * gg * gg;
@@ -93,6 +95,62 @@ extern "C" int mds_multi_adamw(const mds_adamw_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->bias1 > 0.f && a->bias2 > 0.f, "multi_adamw: bias corrections must be positive (step >= 1)");
   MDS_LAUNCH(adamw_kernel, dim3(a->nchunks), dim3(256), 0, stream, *a);
   return mds_check_launch("multi_adamw");
+}
+
+// SGD with momentum / Nesterov over the same tables (torch.optim.SGD: weight decay added to the gradient, buffer
+// initialised WITH the first gradient, dampening applied from the second step on)
+__global__ __launch_bounds__(256) void sgd_kernel(mds_sgd_args a) {
+  if (a.found_inf && *a.found_inf != 0.f) return;
+  const int ti = a.chunks[2 * blockIdx.x], c0 = a.chunks[2 * blockIdx.x + 1];
+  const mds_opt_tensor T = a.table[ti];
+  const long beg = (long)c0 * MDS_OPT_CHUNK;
+  long end = beg + MDS_OPT_CHUNK;
+  if (end > T.n) end = T.n;
+  float* p = T.p;
+  const float* g = a.gbase + T.goff;
+  const bool mom = a.momentum != 0.f;
+  float* b = mom ? a.momentum_buf + T.soff : p;      // (never dereferenced without momentum)
+  const float inv_scale = a.grad_scale ? 1.0f / *a.grad_scale : 1.0f;
+  const float keep = 1.0f - a.dampening;
+  auto upd = [&](float& pp, float gg, float& bb) {
+    gg = gg * inv_scale + a.weight_decay * pp;
+    if (mom) {
+      bb = a.first ? gg : a.momentum * bb + keep * gg;
+      gg = a.nesterov ? gg + a.momentum * bb : bb;
+    }
+    pp -= a.lr * gg;
+  };
+  const bool al = ((((uintptr_t)(p + beg)) | ((uintptr_t)(g + beg)) | ((uintptr_t)(b + beg))) & 15) == 0;
+  long o0 = beg;
+  if (al) {
+    const long nv = (end - beg) >> 2;
+    for (long e = threadIdx.x; e < nv; e += 256) {
+      const long o = beg + 4 * e;
+      f32x4 pp = *(f32x4*)(p + o), bb = mom ? *(f32x4*)(b + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 gg = *(const f32x4*)(g + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pj = pp[j], bj = bb[j];
+        upd(pj, gg[j], bj);
+        pp[j] = pj; bb[j] = bj;
+      }
+      *(f32x4*)(p + o) = pp;
+      if (mom) *(f32x4*)(b + o) = bb;
+    }
+    o0 = beg + 4 * nv;
+  }
+  for (long o = o0 + threadIdx.x; o < end; o += 256) {
+    float bj = mom ? b[o] : 0.f;
+    upd(p[o], g[o], bj);
+    if (mom) b[o] = bj;
+  }
+}
+extern "C" int mds_multi_sgd(const mds_sgd_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->table && a->chunks && a->nchunks > 0, "multi_sgd: bad args");
+  MDS_REQUIRE(a->momentum == 0.f || a->momentum_buf, "multi_sgd: momentum needs a buffer");
+  MDS_REQUIRE(!a->nesterov || (a->momentum > 0.f && a->dampening == 0.f), "multi_sgd: Nesterov momentum requires a momentum and zero dampening");
+  MDS_LAUNCH(sgd_kernel, dim3(a->nchunks), dim3(256), 0, stream, *a);
+  return mds_check_launch("multi_sgd");
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(mds_ema_args a) {

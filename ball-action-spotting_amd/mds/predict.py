@@ -56,6 +56,7 @@ class StreamPredictor:
         self.nfeat = (self.S - 1) * self.span + self.max_chunk + 8          # feature store: one slot per stack END index (mod)
         self.use_graphs = use_graphs
         self._built = None
+        self.encoder_passes = 0          # 2D-encoder passes issued so far (steady state: one per chunk)
         self.reset_buffers()
 
     def close(self):
@@ -79,6 +80,7 @@ class StreamPredictor:
         self.feat_tag = [None] * self.nfeat
 
     def _build(self, frame: torch.Tensor):
+        self.close()             # plans of a previous frame shape / device go back to the module's cache (not pinned forever)
         dev = frame.device
         h, w = frame.shape[-2:]
         assert frame.dtype == torch.uint8 and h <= self.H and w <= self.W, "raw uint8 frames no larger than the padded size"
@@ -197,14 +199,22 @@ class StreamPredictor:
         dev, b = p2d.device, (2 if self.tta else 1)
         wins = [self.idx.make_stack_indexes(i - self._predict_offset) for i in indexes]
         stacks = [[tuple(w_[s * self.ss:(s + 1) * self.ss]) for s in range(self.S)] for w_ in wins]
-        # stacks whose features are not in the store yet; in steady state exactly the newest stack of every frame
-        missing = [[st for st in sts if self.feat_tag[st[-1] % self.nfeat] != st] for sts in stacks]
-        rounds = max(len(m_) for m_ in missing)
-        for r in range(rounds):           # > 1 only right after a (re)start of the stream
-            todo = [m_[min(len(m_) - 1 - r, len(m_) - 1)] if len(m_) > r else stacks[j][-1] for j, m_ in enumerate(missing)]
+        # stacks whose features are not in the store yet, collected ONCE over the whole chunk: windows sit 6 frames apart, so
+        # the newest stack of frame j is also the second newest of frame j + 6 of the same chunk - it is encoded once.  In
+        # steady state that is exactly the newest stack of every frame: one pass of n stacks.
+        uniq = {}
+        for sts in stacks:
+            for st in sts:
+                if self.feat_tag[st[-1] % self.nfeat] != st:
+                    uniq.setdefault(st, None)
+        pending = list(uniq)
+        for r0 in range(0, len(pending), n):           # > 1 pass only right after a (re)start of the stream
+            todo = pending[r0:r0 + n]
+            todo = todo + [todo[-1]] * (n - len(todo))   # a short last pass repeats its last stack (same features, same slot)
             sel = self._idx(c, ("sel", tuple(st[0] % self.nframes for st in todo)), [i % self.nframes for st in todo for i in st], dev)
             torch.index_select(self.frames, 0, sel, out=p2d.x_u8.tensor.view(n * self.ss, *self.frames.shape[1:]))
             self._replay(c, "2d")
+            self.encoder_passes += 1
             fslots = [st[-1] % self.nfeat for st in todo]
             si = self._idx(c, ("fs", tuple(fslots)), fslots, dev)
             self.store[si] = p2d.feat.tensor.view(b, n, self.f).transpose(0, 1)      # images: n originals, then their n mirrored copies

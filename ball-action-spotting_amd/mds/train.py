@@ -4,6 +4,7 @@ Drop-ins for the reference's classes (same constructor arguments and call signat
 
   FocalLoss   <- src/losses.py:53-66      (registered as "focal_loss" in src/argus_models.py:22-25)
   FusedAdamW  <- torch.optim.AdamW        (argus builds it from ("AdamW", {...}), configs/ball_action/*.py:51)
+  FusedSGD    <- torch.optim.SGD          (("SGD", {momentum 0.9, nesterov}), configs/ball_action/ball_finetune_long_004.py:51-55)
   ModelEma    <- src/ema.py:13-55         (created in scripts/ball_action/train.py:80-82, updated every step,
                                            src/argus_models.py:65-66)
 
@@ -103,38 +104,72 @@ def _tensor_table(entries, device):
     return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
 
 
-# ------------------------------------------------------------------------------------------------ AdamW
-class FusedAdamW(torch.optim.Optimizer):
-    """torch.optim.AdamW (decoupled weight decay, bias correction; no amsgrad / maximize) as one launch per param group.
+# ------------------------------------------------------------------------------------------------ optimizers
+class _FusedOptimizer(torch.optim.Optimizer):
+    """What FusedAdamW and FusedSGD share: per parameter group, flat fp32 state buffers (exposed through `state[p][...]`
+    as views, so `state_dict()` has torch's layout), the device tables of one launch over every tensor, and the
+    GradScaler hand-shake.
 
-    The moments live in two flat fp32 buffers per group (exposed through `state[p]['exp_avg' | 'exp_avg_sq']` as
-    views, so `state_dict()` has torch's layout); gradients are addressed relative to one base pointer when they are
-    views of one buffer — which is how mds.MultiDimStacker hands them over — so the device table is built once."""
+    `_step_supports_amp_scaling`: `GradScaler.step` (src/argus_models.py:62) then calls `step()` directly with
+    `self.grad_scale` / `self.found_inf` set to device tensors - no unscale pass over the gradients and no host
+    synchronisation to decide whether to skip; the kernels divide the gradients by the scale on load and return
+    at once when an inf / nan was found.
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, *, maximize=False):
-        if amsgrad or maximize:
-            raise NotImplementedError("mds FusedAdamW: amsgrad / maximize are not implemented (no reference config uses them)")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._g = {}          # group index -> dict(exp_avg, exp_avg_sq, soff, step, cache)
+    One step counter per GROUP (torch keeps one per parameter): they differ only if a parameter of the group has no
+    gradient on some steps, which the reference's training loop never does."""
+    _step_supports_amp_scaling = True
+    STATE_NAMES = ()
 
     def _group_state(self, gi, group):
         gs = self._g.get(gi)
+        ps = list(group["params"])
+        dev = ps[0].device
+        if gs is not None and gs["device"] != dev:           # module.to(device) after the first step: move the state along
+            old = gs
+            gs = None
+        else:
+            old = None
         if gs is None:
-            ps = [p for p in group["params"]]
-            dev = ps[0].device
             assert all(p.dtype == torch.float32 and p.device == dev and p.is_contiguous() for p in ps), \
-                "mds FusedAdamW: fp32 contiguous parameters on one device"
+                f"mds {type(self).__name__}: fp32 contiguous parameters on one device"
             soff, off = {}, 0
             for p in ps:
                 soff[id(p)] = off
-                off += (p.numel() + 3) // 4 * 4          # keep every tensor's moments 16-byte aligned
-            gs = dict(exp_avg=torch.zeros(off, device=dev), exp_avg_sq=torch.zeros(off, device=dev), soff=soff, step=0, cache=None)
+                off += (p.numel() + 3) // 4 * 4          # keep every tensor's state 16-byte aligned
+            gs = dict(soff=soff, step=old["step"] if old else 0, cache=None, device=dev)
+            for name in self.STATE_NAMES:
+                gs[name] = old[name].to(dev) if old else torch.zeros(off, device=dev)
             for p in ps:
                 o = soff[id(p)]
-                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": gs["exp_avg"][o:o + p.numel()].view_as(p),
-                                 "exp_avg_sq": gs["exp_avg_sq"][o:o + p.numel()].view_as(p)}
+                self.state[p] = {"step": torch.tensor(float(gs["step"])),
+                                 **{name: gs[name][o:o + p.numel()].view_as(p) for name in self.STATE_NAMES}}
             self._g[gi] = gs
         return gs
+
+    def _tables(self, gs, active, grads):
+        """device tables of this group's launch; rebuilt when the set of tensors, a parameter's or a gradient's address changes"""
+        dev = active[0].device
+        base = grads[0].untyped_storage().data_ptr()
+        shared = all(g.untyped_storage().data_ptr() == base for g in grads)
+        if not shared:
+            base = 0
+        sig = (shared, tuple(id(p) for p in active), tuple(p.data_ptr() for p in active), tuple(g.data_ptr() - base for g in grads))
+        cache = gs["cache"]
+        if cache is None or cache["sig"] != sig:
+            entries = [(p.data_ptr(), (g.data_ptr() - base) // 4, gs["soff"][id(p)], p.numel()) for p, g in zip(active, grads)]
+            chunks, nchunks = _chunk_table([p.numel() for p in active], dev)
+            cache = gs["cache"] = dict(sig=sig, table=_tensor_table(entries, dev), chunks=chunks, nchunks=nchunks)
+        cache["keep"] = grads            # the launch is asynchronous: the gradient buffer must outlive it
+        return cache, base
+
+    def _amp(self, dev):
+        """(found_inf, grad_scale) device tensors set by GradScaler.step for this call, or None"""
+        fi, sc = getattr(self, "found_inf", None), getattr(self, "grad_scale", None)
+        fix = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).reshape(1)
+        return fix(fi), fix(sc)
+
+    def _launch(self, gs, group, active, cache, base, found_inf, grad_scale):
+        raise NotImplementedError
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -147,30 +182,15 @@ class FusedAdamW(torch.optim.Optimizer):
             if not active:
                 continue
             gs = self._group_state(gi, group)
-            dev = active[0].device
             grads = [p.grad for p in active]
-            assert all(g.dtype == torch.float32 and g.is_contiguous() for g in grads), "mds FusedAdamW: fp32 contiguous gradients"
-            base = grads[0].untyped_storage().data_ptr()
-            shared = all(g.untyped_storage().data_ptr() == base for g in grads)
-            if not shared:
-                base = 0
-            sig = (shared, tuple(id(p) for p in active), tuple(g.data_ptr() - base for g in grads))
-            cache = gs["cache"]
-            if cache is None or cache["sig"] != sig:
-                entries = [(p.data_ptr(), (g.data_ptr() - base) // 4, gs["soff"][id(p)], p.numel()) for p, g in zip(active, grads)]
-                chunks, nchunks = _chunk_table([p.numel() for p in active], dev)
-                cache = gs["cache"] = dict(sig=sig, table=_tensor_table(entries, dev), chunks=chunks, nchunks=nchunks)
-            gs["step"] += 1
-            t = gs["step"]
-            b1, b2 = group["betas"]
-            lib = _lib(active[0])
-            args = cabi.make("mds_adamw_args", table=cache["table"], chunks=cache["chunks"], nchunks=cache["nchunks"], gbase=base,
-                             exp_avg=gs["exp_avg"], exp_avg_sq=gs["exp_avg_sq"], lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
-                             eps=float(group["eps"]), weight_decay=float(group["weight_decay"]), bias1=1.0 - b1 ** t,
-                             bias2=1.0 - b2 ** t, found_inf=None)
+            assert all(g.dtype == torch.float32 and g.is_contiguous() for g in grads), f"mds {type(self).__name__}: fp32 contiguous gradients"
+            cache, base = self._tables(gs, active, grads)
+            dev = active[0].device
+            found_inf, grad_scale = self._amp(dev)
+            gs["step"] += 1      # (a step GradScaler skips on the device still counts here; torch's fused optimizers rewind it on the device)
             with torch.cuda.device(dev) if dev.type == "cuda" else _null():
-                lib.check(lib.fn["multi_adamw"](C.byref(args), _stream(active[0])), "multi_adamw")
-            cache["keep"] = grads            # the launch is asynchronous: the gradient buffer must outlive it
+                self._launch(gs, group, active, cache, base, found_inf, grad_scale)
+            cache["amp"] = (found_inf, grad_scale)
         return loss
 
     def state_dict(self):
@@ -193,9 +213,57 @@ class FusedAdamW(torch.optim.Optimizer):
             for p in group["params"]:
                 st = saved.get(id(p))
                 if st:
-                    self.state[p]["exp_avg"].copy_(st["exp_avg"])
-                    self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
-                    gs["step"] = int(float(st["step"]))
+                    for name in self.STATE_NAMES:
+                        if st.get(name) is not None:
+                            self.state[p][name].copy_(st[name])
+                    if "step" in st:
+                        gs["step"] = int(float(st["step"]))
+
+
+class FusedAdamW(_FusedOptimizer):
+    """torch.optim.AdamW (decoupled weight decay, bias correction; no amsgrad / maximize) as one launch per param group.
+    Gradients are addressed relative to one base pointer when they are views of one buffer - which is how
+    mds.MultiDimStacker hands them over - so the device table is built once."""
+    STATE_NAMES = ("exp_avg", "exp_avg_sq")
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, *, maximize=False):
+        if amsgrad or maximize:
+            raise NotImplementedError("mds FusedAdamW: amsgrad / maximize are not implemented (no reference config uses them)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._g = {}          # group index -> dict(exp_avg, exp_avg_sq, soff, step, cache, device)
+
+    def _launch(self, gs, group, active, cache, base, found_inf, grad_scale):
+        t = gs["step"]
+        b1, b2 = group["betas"]
+        lib = _lib(active[0])
+        args = cabi.make("mds_adamw_args", table=cache["table"], chunks=cache["chunks"], nchunks=cache["nchunks"], gbase=base,
+                         exp_avg=gs["exp_avg"], exp_avg_sq=gs["exp_avg_sq"], lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
+                         eps=float(group["eps"]), weight_decay=float(group["weight_decay"]), bias1=1.0 - b1 ** t,
+                         bias2=1.0 - b2 ** t, found_inf=found_inf, grad_scale=grad_scale)
+        lib.check(lib.fn["multi_adamw"](C.byref(args), _stream(active[0])), "multi_adamw")
+
+
+class FusedSGD(_FusedOptimizer):
+    """torch.optim.SGD (momentum, dampening, weight_decay, nesterov; no maximize) as one launch per param group - the
+    optimizer of the long-sequence fine-tune: ("SGD", {lr, momentum 0.9, nesterov True}),
+    configs/ball_action/ball_finetune_long_004.py:51-55."""
+    STATE_NAMES = ("momentum_buffer",)
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, *, maximize=False):
+        if maximize:
+            raise NotImplementedError("mds FusedSGD: maximize is not implemented (no reference config uses it)")
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov))
+        self._g = {}
+
+    def _launch(self, gs, group, active, cache, base, found_inf, grad_scale):
+        lib = _lib(active[0])
+        args = cabi.make("mds_sgd_args", table=cache["table"], chunks=cache["chunks"], nchunks=cache["nchunks"], gbase=base,
+                         momentum_buf=gs["momentum_buffer"], lr=float(group["lr"]), momentum=float(group["momentum"]),
+                         dampening=float(group["dampening"]), weight_decay=float(group["weight_decay"]),
+                         nesterov=int(bool(group["nesterov"])), first=int(gs["step"] == 1), found_inf=found_inf, grad_scale=grad_scale)
+        lib.check(lib.fn["multi_sgd"](C.byref(args), _stream(active[0])), "multi_sgd")
 
 
 # ------------------------------------------------------------------------------------------------ EMA
@@ -234,17 +302,19 @@ class ModelEma(nn.Module):
         if self._cache is None or self._cache["sig"] != sig:
             entries = [(e.data_ptr(), m.data_ptr() // 4, 0, e.numel()) for e, m in fl]     # absolute source addresses (gbase = NULL)
             chunks, nchunks = _chunk_table([e.numel() for e, _ in fl], dev)
-            self._cache = dict(sig=sig, table=_tensor_table(entries, dev), chunks=chunks, nchunks=nchunks)
+            self._cache = dict(sig=sig, table=_tensor_table(entries, dev) if fl else None, chunks=chunks, nchunks=nchunks)
         c = self._cache
-        lib = _lib(evs[0])
-        args = cabi.make("mds_ema_args", table=c["table"], chunks=c["chunks"], nchunks=c["nchunks"], gbase=None, decay=float(self.decay))
-        with torch.cuda.device(dev) if dev.type == "cuda" else _null():
-            lib.check(lib.fn["multi_ema"](C.byref(args), _stream(evs[0])), "multi_ema")
+        if c["nchunks"]:       # (a state_dict without fp32 entries has nothing to launch)
+            lib = _lib(evs[0])
+            args = cabi.make("mds_ema_args", table=c["table"], chunks=c["chunks"], nchunks=c["nchunks"], gbase=None, decay=float(self.decay))
+            with torch.cuda.device(dev) if dev.type == "cuda" else _null():
+                lib.check(lib.fn["multi_ema"](C.byref(args), _stream(evs[0])), "multi_ema")
         ints = [(e, m) for e, m in rest if e.numel() == 1 and not e.is_floating_point()]
         if ints:
-            es = torch.stack([e.reshape(()) for e, _ in ints]).double()
-            ms = torch.stack([m.reshape(()) for _, m in ints]).double()
-            new = (self.decay * es + (1. - self.decay) * ms).to(ints[0][0].dtype)     # the reference's float blend + truncating copy_
+            es = torch.stack([e.reshape(()) for e, _ in ints])
+            ms = torch.stack([m.reshape(()) for _, m in ints])
+            # src/ema.py:52: `decay * e + (1 - decay) * m` on integer tensors promotes to float32, then copy_ truncates
+            new = (self.decay * es + (1. - self.decay) * ms).to(ints[0][0].dtype)
             torch._foreach_copy_([e.reshape(()) for e, _ in ints], list(new.unbind()))
         for e, m in rest:
             if not (e.numel() == 1 and not e.is_floating_point()):

@@ -16,9 +16,12 @@ Workloads (--config):
 A step is one pass of the hot path over one batch; inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     : the dominant HIP kernel (largest share of the per-kernel pass, fwd and bwd uses of one kernel folded
-                 together), algorithmic bytes (or flops) per launch / HIP-event launch time, PMC traffic measured by a
-                 rocprofv3 child run of this very script, and the whole-path fraction of SURVEY.md §8(d)
+  roofline     : the dominant HIP kernel family IN THE STEP (rocprofv3 --kernel-trace --stats child run of this very script,
+                 both HIP streams running; fwd and bwd uses of one kernel folded together): algorithmic bytes (or flops)
+                 per launch / its average in-step launch duration; `isolated` keeps the per-launch HIP-event numbers (each
+                 launch timed alone); PMC traffic from further child runs; the whole-path fraction of SURVEY.md §8(d)
+  other_configs: BASELINE.json configs[3] (long004, its own SGD-Nesterov recipe) and configs[4] (predict: reference API
+                 frame by frame and predict_batch, with its cpu_baseline), each a child run of this script
   cpu_baseline : the oracle (kind "port") timed on this box's host cores, bounded sample.
 """
 import argparse
@@ -49,14 +52,17 @@ CONFIG = dict(model_name="tf_efficientnetv2_b0.in1k", num_classes=2, num_frames=
               drop_rate=0.2, drop_path_rate=0.2, act_layer="silu")
 
 
-def focal_loss(logits, target, gamma=1.2):
-    """sigmoid focal loss, alpha=-1, mean (reference src/losses.py:34-50) in fp32."""
+def focal_loss(logits, target, gamma=1.2, alpha=-1.0):
+    """sigmoid focal loss, mean (reference src/losses.py:34-50) in fp32."""
     import torch
     x = logits.float()
     p = torch.sigmoid(x)
     ce = torch.nn.functional.binary_cross_entropy_with_logits(x, target, reduction="none")
     p_t = p * target + (1 - p) * (1 - target)
-    return (ce * (1 - p_t) ** gamma).mean()
+    loss = ce * (1 - p_t) ** gamma
+    if alpha >= 0:
+        loss = (alpha * target + (1 - alpha) * (1 - target)) * loss
+    return loss.mean()
 
 
 def cpu_baseline(max_seconds=20.0):
@@ -162,6 +168,59 @@ def pmc_child(counters, extra_args, timeout=240):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def trace_child(extra_args, steps=8, timeout=300):
+    """Run this script under `rocprofv3 --kernel-trace --stats` (both HIP streams running, the real step) and return
+    {kernel family: {"calls": n, "total_us": t, "avg_us": t / n}} from its kernel_stats.csv - the IN-STEP launch durations."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="mds_kt_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--stats", "-d", tmp, "-o", "kt", "--output-format", "csv", "--", sys.executable,
+           os.path.abspath(__file__), "--steps", str(steps), "--warmup", "2", "--profile-steps", "0", "--no-cpu-baseline", "--no-pmc",
+           "--no-other-configs", *extra_args]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if not files:
+            return None
+        if os.environ.get("MDS_KEEP_TRACE_STATS"):      # developer: keep the csv (copied to profiles/ by hand)
+            shutil.copy(files[0], os.environ["MDS_KEEP_TRACE_STATS"])
+        out = {}
+        for r in csv.DictReader(open(files[0])):
+            fam = kernel_family(r["Name"])
+            e = out.setdefault(fam, {"calls": 0, "total_us": 0.0})
+            e["calls"] += int(r["Calls"]); e["total_us"] += float(r["TotalDurationNs"]) * 1e-3
+        for e in out.values():
+            e["avg_us"] = e["total_us"] / max(e["calls"], 1)
+        out["_steps"] = steps + 2
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def other_config(name, extra, timeout=600):
+    """One more BASELINE.json config measured by a child run of this script (fresh process: the 12 GB plan of the main
+    workload is gone); returns its JSON line as a dict with the bulky per-kernel fields dropped."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--no-pmc", "--profile-steps", "0", "--no-other-configs", *extra]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, timeout=timeout, capture_output=True, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        for k in ("kernel_breakdown", "top_launches"):
+            d.pop(k, None)
+        return d
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {str(e)[:200]}"}
 
 
 def pmc_for(dom, extra_args):
@@ -328,7 +387,8 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child runs that measure roofline.traffic")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child runs that measure roofline.traffic and the in-step kernel durations")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of configs 4 and 5 (`other_configs` of the train line)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--chunk", type=int, default=8, help="--config predict: consecutive frames per predictor call")
     ap.add_argument("--torch-step", action="store_true", help="torch's focal loss + torch.optim.AdamW(fused=True) instead of mds.train")
@@ -371,10 +431,16 @@ def main():
         parallel.data_parallel(model)
     from mds import train as mtrain
     trainable = [p for p in model.parameters() if p.requires_grad]
+    long = args.config == "long004"
+    # the config's own recipe: sampling_weights_001.py:46-55 AdamW + focal(alpha -1, gamma 1.2); ball_finetune_long_004.py:46-55
+    # SGD(momentum 0.9, nesterov) at lr = get_lr(1e-3, 4) + focal(alpha 0.4, gamma 1.2)
+    lr = 1e-3 * 4 / 4 if long else 3e-4
     if args.torch_step:
-        opt, loss_fn = torch.optim.AdamW(trainable, lr=3e-4, fused=True), focal_loss
-    else:      # loss value+gradient in one launch, AdamW over all tensors in one launch
-        opt, loss_fn = mtrain.FusedAdamW(trainable, lr=3e-4), mtrain.FocalLoss(alpha=-1.0, gamma=1.2)
+        opt = torch.optim.SGD(trainable, lr=lr, momentum=0.9, nesterov=True) if long else torch.optim.AdamW(trainable, lr=lr, fused=True)
+        loss_fn = (lambda o, t: focal_loss(o, t, alpha=0.4)) if long else focal_loss
+    else:      # loss value+gradient in one launch, the optimizer over all tensors in one launch
+        opt = mtrain.FusedSGD(trainable, lr=lr, momentum=0.9, nesterov=True) if long else mtrain.FusedAdamW(trainable, lr=lr)
+        loss_fn = mtrain.FocalLoss(alpha=0.4 if long else -1.0, gamma=1.2)
     B = args.batch
     x = torch.rand(B, T, args.height, args.width, device=dev, generator=torch.Generator(dev).manual_seed(1234 + rank))
     target = torch.randint(0, 2, (B, 2), device=dev, generator=torch.Generator(dev).manual_seed(4321)).float()
@@ -455,16 +521,53 @@ def main():
         if world == 1 and not args.no_pmc:
             extra = ["--config", args.config, "--batch", str(B), "--height", str(args.height), "--width", str(args.width),
                      "--dtype", args.dtype] + (["--torch-step"] if args.torch_step else [])
+            # IN-STEP durations: the per-kernel pass above times each launch ALONE on one stream; inside the step the weight
+            # gradients run on a second stream beside the dependent chain.  A rocprofv3 --kernel-trace --stats child run of this
+            # script gives every kernel's duration in the real step; the dominant family and the roofline fraction come from
+            # THAT trace (profiles/rNN_bench_kernel_stats.csv is the same command), the isolated numbers stay as `isolated`.
+            kt = trace_child(extra)
+            if kt:
+                nst = kt.pop("_steps")
+                fams = {k: v for k, v in kt.items() if k in agg}
+                if fams:
+                    isolated = dict(roofline)
+                    dom = max(fams, key=lambda k: fams[k]["total_us"])
+                    a = agg[dom]
+                    n_launch = a[1] // args.profile_steps
+                    avg_bytes, avg_flops = a[2] / a[1], a[3] / a[1]
+                    avg_us = fams[dom]["avg_us"]
+                    gbs, tfl = avg_bytes / avg_us / 1e3, avg_flops / avg_us / 1e6
+                    hbm_bound = (avg_bytes / (HBM_PEAK_GBS * 1e9)) >= (avg_flops / (MFMA_PEAK_TFLOPS * 1e12))
+                    tot_us = sum(v["total_us"] for v in fams.values())
+                    roofline.update({"kernel": dom, "bound": "hbm" if hbm_bound else "mfma",
+                                     "achieved": round(gbs if hbm_bound else tfl, 2), "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS,
+                                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                                     "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfl / MFMA_PEAK_TFLOPS), 4),
+                                     "avg_launch_us": round(avg_us, 2), "launches_per_step": n_launch,
+                                     "alg_bytes_per_launch": int(avg_bytes), "alg_flops_per_launch": int(avg_flops),
+                                     "kernel_TFLOPs": round(tfl, 1), "kernel_mfma_frac": round(tfl / MFMA_PEAK_TFLOPS, 4),
+                                     "share_of_kernel_time": round(fams[dom]["total_us"] / tot_us, 3),
+                                     "timing": "in-step: rocprofv3 --kernel-trace --stats child run of this script, both HIP streams running",
+                                     "trace_launches_per_step": round(fams[dom]["calls"] / nst, 1),
+                                     "isolated": {k: isolated.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_us", "share_of_kernel_time")},
+                                     "in_step_ms_per_step": {k: round(v["total_us"] / nst / 1e3, 3) for k, v in
+                                                             sorted(fams.items(), key=lambda kv: -kv[1]["total_us"])[:12]}})
             roofline.update(pmc_for(dom, extra))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+    others = None
+    if rank == 0 and world == 1 and args.config == "train" and full and not args.no_other_configs:
+        # BASELINE.json configs[3] and configs[4] beside the headline line (child runs of this script, 20 steps / 300 frames)
+        torch.cuda.empty_cache()      # (the children are separate processes on the same 288 GB device)
+        others = {"long004": other_config("long004", ["--steps", "20", "--warmup", "5", "--no-cpu-baseline"]),
+                  "predict": other_config("predict", ["--steps", "300"])}
 
     if rank == 0:
-        stepk = "torch focal loss / AdamW(fused)" if args.torch_step else "mds.train fused focal loss / multi-tensor AdamW"
+        stepk = "torch focal loss / optimizer" if args.torch_step else "mds.train fused focal loss / multi-tensor optimizer"
         what = {"train": f"fwd + focal loss + bwd + grad all-reduce + AdamW ({stepk})",
-                "long004": "frozen 2D encoder fwd (BN in train mode) + tail fwd/bwd + focal loss + grad all-reduce + AdamW"}[args.config]
+                "long004": f"frozen 2D encoder fwd (BN in train mode) + tail fwd/bwd + focal loss (alpha 0.4) + grad all-reduce + SGD-Nesterov ({stepk})"}[args.config]
         name = {"train": "sampling_weights_001", "long004": "ball_finetune_long_004"}[args.config]
         out = {"metric": f"frame-windows/sec (fwd+bwd) at {T}x{args.height}x{args.width}, batch {B}", "value": round(wps, 3),
                "unit": "frame-windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -475,6 +578,8 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
                "top_launches": top_launches if args.profile_steps > 0 else None,
                "loss": round(float(loss.detach()), 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+        if others is not None:
+            out["other_configs"] = others
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 111
+#define MDS_VERSION 112
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -44,7 +44,10 @@ const char* mds_last_error(void);
 #define MDS_KNOB_DW_ORDER 1      /* 1: depthwise kernels take the channel chunk as the fast grid index (A/B switch) */
 #define MDS_KNOB_PW_WRES 2     /* 1: mds_pw_fwd never takes the filter-resident kernel (A/B switch); 2: takes it at any M (tests); 3: lower row bar */
 #define MDS_KNOB_PW_DEEP 3     /* 1: mds_pw_fwd keeps TWO K chunks in flight for the K-heavy layers (study variant: slower inside the step) */
-#define MDS_KNOB_COUNT 4
+#define MDS_KNOB_WG_DBG 4      /* ablation bits of the 1x1 weight-gradient kernels (measurement only) */
+#define MDS_KNOB_WG_BLOCKS 5   /* split-M block budget of mds_pw_wgrad (0 = default) */
+#define MDS_KNOB_WG_GROUPS 6   /* 2 / 4: mds_pw_wgrad runs that many four-wave groups per block (faster alone, slower inside the step) */
+#define MDS_KNOB_COUNT 7
 int mds_dev_set(int knob, int value);
 
 /* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
@@ -563,9 +566,29 @@ typedef struct {
   float lr, beta1, beta2, eps, weight_decay;
   float bias1, bias2;            /* 1 - beta1^t, 1 - beta2^t for this step */
   const float* found_inf;        /* optional [1] (GradScaler): the whole update is skipped when != 0 */
+  const float* grad_scale;       /* optional [1] (GradScaler): gradients are divided by it on load (no unscale pass) */
 } mds_adamw_args;
 #define MDS_OPT_CHUNK 4096
 int mds_multi_adamw(const mds_adamw_args* a, mds_stream_t stream);
+
+/* Multi-tensor SGD with momentum / Nesterov (torch.optim.SGD semantics) - the optimizer of the long-sequence
+ * fine-tune, configs/ball_action/ball_finetune_long_004.py:51-55 ("SGD", momentum 0.9, nesterov).  Per element
+ *   g = grad / grad_scale + weight_decay * p;  buf = first ? g : momentum * buf + (1 - dampening) * g;
+ *   p -= lr * (nesterov ? g + momentum * buf : buf)          (momentum == 0: p -= lr * g, no buffer access)
+ * Same tables as mds_multi_adamw (soff addresses the momentum buffer).                                     */
+typedef struct {
+  const mds_opt_tensor* table;
+  const int* chunks;
+  int nchunks;
+  const float* gbase;
+  float* momentum_buf;           /* flat; may be NULL when momentum == 0 */
+  float lr, momentum, dampening, weight_decay;
+  int nesterov;
+  int first;                     /* 1 on the first step of the group: buf = g (torch initialises the buffer with the gradient) */
+  const float* found_inf;        /* optional [1]: skip the update when != 0 */
+  const float* grad_scale;       /* optional [1]: gradients are divided by it on load */
+} mds_sgd_args;
+int mds_multi_sgd(const mds_sgd_args* a, mds_stream_t stream);
 
 /* Multi-tensor exponential moving average: ema = decay*ema + (1-decay)*model for every float entry of
  * the state_dict (src/ema.py:47-55); table entries: p = ema tensor, goff = offset of the model tensor

@@ -203,3 +203,49 @@ def test_fp32_full_window_vs_oracle_config4_frozen_encoder():
     assert errs[0][0] < 2e-3, errs[:6]
     for (n, b), (_, b2) in zip(ref.named_buffers(), prod.named_buffers()):
         assert _rel(b2, b, 1e-6) < 1e-3, n          # frozen encoder still updates its running statistics
+
+
+def test_config4_batch4_properties_with_its_own_recipe():
+    """BASELINE configs[3] at its full shape, 4 x 33 x 736 x 1280 bf16, frozen encoder in train mode, the config's own
+    recipe (focal alpha 0.4 / gamma 1.2, SGD momentum 0.9 Nesterov at lr 1e-3; ball_finetune_long_004.py:46-55,67):
+    window-permutation equivariance of the logits, the bias-gradient identity, no encoder gradients, running statistics of
+    the frozen encoder still updated, and the loss goes down over a few fused SGD steps."""
+    from mds import train as mtrain
+    torch.manual_seed(4)
+    kw = dict(orc.BASIC_CONFIG_KWARGS, num_frames=33, drop_rate=0.0, drop_path_rate=0.0)
+    m = mds.MultiDimStacker(**kw).to(DEV).train()
+    for p in m.conv2d_encoder.parameters():
+        p.requires_grad_(False)
+    x = torch.rand(4, 33, 736, 1280, device=DEV, generator=torch.Generator(DEV).manual_seed(9))
+    tgt = torch.tensor([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0], [0.0, 0.0]], device=DEV)
+    loss_fn = mtrain.FocalLoss(alpha=0.4, gamma=1.2)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = m(x)
+    y1.retain_grad()
+    l1 = loss_fn(y1, tgt)
+    l1.backward()
+    assert all(p.grad is None for p in m.conv2d_encoder.parameters())
+    assert torch.allclose(m.classifier.bias.grad, y1.grad.float().sum(0), rtol=1e-4, atol=1e-7)
+    g1 = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+    assert g1.numel() == 1160163 + 2 * (2816 - 1280) and torch.isfinite(g1).all()     # SURVEY 8(e): the tail's parameters (classifier 2816 -> 2)
+    assert not torch.equal(state["conv2d_encoder.bn1.running_mean"], m.conv2d_encoder.bn1.running_mean)
+    perm = torch.tensor([1, 3, 0, 2], device=DEV)
+    m.load_state_dict(state)
+    m.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2 = m(x[perm].contiguous())
+    loss_fn(y2, tgt[perm]).backward()
+    assert (y2.float() - y1.detach().float()[perm]).abs().max().item() <= 2e-2 * y1.detach().float().abs().max().item() + 1e-3
+    g2 = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+    assert torch.nn.functional.cosine_similarity(g1, g2, dim=0).item() > 0.98
+    opt = mtrain.FusedSGD([p for p in m.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, nesterov=True)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = loss_fn(m(x), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0], losses

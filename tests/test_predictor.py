@@ -115,3 +115,65 @@ def test_stream_predictor_matches_reference_logic(be, tta):
     for index in list(range(0, 30)) + [40]:
         out, _ = sp2.predict(torch.zeros(58, 90, dtype=torch.uint8), index)
     assert out is None
+
+
+def test_chunked_prediction_encodes_every_stack_once(be):
+    """windows sit 6 frames apart, so inside a chunk of 8 the newest stack of frame j is the second newest of
+    frame j + 6 - the 2D encoder must run ONE pass of n stacks per chunk in steady state (it ran 2 at n = 8, 5 at n = 32)."""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    prod = mds.MultiDimStacker(**kw).to(be.device)
+    if be.name == "emu":
+        prod._lib = be.lib
+    n = 8
+    sp = StreamPredictor(prod, frame_size=(64, 32), use_graphs=False)
+    frames = torch.zeros(n, 32, 64, dtype=torch.uint8)
+    passes = []
+    for first in range(0, 7 * n, n):
+        before = sp.encoder_passes
+        sp.predict_batch(frames, first)
+        passes.append(sp.encoder_passes - before)
+    assert passes[-2:] == [1, 1], passes          # steady state: one pass of n stacks per chunk
+    # the chunk after the one that straddles the first complete window still misses the stacks ending at frames 26, 27 (no
+    # window was complete there): 10 distinct stacks = 2 passes, not the 5 of a per-frame `missing` list
+    assert passes[4] <= 2, passes
+
+
+@pytest.mark.gpu
+def test_stream_predictor_at_the_real_frame_size():
+    """BASELINE configs[4] at its real shape: raw 720 x 1280 uint8 frames padded to 736 x 1280 (src/frames.py:12-31), fp32,
+    the first two complete windows (frames 0..29) frame by frame through the reference API against the reference's
+    predictor logic on the oracle."""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    ref = fill_deterministic(orc.MultiDimStacker(**kw), 6, scale=0.02)
+    g = torch.Generator().manual_seed(2)
+    size = (1280, 736)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+
+    def new_frame():
+        return torch.randint(0, 256, (720, 1280), generator=g).to(torch.uint8)
+    for bn in ref.modules():
+        if isinstance(bn, torch.nn.modules.batchnorm._BatchNorm):
+            bn.momentum = 1.0
+    ref.train()
+    rp0 = RefPredictor(ref, size, False)
+    with torch.no_grad():      # running statistics from one window of the same frame distribution
+        ref(torch.stack([rp0.process(new_frame()[None, None])[0, 0] for _ in range(15)])[None])
+    prod = mds.MultiDimStacker(**kw)
+    prod.load_state_dict(ref.state_dict())
+    prod = prod.to("cuda:0")
+    rp = RefPredictor(ref, size, False)
+    sp = StreamPredictor(prod, frame_size=size, tta=False)
+    refs, outs = [], []
+    for index in range(30):
+        frame = new_frame()
+        pr, ir = rp.predict(frame, index)
+        pp, ip = sp.predict(frame.cuda(), index)
+        assert ir == ip == index - 14 and (pr is None) == (pp is None) == (index < 28)
+        if pr is not None:
+            refs.append(pr); outs.append(pp.float().cpu())
+    assert len(refs) == 2
+    lref, lg = torch.logit(torch.stack(refs).double()), torch.logit(torch.stack(outs).double())
+    assert torch.isfinite(lref).all() and ((torch.stack(refs) > 1e-4) & (torch.stack(refs) < 1 - 1e-4)).all(), refs
+    # fp32 kernels against the fp32 oracle at the real shape: logits within 1e-3 of their magnitude (+ 1e-4 absolute)
+    err = (lg - lref).abs().max().item()
+    assert err < 1e-3 * lref.abs().max().item() + 1e-4, (err, lref)

@@ -93,3 +93,105 @@ def test_model_ema_matches_reference_arithmetic(lib):
     for (k, e), r in zip(ema.ema.state_dict().items(), ref_ema.state_dict().values()):
         torch.testing.assert_close(e.cpu(), r, rtol=1e-5, atol=1e-6, msg=k)
     assert not ema.ema.training
+
+
+@pytest.mark.parametrize("momentum,nesterov,dampening,wd", [(0.9, True, 0.0, 0.0), (0.9, False, 0.1, 1e-4), (0.0, False, 0.0, 5e-4)])
+def test_fused_sgd_matches_torch_sgd(lib, momentum, nesterov, dampening, wd):
+    """configs/ball_action/ball_finetune_long_004.py:51-55 builds ("SGD", {momentum 0.9, nesterov True})"""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(576, 1, 3, 3, 3), (24,), (9000,), (3,), (2, 2816), (1,)]
+    ref = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+    mine = [lib.t(p.detach().clone()).requires_grad_(True) for p in ref]
+    kw = dict(lr=2e-2, momentum=momentum, nesterov=nesterov, dampening=dampening, weight_decay=wd)
+    ro, mo = torch.optim.SGD(ref, **kw), train.FusedSGD(mine, **kw)
+    total = sum(p.numel() for p in ref)
+    for step in range(4):
+        flat = torch.randn(total, generator=g)
+        flat_d = lib.t(flat)
+        off = 0
+        for p, q in zip(ref, mine):
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p).clone()
+            q.grad = flat_d[off:off + n].view_as(q)
+            off += n
+        if step == 2:
+            for grp in ro.param_groups + mo.param_groups:
+                grp["lr"] = 5e-3
+        ro.step(); mo.step()
+    lib.sync()
+    for p, q in zip(ref, mine):
+        torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-5, atol=2e-6)
+    if momentum:
+        sd = mo.state_dict()
+        torch.testing.assert_close(sd["state"][2]["momentum_buffer"].cpu(), ro.state[ref[2]]["momentum_buffer"], rtol=2e-5, atol=1e-6)
+        mo2 = train.FusedSGD(mine, **kw)
+        mo2.load_state_dict(copy.deepcopy(sd))
+        for p, q in zip(ref, mine):
+            p.grad = torch.ones_like(p); q.grad = torch.ones_like(q)
+        ro.step(); mo2.step()
+        lib.sync()
+        for p, q in zip(ref, mine):
+            torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("which", ["adamw", "sgd"])
+def test_fused_optimizers_take_grad_scale_and_found_inf_on_the_device(lib, which):
+    """the hand-shake of GradScaler.step with `_step_supports_amp_scaling` optimizers (src/argus_models.py:58-62):
+    gradients arrive SCALED, `grad_scale` / `found_inf` are device tensors set as attributes for the call - the kernel
+    unscales on load and skips the whole update when an overflow was found, with no host synchronisation"""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(40, 7), (5000,), (3,)]
+    ref = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+    mine = [lib.t(p.detach().clone()).requires_grad_(True) for p in ref]
+    if which == "adamw":
+        ro, mo = torch.optim.AdamW(ref, lr=1e-2), train.FusedAdamW(mine, lr=1e-2)
+    else:
+        ro, mo = torch.optim.SGD(ref, lr=1e-2, momentum=0.9, nesterov=True), train.FusedSGD(mine, lr=1e-2, momentum=0.9, nesterov=True)
+    assert mo._step_supports_amp_scaling
+    scale = 1024.0
+    for step in range(3):
+        overflow = step == 1
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad = gr.clone()
+            q.grad = lib.t(gr * scale)
+        before = [q.detach().clone() for q in mine]
+        mo.grad_scale = lib.t(torch.tensor(scale))
+        mo.found_inf = lib.t(torch.tensor(1.0 if overflow else 0.0))
+        mo.step()
+        del mo.grad_scale, mo.found_inf
+        lib.sync()
+        if overflow:
+            for b, q in zip(before, mine):
+                assert torch.equal(b, q.detach()), "a step with found_inf set must leave parameters untouched"
+            if which == "adamw":          # torch's fused AdamW rewinds its step count on overflow; ours counts on the host
+                mo._g[0]["step"] -= 1
+            continue
+        ro.step()
+    for p, q in zip(ref, mine):
+        torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-5, atol=2e-6)
+
+
+def test_fused_optimizer_follows_parameter_reallocation(lib):
+    """the device table is keyed by the parameters' addresses too (module.to() / p.data swap after a step)"""
+    p = lib.t(torch.ones(300)).requires_grad_(True)
+    opt = train.FusedSGD([p], lr=0.5)
+    p.grad = torch.ones_like(p)
+    opt.step()
+    p.data = p.data.clone()            # new allocation, same Parameter object
+    p.grad = torch.ones_like(p)
+    opt.step()
+    lib.sync()
+    torch.testing.assert_close(p.detach().cpu(), torch.zeros(300))
+
+
+def test_model_ema_without_float_entries_is_a_no_op(lib):
+    class Counter(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.register_buffer("n", torch.tensor(5))
+    m = Counter().to(lib.device)
+    ema = train.ModelEma(m, decay=0.5)
+    m.n += 4
+    ema.update(m)
+    assert int(ema.ema.n) == int(0.5 * 5 + 0.5 * 9)
