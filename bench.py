@@ -189,7 +189,7 @@ def trace_child(extra_args, steps=8, timeout=300):
         if not files:
             return None
         if os.environ.get("MDS_KEEP_TRACE_STATS"):      # developer: keep the csv (copied to profiles/ by hand)
-            shutil.copy(files[0], os.environ["MDS_KEEP_TRACE_STATS"])
+            shutil.copy(files[0], os.path.join(ROOT, os.environ["MDS_KEEP_TRACE_STATS"]))     # (relative paths: from the repo root)
         out = {}
         for r in csv.DictReader(open(files[0])):
             fam = kernel_family(r["Name"])

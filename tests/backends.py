@@ -47,6 +47,14 @@ def be(request):
     return _cache[name]
 
 
+@pytest.fixture
+def be_gpu():
+    """the gfx950 library only: for tests that never run on the simulator (it is then not even built on the GPU box)"""
+    if "gpu" not in _cache:
+        _cache["gpu"] = Backend("gpu")
+    return _cache["gpu"]
+
+
 DT = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
 
 

@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backends import be, DT, assert_close  # noqa: F401
+from backends import be, be_gpu, DT, assert_close  # noqa: F401
 from mds import cabi, geometry as geo
 from oracle.multidim_stacker_ref import Conv2dSame
 
@@ -235,11 +235,11 @@ def _rand_cases(n, seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("N,H,W,Cin,Cout,stride,mode,blocks", _rand_cases(16, 20260928))
-def test_conv_fwd_random_shapes(be, dt, N, H, W, Cin, Cout, stride, mode, blocks):
+def test_conv_fwd_random_shapes(be_gpu, dt, N, H, W, Cin, Cout, stride, mode, blocks):
     """seeded random layer shapes through whichever kernel the launcher picks (persistent: every N-tile / row-fragment
-    template, K tails; chunked: Cin % 32 != 0, Cout tails), default grid and a few-block grid"""
-    if be.name != "gpu":
-        pytest.skip("GPU only: the simulator is too slow for 32 random layers")
+    template, K tails; chunked: Cin % 32 != 0, Cout tails), default grid and a few-block grid (GPU only: the simulator
+    is too slow for 32 random layers)"""
+    be = be_gpu
     be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
     try:
         test_conv_fwd(be, dt, N, H, W, Cin, Cout, stride, mode)
