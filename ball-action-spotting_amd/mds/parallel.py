@@ -37,12 +37,28 @@ def allreduce_mean_(flat: torch.Tensor, group=None, force: bool = False) -> torc
 
 
 def broadcast_state(module: torch.nn.Module, src: int = 0, group=None):
-    """Make every rank start from rank `src`'s parameters and buffers (as DDP does at wrap time)."""
+    """Make every rank start from rank `src`'s parameters and buffers (as DDP does at wrap time): ONE broadcast of a packed
+    fp32 buffer (all 6.77 M parameters + the BatchNorm running statistics, ~27.5 MB - a single large message instead of
+    ~830 small ones on a point-to-point fabric) plus one of the packed integer buffers (num_batches_tracked).
+    BatchNorm buffers are NOT re-synchronised afterwards: every rank keeps the running statistics of its own shards,
+    exactly what the reference's DataParallel / single-GPU runs and torch DDP (broadcast_buffers aside) leave to rank 0's
+    checkpoint - the EMA copy that is validated and saved lives on rank 0."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     with torch.no_grad():
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t, src=src, group=group)
+        tensors = list(module.parameters()) + list(module.buffers())
+        for floating in (True, False):
+            ts = [t for t in tensors if t.is_floating_point() == floating]
+            if not ts:
+                continue
+            dt = torch.float32 if floating else torch.int64
+            flat = torch.cat([t.detach().reshape(-1).to(dt) for t in ts])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape).to(t.dtype))
+                off += n
 
 
 class BucketedSync:
@@ -58,6 +74,8 @@ class BucketedSync:
     def __init__(self, group=None, force: bool = False):
         self.group, self.force = group, force
         self.handles, self.comm, self.events = [], None, []
+        self.timing = False          # bench: record an event pair around every slice's all-reduce on the communication stream
+        self.last_timing = None      # [(lo, hi, microseconds)] of the last step when `timing` is on
 
     def active(self):
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
@@ -77,7 +95,14 @@ class BucketedSync:
                     self.comm.wait_event(ev)
                     self.events.append(ev)
             with torch.cuda.stream(self.comm):
-                self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi))
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm)
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.timing:
+                    e1.record(self.comm)
+                    self._tev = getattr(self, "_tev", []) + [(lo, hi, e0, e1)]
+                self.handles.append((h, lo, hi))
         else:
             self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi))
 
@@ -90,6 +115,10 @@ class BucketedSync:
         if self.comm is not None:
             torch.cuda.current_stream(plan.device).wait_stream(self.comm)
         self.buckets = [(lo, hi) for _, lo, hi in self.handles]     # kept for inspection by tests
+        if self.timing and getattr(self, "_tev", None):
+            torch.cuda.synchronize(plan.device)
+            self.last_timing = [(lo, hi, round(e0.elapsed_time(e1) * 1e3, 1)) for lo, hi, e0, e1 in self._tev]
+            self._tev = []
         self.handles, self.events = [], []
         return dist.get_world_size(self.group)
 

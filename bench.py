@@ -473,6 +473,18 @@ def main():
         elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
     wps = B * world * args.steps / elapsed
+    par_info = None
+    if world > 1:       # one more step with an event pair around every slice's all-reduce: makes an N-GPU line self-explaining
+        sync = getattr(model, "_grad_sync", None)
+        if hasattr(sync, "timing"):
+            sync.timing = True
+            step()
+            fence()
+            sync.timing = False
+            sl = sync.last_timing or []
+            par_info = {"rccl_ranks": world, "backend": dist.get_backend(), "allreduce_slices_in_backward_order":
+                        [{"elems": hi - lo, "MB": round((hi - lo) * 4 / 1e6, 2), "us": us} for lo, hi, us in sl],
+                        "note": "rank 0, communication stream; the slices overlap the rest of the backward pass"}
     assert torch.isfinite(loss).item(), "non-finite loss"
 
     # ---- per-kernel pass: HIP event pairs around every launch (on the launch stream).  Keyed by HIP kernel:
@@ -580,6 +592,8 @@ def main():
                "loss": round(float(loss.detach()), 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
         if others is not None:
             out["other_configs"] = others
+        if par_info is not None:
+            out["parallel"] = par_info
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 112
+#define MDS_VERSION 113
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -601,6 +601,49 @@ typedef struct {
   float decay;
 } mds_ema_args;
 int mds_multi_ema(const mds_ema_args* a, mds_stream_t stream);
+
+/* ---- the training augmentations as fused passes over the (B, T, H, W) fp32 frame batch
+ * (src/ball_action/augmentations.py:7-22 = src/action/augmentations.py:7-22, src/augmentations.py:42-78, call site
+ * src/argus_models.py:49-53).  The geometric stages (camera move, rotation, resized crop, horizontal flip) are composed on
+ * the host into ONE destination -> source affine map per frame; a pass is one launch over the whole batch in which every
+ * sample does what its job entry says:
+ *   COPY  dst = src                        WARP  dst(x, y) = bilinear src(map(x, y)), zeros outside (grid_sample,
+ *   SHARP kornia sharpness (3x3 interior         align_corners=True)
+ *         smoothing blended with the input)TAPS  dst = sum_k w_k src(x + dx_k, y + dy_k), zeros outside (motion blur)
+ * followed - in the sample's LAST pass (`point`) - by the point operations in the reference's order: brightness (additive,
+ * clamped), contrast (multiplicative, clamped), posterize (bit mask of the 8-bit value), Gaussian noise (from `noise`, or
+ * generated in the kernel by Philox-4x32-10 + Box-Muller keyed by the job's seed and the element index).
+ * A sample without spatial filters is read once and written once; sharpness / motion blur add one pass each through
+ * scratch buffers for the samples that drew them (p = 0.2 each).                                                      */
+#define MDS_AUG_COPY 0
+#define MDS_AUG_WARP 1
+#define MDS_AUG_SHARP 2
+#define MDS_AUG_TAPS 3
+#define MDS_AUG_MAX_TAPS 48
+typedef struct {
+  int active;                 /* 0: nothing to do for this sample in this pass */
+  int src, dst;               /* indices into mds_aug_args.buf */
+  int mode;                   /* MDS_AUG_* */
+  int point;                  /* 1: point operations + final store (the sample's last pass) */
+  float sharp_factor;         /* SHARP: out = blurred + (in - blurred) * factor */
+  int ntaps;                  /* TAPS */
+  int bright_on;   float bright_add;
+  int contrast_on; float contrast_mul;
+  int posterize_bits;         /* 0 = off; 1..7: keep that many high bits */
+  int noise_on;    float noise_std, noise_mean;
+  int noise_seed;
+  int tap_dx[MDS_AUG_MAX_TAPS];
+  int tap_dy[MDS_AUG_MAX_TAPS];
+  float tap_w[MDS_AUG_MAX_TAPS];
+} mds_aug_job;
+typedef struct {
+  int B, T, H, W;
+  float* buf[4];              /* 0 = input batch (read only), 1 = output batch, 2 / 3 = scratch (only if a job names them) */
+  const mds_aug_job* jobs;    /* device [B] */
+  const float* maps;          /* device [B][T][6]: sx = m0 x + m1 y + m2, sy = m3 x + m4 y + m5 (WARP jobs) */
+  const float* noise;         /* optional device (B, T, H, W) standard-normal draws; NULL = generate */
+} mds_aug_args;
+int mds_aug_pass(const mds_aug_args* a, mds_stream_t stream);
 
 /* ---- parameter packing: fp32 PyTorch parameters -> the layouts/dtypes the kernels read.
  * One launch handles a device-resident table of jobs.                                          */

@@ -1,0 +1,177 @@
+"""SURVEY 8(f) N3 - the fused augmentation passes (mds.augment / mds_aug_pass) against the CPU restatement of the reference
+pipeline (oracle/augment_ref.py), stage by stage with injected parameters, and the restatement itself against the fixture the
+reference's own RandomCameraMove produced (tests/golden/make_golden_augment.py)."""
+import numpy as np
+import pytest
+import torch
+
+from backends import be  # noqa: F401
+from oracle import augment_ref as aug
+from mds import augment
+
+
+def _t(v):
+    return torch.as_tensor(np.asarray(v), dtype=torch.float32)
+
+
+def _oracle_params(s):
+    """mds.augment parameter dicts hold plain lists / floats; the oracle's camera parameters are tensors"""
+    s = dict(s)
+    if "camera" in s:
+        s["camera"] = {k: _t(v) for k, v in s["camera"].items()}
+    return s
+
+
+# ------------------------------------------------------------------------------------------------ oracle pinned to the reference
+def test_oracle_camera_move_matches_the_reference_file(golden):
+    g = golden("augment_camera_move")
+    x, y, sel = torch.from_numpy(g["x"]), torch.from_numpy(g["y"]), g["selected"]
+    assert sel.tolist() == [True, False, True]
+    torch.testing.assert_close(aug.tensor_linspace(torch.tensor([1.0, -2.0]), torch.tensor([3.0, 4.0]), 7), torch.from_numpy(g["linspace"]))
+    for i in range(x.shape[0]):
+        if not sel[i]:
+            assert torch.equal(y[i], x[i])                   # `random.random() > p: continue` leaves the clone untouched
+            continue
+        p = {k: torch.from_numpy(g[f"p{i}.{k}"]) for k in ("angle", "translations", "center", "scale")}
+        torch.testing.assert_close(aug.camera_move(x[i], p), y[i], rtol=1e-5, atol=1e-6)
+        # the single-resampling form with only this stage active is the same computation
+        torch.testing.assert_close(aug.apply_single_resampling(x[i:i + 1], [dict(camera=p)])[0], y[i], rtol=1e-4, atol=2e-5)
+
+
+def test_single_resampling_equals_the_reference_order_for_one_geometric_stage():
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(4, 3, 20, 28, generator=g)
+    params = [dict(rotation=2.1), dict(crop=(2, 1, 24, 17)), dict(flip=True), dict(flip=True, brightness=1.1, contrast=0.9, posterize=4)]
+    a, b = aug.apply_reference_order(x, params), aug.apply_single_resampling(x, params)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5)
+
+
+def test_motion_kernel_restatements_agree():
+    for angle, direction in [(0.0, 0.0), (7.5, 1.0), (-6.2, -0.4), (3.3, 0.7)]:
+        k_ref = aug.motion_kernel(11, angle, direction).numpy()
+        k = augment.motion_kernel(11, angle, direction)
+        assert abs(k.sum() - 1) < 1e-6 and np.abs(k - k_ref).max() < 1e-6, (angle, direction)
+        assert (k != 0).sum() <= augment.MAX_TAPS
+
+
+# ------------------------------------------------------------------------------------------------ HIP passes vs the oracle
+STAGES = {
+    "identity": dict(),
+    "camera": dict(camera=dict(angle=[1.9, -2.2], translations=[[2.5, -1.0], [-3.0, 0.8]], center=[[19.5, 11.5]] * 2, scale=[[0.96, 0.96], [1.04, 1.04]])),
+    "rotation": dict(rotation=-2.3),
+    "crop": dict(crop=(3, 2, 33, 20)),
+    "flip": dict(flip=True),
+    "sharpness": dict(sharpness=0.35),
+    "motion_blur": dict(motion_blur=dict(ksize=11, angle=5.5, direction=0.6)),
+    "brightness": dict(brightness=1.17),
+    "contrast": dict(contrast=0.83),
+    "posterize": dict(posterize=3),
+    "noise": dict(noise=dict(std=0.05, mean=0.0, seed=7)),
+}
+
+
+@pytest.mark.parametrize("stage", list(STAGES))
+def test_each_stage_alone_matches_the_oracle(be, stage):
+    g = torch.Generator().manual_seed(11)
+    b, t, h, w = 2, 4, 24, 40
+    x = torch.rand(b, t, h, w, generator=g)
+    noise = torch.randn(b, t, h, w, generator=g)
+    params = [STAGES[stage], dict()]                                  # the second sample stays untouched
+    mod = augment.TrainAugmentations((w, h))
+    mod._lib = be.lib if be.name == "emu" else None
+    out = mod(be.t(x), params=params, noise=be.t(noise))
+    be.sync()
+    ref = aug.apply_reference_order(x, [_oracle_params(s) for s in params], noise)
+    assert torch.equal(out[1].cpu(), x[1]), "a sample no stage fires for must come back bit-identical"
+    if stage in ("identity", "flip", "posterize", "brightness", "contrast"):
+        torch.testing.assert_close(out.cpu(), ref, rtol=0, atol=1e-7)
+    else:
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=2e-5)
+
+
+def test_fused_pipeline_matches_the_single_resampling_oracle(be):
+    """every stage firing at once (three samples with different subsets): the fused passes against the oracle's single-resampling
+    form; and against the reference order within the interpolation blur the fusion removes"""
+    g = torch.Generator().manual_seed(12)
+    b, t, h, w = 3, 5, 32, 48
+    x = torch.rand(b, t, h, w, generator=g)
+    x = torch.nn.functional.avg_pool2d(x, 3, stride=1, padding=1)     # smooth frames: resampling differences stay small
+    noise = torch.randn(b, t, h, w, generator=g)
+    every = dict()
+    for k in ("camera", "rotation", "flip", "sharpness", "motion_blur", "brightness", "contrast", "noise"):
+        every.update(STAGES[k])
+    every["camera"] = dict(every["camera"], center=[[(w - 1) / 2, (h - 1) / 2]] * 2)
+    every["crop"] = (2, 1, 43, 29)
+    params = [every, dict(crop=(1, 2, 44, 28), sharpness=0.8, posterize=5), dict(rotation=1.2, motion_blur=dict(ksize=11, angle=-7.0, direction=-1.0), contrast=1.15)]
+    mod = augment.TrainAugmentations((w, h))
+    mod._lib = be.lib if be.name == "emu" else None
+    out = mod(be.t(x), params=params, noise=be.t(noise)).cpu()
+    be.sync()
+    op = [_oracle_params(s) for s in params]
+    single = aug.apply_single_resampling(x, op, noise)
+    for i in (0, 2):
+        torch.testing.assert_close(out[i], single[i], rtol=1e-4, atol=5e-5)
+    # posterize quantises: a 1e-6 difference before it may flip a level at isolated pixels
+    d = (out[1] - single[1]).abs()
+    assert (d > 1e-4).float().mean().item() < 2e-3 and d.max().item() <= 8 / 255 + 1e-6
+    seq = aug.apply_reference_order(x, op, noise)
+    assert (out[0] - seq[0])[:, 4:-4, 4:-4].abs().mean().item() < 2e-2     # same picture, less blur
+
+
+def test_noise_generated_in_the_kernel_is_standard_normal(be):
+    b, t, h, w = 1, 2, 64, 96
+    x = torch.full((b, t, h, w), 0.5)
+    mod = augment.TrainAugmentations((w, h))
+    mod._lib = be.lib if be.name == "emu" else None
+    p = [dict(noise=dict(std=0.05, mean=0.0, seed=1234))]
+    o1 = mod(be.t(x), params=p).cpu()
+    o2 = mod(be.t(x), params=p).cpu()
+    o3 = mod(be.t(x), params=[dict(noise=dict(std=0.05, mean=0.0, seed=99))]).cpu()
+    be.sync()
+    z = (o1 - 0.5) / 0.05
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)               # a function of (seed, element) only
+    assert abs(z.mean().item()) < 0.03 and abs(z.std().item() - 1) < 0.03
+    assert abs((z ** 3).mean().item()) < 0.1 and abs((z ** 4).mean().item() - 3) < 0.25
+    assert abs(torch.corrcoef(torch.stack([z[0, 0].flatten()[:-1], z[0, 0].flatten()[1:]]))[0, 1].item()) < 0.05
+
+
+def test_sampler_follows_the_reference_probabilities_and_ranges():
+    mod = augment.TrainAugmentations((1280, 736), seed=5)
+    ps = mod.sample_params(4000, 15, 736, 1280)
+    want = dict(camera=0.2, rotation=0.3, crop=0.8, flip=0.5, sharpness=0.2, motion_blur=0.2, brightness=0.3, contrast=0.3, posterize=0.2, noise=0.2)
+    for k, p in want.items():
+        f = sum(k in s for s in ps) / len(ps)
+        assert abs(f - p) < 0.03, (k, f)
+    crops = [s["crop"] for s in ps if "crop" in s]
+    assert all(0 <= x0 and x0 + cw <= 1280 and 0 <= y0 and y0 + ch <= 736 for x0, y0, cw, ch in crops)
+    areas = np.array([cw * ch / (1280 * 736) for _, _, cw, ch in crops if (cw, ch) != (1280, 736)])
+    assert 0.88 < areas.min() and areas.max() <= 1.0 and len(areas) > 0.9 * len(crops)      # scale=(0.9, 1.0); fallbacks are rare
+    assert all(3 <= s["posterize"] <= 7 for s in ps if "posterize" in s)
+    assert all(0.8 <= s["brightness"] <= 1.2 for s in ps if "brightness" in s)
+    cam = [s["camera"] for s in ps if "camera" in s]
+    assert all(abs(a) <= 2.5 for c in cam for a in c["angle"]) and all(abs(tr[0]) <= 128 and abs(tr[1]) <= 36.8 for c in cam for tr in c["translations"])
+
+
+@pytest.mark.gpu
+def test_augmentations_at_the_training_shape():
+    """4 x 15 x 736 x 1280 (BASELINE configs[1]): size-independent properties of the fused passes"""
+    dev = "cuda:0"
+    x = torch.rand(4, 15, 736, 1280, device=dev, generator=torch.Generator(dev).manual_seed(3))
+    mod = augment.get_train_augmentations((1280, 736))
+    assert torch.equal(mod(x, params=[{}, {}, {}, {}]), x)                                        # nothing fires: a copy
+    f = mod(x, params=[dict(flip=True)] * 4)
+    assert torch.equal(f, torch.flip(x, dims=[-1]))                                               # flip is exact
+    assert torch.equal(mod(f, params=[dict(flip=True)] * 4), x)                                   # and an involution
+    c = mod(x, params=[dict(crop=(0, 0, 1280, 736))] * 4)
+    assert (c - x).abs().max().item() < 1e-6                                                      # the full-frame crop is the identity map
+    lin = mod(x, params=[dict(brightness=1.1, contrast=0.9)] * 4)
+    torch.testing.assert_close(lin, ((x + 0.1).clamp(0, 1) * 0.9).clamp(0, 1), rtol=0, atol=1e-7)
+    y = mod(x)                                                                                    # sampled parameters
+    assert y.shape == x.shape and torch.isfinite(y).all() and -0.5 < y.min().item() and y.max().item() < 1.5
+    # a translation-only camera move shifts the picture by the offset.  (The reference's tensor_linspace forms
+    # start * linspace(1, 0) + end * linspace(0, 1) in fp32: the weights of an inner frame do not sum to exactly 1, so its
+    # offset is 8.000014 rather than 8 - exact for the first and the last frame, ~1e-5 of a pixel otherwise.)
+    sh = dict(camera=dict(angle=[0.0, 0.0], translations=[[8.0, 4.0], [8.0, 4.0]], center=[[639.5, 367.5]] * 2, scale=[[1.0, 1.0]] * 2))
+    s = mod(x[:1], params=[sh])
+    assert torch.equal(s[0, 0, 4:, 8:], x[0, 0, :-4, :-8]) and torch.equal(s[0, -1, 4:, 8:], x[0, -1, :-4, :-8])
+    assert (s[0, :, 4:, 8:] - x[0, :, :-4, :-8]).abs().max().item() < 1e-3 and s[0, :, :4].abs().max().item() < 1e-4

@@ -17,7 +17,7 @@ def test_shard_windows_partitions_everything():
         assert max(map(len, parts)) - min(map(len, parts)) <= 1
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, frozen=False):
     for p in sys.path_extra:
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -45,7 +45,11 @@ def _worker(rank, world, port, tmp):
     ref.load_state_dict(prod.state_dict())
     ref0 = fill_deterministic(orc.MultiDimStacker(**kw), 3, scale=0.05)
     for a, b in zip(ref.state_dict().values(), ref0.state_dict().values()):
-        assert torch.equal(a, b)                             # broadcast made every rank equal to rank 0
+        assert torch.equal(a, b)                             # the packed broadcast made every rank equal to rank 0
+    if frozen:                                               # config 4: only the temporal tail's 1.16 M parameters are exchanged
+        for m_ in (prod, ref0):
+            for p_ in m_.conv2d_encoder.parameters():
+                p_.requires_grad_(False)
     # (64x32: at 32x32 the last stages see 1x1 maps, BN over 5 samples is ill-conditioned in fp32)
     xs = [torch.rand(1, 15, 64, 32, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
     tgt = torch.tensor([[1.0, 0.0]])
@@ -54,18 +58,27 @@ def _worker(rank, world, port, tmp):
     want = None
     for r in range(world):                                   # oracle on every shard, fresh copy each
         m = orc.MultiDimStacker(**kw); m.load_state_dict(ref0.state_dict()); m.train()
+        if frozen:
+            for p_ in m.conv2d_encoder.parameters():
+                p_.requires_grad_(False)
         orc.sigmoid_focal_loss(m(xs[r]), tgt, alpha=-1.0, gamma=1.2).backward()
-        g = torch.cat([p.grad.flatten() for p in m.parameters()])
+        g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
         want = g if want is None else want + g
     want /= world
-    got = torch.cat([p.grad.flatten() for p in prod.parameters()])
+    got = torch.cat([p.grad.flatten() for p in prod.parameters() if p.grad is not None])
+    assert got.numel() == want.numel() and (not frozen or all(p.grad is None for p in prod.conv2d_encoder.parameters()))
     err = (got - want).abs().max().item() / want.abs().max().item()
     assert err < 1e-3, err
     # the exchange ran as several slices of the flat arena, in backward order (head first, stem last), covering it once
     buckets = prod._grad_sync.buckets
     total = sum(p.numel() for p in prod.parameters())
-    assert len(buckets) >= 3 and buckets[0][1] == total and buckets[-1][0] == 0
-    assert all(a[0] == b[1] for a, b in zip(buckets, buckets[1:])) and all(hi - lo >= 1_000_000 for lo, hi in buckets[:-1])
+    if frozen:       # the frozen encoder's part of the arena [0, 5 610 384) is never exchanged: one slice, the tail's 1.16 M elements
+        lo_tail = sum(p.numel() for p in prod.conv2d_encoder.parameters())
+        assert buckets[0][1] == total and buckets[-1][0] == lo_tail and sum(hi - lo for lo, hi in buckets) == total - lo_tail == got.numel()
+    else:
+        assert len(buckets) >= 3 and buckets[0][1] == total and buckets[-1][0] == 0
+        assert all(hi - lo >= 1_000_000 for lo, hi in buckets[:-1])
+    assert all(a[0] == b[1] for a, b in zip(buckets, buckets[1:]))
     torch.save(got, os.path.join(tmp, f"g{rank}.pt"))
     dist.barrier()
     if rank == 0:                                            # every rank holds the same averaged gradient
@@ -74,21 +87,21 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_gloo_gradients_match_mean_of_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,frozen", [(2, False), (4, False), (2, True)])
+def test_gloo_gradients_match_mean_of_oracle(tmp_path, world, frozen):
     sys.path_extra = [p for p in sys.path if "repo" in p]
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     procs = []
     for r in range(world):
-        p = ctx.Process(target=_spawn_entry, args=(r, world, port, str(tmp_path), sys.path_extra))
+        p = ctx.Process(target=_spawn_entry, args=(r, world, port, str(tmp_path), sys.path_extra, frozen))
         p.start(); procs.append(p)
     for p in procs:
         p.join(900)
         assert p.exitcode == 0
 
 
-def _spawn_entry(rank, world, port, tmp, paths):
+def _spawn_entry(rank, world, port, tmp, paths, frozen=False):
     sys.path_extra = paths
-    _worker(rank, world, port, tmp)
+    _worker(rank, world, port, tmp, frozen)
