@@ -312,6 +312,14 @@ class Plan:
         if self.need_grad:
             chain = [(rec, bseg) for name, bseg in (("head", "bhead"), ("3d", "b3d"), ("2d", "b2d")) for rec in reversed(self._recs[name])]
             gout = None
+            # the sub-forwards called on their own under autograd (reference: multidim_stacker.py:210-237 are ordinary
+            # differentiable methods): the incoming gradient is copied into a channels-last buffer that starts the chain
+            if self.kind == "3d":        # gradient wrt the ACTIVATED projection output (b, S, h, w, 256)
+                self.uq_in = self.act(N * h * w, m.num_features // S)
+                gout = Grad(self.uq_in)
+            if self.kind == "2d":        # gradient wrt the activated 2D features (b, S, h, w, 192)
+                self.dfeat_in = self.act(N * h * w, m.num_3d_features)
+                gout = Grad(self.dfeat_in)
             # Gradient buckets for data parallelism: closures run in reverse parameter order, so once closure i
             # has been issued every parameter at or above min(lo of closures 0..i) is final; a cut after ~1.5 M elements
             # lets the all-reduce of that slice of the flat arena start while the rest of the backward still runs.
@@ -329,7 +337,8 @@ class Plan:
                 if gout is None:
                     break
             self.grad_lo = hi        # parameters below this offset receive no gradient in this plan (frozen encoder)
-            self.dfeat = gout.buf if (self.kind == "tail" and gout is not None) else None   # gradient wrt the (b,S,h,w,192) features
+            self.dfeat = gout.buf if (self.kind in ("tail", "3d") and gout is not None) else None   # gradient wrt the (b,S,h,w,192) features
+            self.dyq_out = gout.buf if (self.kind == "head" and gout is not None) else None      # gradient wrt forward_head's input
 
     # -- helpers emitting a conv + its BN finalize
     def _pw(self, seg, x, M, K, N_, wparam, pro=None, stats_bn=None, residual=None, wt=None, epi_mode=None):

@@ -6,16 +6,23 @@ Same constructor, attributes, methods and ``state_dict`` as the reference class
 runs in the hand-written gfx950 kernels of ``libmds_hip.so`` (C ABI: include/mds.h) driven by
 ``engine.Plan``; if the library is missing this module raises — there is no eager/CPU fallback.
 
-``torch.compile(module)`` (``scripts/ball_action/train.py:83-86``) is supported by construction: the
-public forwards are ``torch.compiler.disable``d, i.e. Dynamo treats the whole hot path as ONE opaque
-call (it already is a static launch schedule; there is nothing for a tracing compiler to add) and
-never traces into the planner.
+``torch.compile(module)`` (``scripts/ball_action/train.py:83-86``): the training forward is a registered operator,
+``torch.ops.mds.forward`` (``torch.library.custom_op`` with a fake implementation and an autograd formula whose backward is
+the operator ``torch.ops.mds.backward``), so Dynamo / AOTAutograd / Inductor trace THROUGH ``forward`` with
+``fullgraph=True`` and see one opaque node each way - the hot path already is a static launch schedule, there is nothing for a
+tracing compiler to add.  The operator finds its module through an integer handle (operators take tensors and scalars,
+not modules); BatchNorm's running statistics are updated by the launch as a side effect, as in eager mode.
+``MDS_CUSTOM_OP=0`` selects the former ``torch.autograd.Function`` behind ``torch.compiler.disable`` (a graph break).
 """
 from __future__ import annotations
 
+import copy
+import itertools
+import os
 import warnings
+import weakref
 from collections import OrderedDict
-from typing import Optional
+from typing import List, Optional, Tuple
 
 import torch
 from torch import nn
@@ -98,23 +105,7 @@ class _MDSFunction(torch.autograd.Function):
                                "plan was reused by a later forward); a second backward / retain_graph is not supported")
         (x,) = ctx.saved_tensors            # raises if x was modified in place since forward
         ctx.consumed = True
-        sync = getattr(ctx.module, "_grad_sync", None)
-        bucketed = hasattr(sync, "on_cut")
-        with plan.device_guard():
-            plan.bind_input(x)
-            plan.bind_dlogits(dlogits)
-            plan.begin_backward()
-            plan.cut_hook = sync.on_cut if bucketed else None     # data parallel: all-reduce each slice as soon as it is final
-            plan.run("bhead"); plan.run("b3d"); plan.run("b2d")
-            plan.cut_hook = None
-            plan.join_backward()
-            if bucketed:
-                world = sync.finish(plan)
-                flat = plan.grad_arena.tensor / world if world > 1 else plan.grad_arena.tensor.clone()
-            else:
-                flat = plan.grad_arena.tensor.clone()  # one launch; the arena is reused next step
-                if sync is not None:
-                    sync(flat)                         # data parallel: one RCCL all-reduce of the flat buffer
+        flat = _run_backward(ctx.module, plan, x, dlogits)
         grads = []
         for p in plan.params:
             if p.requires_grad:
@@ -162,6 +153,158 @@ class _TailFunction(torch.autograd.Function):
         return (dfeats, None, None, *grads)
 
 
+class _SubFunction(torch.autograd.Function):
+    """forward_2d / forward_3d / forward_head called on their own with autograd on (the reference's are ordinary
+    differentiable methods, multidim_stacker.py:210-237): one plan of that kind with its backward schedule; gradients for
+    the input (3d, head) and for the parameters of that part of the network only."""
+
+    @staticmethod
+    def forward(ctx, inp, module, plan, kind, *params):
+        ctx.plan, ctx.kind, ctx.token, ctx.module = plan, kind, _Release(plan), module
+        ctx.params = params
+        plan.in_flight = True
+        plan.generation += 1
+        ctx.generation, ctx.shape = plan.generation, inp.shape
+        ctx.save_for_backward(inp)
+        return module._run_sub(plan, kind, inp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan, kind = ctx.plan, ctx.kind
+        if ctx.generation != plan.generation or not plan.in_flight:
+            raise RuntimeError("mds: the activations of this forward have been released")
+        (inp,) = ctx.saved_tensors
+        m = ctx.module
+        dinp = None
+        with plan.device_guard():
+            plan.begin_backward()
+            if kind == "2d":
+                b, t, h, w = ctx.shape
+                s_ = t // m.stack_size
+                plan.bind_input(inp)
+                plan.dfeat_in.tensor.view(b, s_, plan.h, plan.w, m.num_3d_features).copy_(dout.permute(0, 1, 3, 4, 2))
+                plan.run("b2d")
+            elif kind == "3d":
+                b, t, c, h, w = ctx.shape
+                cq = m.num_features // t
+                plan.uq_in.tensor.view(b, t, h, w, cq).copy_(dout.view(b, t, cq, h, w).permute(0, 1, 3, 4, 2))
+                plan.run("b3d")
+                dinp = plan.dfeat.tensor.view(b, t, h, w, c).permute(0, 1, 4, 2, 3).float().contiguous()
+            else:
+                b, f, h, w = ctx.shape
+                t = m.num_stacks
+                plan.bind_dlogits(dout)
+                plan.run("bhead")
+                dinp = plan.dyq_out.tensor.view(b, t, h, w, f // t).permute(0, 1, 4, 2, 3).reshape(b, f, h, w).float().contiguous()
+            plan.join_backward()
+            flat = plan.grad_arena.tensor.clone()
+        grads = [flat[plan.poff[id(p)]:plan.poff[id(p)] + p.numel()].view(p.shape) if p.requires_grad else None for p in ctx.params]
+        plan.in_flight = False
+        return (dinp, None, None, None, *grads)
+
+
+# ------------------------------------------------------------------------------------------------ registered operators
+_MODULES = weakref.WeakValueDictionary()      # handle -> MultiDimStacker (operators cannot take a module argument)
+_HANDLES = itertools.count(1)
+_TOKENS = itertools.count(1)
+USE_CUSTOM_OP = os.environ.get("MDS_CUSTOM_OP", "1") != "0"
+
+
+def _module_of(handle: int):
+    m = _MODULES.get(handle)
+    if m is None:
+        raise RuntimeError(f"mds: module handle {handle} is gone (the MultiDimStacker it named was deleted)")
+    return m
+
+
+@torch.library.custom_op("mds::forward", mutates_args=())
+def _op_forward(x: torch.Tensor, params: List[torch.Tensor], handle: int, need_grad: bool, code: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """logits of MultiDimStacker.forward + a CPU token naming the launch plan that holds the activations for backward.
+    `params` only tells autograd what the result depends on - the kernels read the module's parameters in place."""
+    m = _module_of(handle)
+    b, t, h, w = x.shape
+    plan = m._plan(x, "full", b, t, h, w, need_grad, code=code)
+    token = 0
+    if need_grad:
+        live = m._live
+        while len(live) >= 4:                      # forwards whose backward never came (loss evaluated under grad mode, then dropped)
+            live.pop(next(iter(live))).in_flight = False
+        token = next(_TOKENS)
+        live[token] = plan
+        plan.in_flight = True
+        plan.generation += 1
+    with plan.device_guard():
+        plan.bind_input(x)
+        plan.begin_forward(m._mask_override)
+        plan.run("f2d"); plan.run("f3d"); plan.run("fhead")
+        return plan.logits.tensor.view(b, -1).clone(), torch.tensor(token, dtype=torch.int64)
+
+
+@_op_forward.register_fake
+def _(x, params, handle, need_grad, code):
+    return x.new_empty((x.shape[0], _module_of(handle).classifier.out_features), dtype=torch.float32), torch.empty((), dtype=torch.int64)
+
+
+@torch.library.custom_op("mds::backward", mutates_args=())
+def _op_backward(dlogits: torch.Tensor, x: torch.Tensor, token: torch.Tensor, handle: int) -> torch.Tensor:
+    """the flat fp32 gradient arena (all parameters, parameter order) of the forward named by `token`"""
+    m = _module_of(handle)
+    plan = m._live.pop(int(token.item()), None)          # (a CPU scalar: no device synchronisation)
+    if plan is None:
+        raise RuntimeError("mds: the activations of this forward have been released (backward already ran, or the "
+                           "plan was reused by a later forward); a second backward / retain_graph is not supported")
+    flat = _run_backward(m, plan, x, dlogits)
+    plan.in_flight = False
+    return flat
+
+
+@_op_backward.register_fake
+def _(dlogits, x, token, handle):
+    return dlogits.new_empty((sum(p.numel() for p in _module_of(handle).parameters()),), dtype=torch.float32)
+
+
+def _op_setup_context(ctx, inputs, output):
+    x, params, handle, need_grad, code = inputs
+    ctx.save_for_backward(x, output[1])     # x is version-checked: an in-place edit before backward raises
+    ctx.handle = handle
+    ctx.meta = [(p.numel(), p.shape, p.requires_grad) for p in params]
+
+
+def _op_backward_formula(ctx, dlogits, dtoken):
+    x, token = ctx.saved_tensors
+    flat = torch.ops.mds.backward(dlogits.contiguous(), x, token, ctx.handle)
+    grads, off = [], 0
+    for n, shape, req in ctx.meta:
+        grads.append(flat[off:off + n].view(shape) if req else None)
+        off += n
+    return None, grads, None, None, None
+
+
+_op_forward.register_autograd(_op_backward_formula, setup_context=_op_setup_context)
+
+
+def _run_backward(module, plan, x, dlogits):
+    """issue the backward schedule of `plan`; returns the flat gradient buffer (averaged over ranks under data parallelism)"""
+    sync = getattr(module, "_grad_sync", None)
+    bucketed = hasattr(sync, "on_cut")
+    with plan.device_guard():
+        plan.bind_input(x)
+        plan.bind_dlogits(dlogits)
+        plan.begin_backward()
+        plan.cut_hook = sync.on_cut if bucketed else None     # data parallel: all-reduce each slice as soon as it is final
+        plan.run("bhead"); plan.run("b3d"); plan.run("b2d")
+        plan.cut_hook = None
+        plan.join_backward()
+        if bucketed:
+            world = sync.finish(plan)
+            flat = plan.grad_arena.tensor / world if world > 1 else plan.grad_arena.tensor.clone()
+        else:
+            flat = plan.grad_arena.tensor.clone()  # one launch; the arena is reused next step
+            if sync is not None:
+                sync(flat)                         # data parallel: one RCCL all-reduce of the flat buffer
+    return flat
+
+
 def _load_pretrained_encoder(encoder: nn.Module, model_name: str, in_chans: int):
     """``pretrained=True`` (configs/ball_action/sampling_weights_001.py:36): the reference gets ImageNet
     weights from ``timm.create_model(..., pretrained=True)`` (multidim_stacker.py:166-176).  Do the same when
@@ -176,11 +319,15 @@ def _load_pretrained_encoder(encoder: nn.Module, model_name: str, in_chans: int)
         encoder.load_state_dict(sd)
         return True
     except Exception as e:  # ImportError, no network / no cached weights, layout mismatch
-        warnings.warn(
-            f"mds.MultiDimStacker(pretrained=True): ImageNet weights for '{model_name}' could not be loaded "
-            f"({type(e).__name__}: {e}). The 2D encoder is RANDOMLY INITIALISED — load a checkpoint "
-            f"(load_state_dict / src.utils.load_weights_from_pretrain) before training stage 1, or install timm with "
-            f"cached weights.", RuntimeWarning, stacklevel=3)
+        msg = (f"mds.MultiDimStacker(pretrained=True): ImageNet weights for '{model_name}' could not be loaded "
+               f"({type(e).__name__}: {e}).")
+        if os.environ.get("MDS_ALLOW_RANDOM_INIT") != "1":
+            # the reference's timm.create_model(pretrained=True) fails hard here too; stage-1 training from a random encoder
+            # is never what the caller meant
+            raise RuntimeError(msg + " Install timm with its cached weights, construct with pretrained=False and load a "
+                               "checkpoint (load_state_dict / src.utils.load_weights_from_pretrain), or set "
+                               "MDS_ALLOW_RANDOM_INIT=1 to continue with a RANDOMLY INITIALISED encoder.") from e
+        warnings.warn(msg + " MDS_ALLOW_RANDOM_INIT=1: the 2D encoder is RANDOMLY INITIALISED.", RuntimeWarning, stacklevel=3)
         return False
 
 
@@ -220,6 +367,26 @@ class MultiDimStacker(nn.Module):
         self._lib: Optional[cabi.Lib] = None  # tests inject the kernel simulator here; product: cabi.load()
         self._mask_override = None            # parity tests: host-supplied DropPath/dropout masks
         self._grad_sync = None                # mds.parallel.data_parallel installs the all-reduce here
+        self._register()
+
+    def _register(self):
+        """a fresh operator handle for this instance (never shared with the module it was copied / unpickled from)"""
+        self._handle = next(_HANDLES)
+        self._live = {}                       # token -> plan of a grad-enabled forward whose backward has not run yet
+        self._warned_fp16 = False
+        _MODULES[self._handle] = self
+
+    def __deepcopy__(self, memo):             # src/ema.py:40 deep-copies the module: the copy is its own operator target
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_live" else (v if k == "_lib" else copy.deepcopy(v, memo))     # (a loaded library is shared)
+        new._register()
+        return new
+
+    def __setstate__(self, state):            # torch.save(module) / pickle
+        super().__setstate__(state)
+        self._register()
 
     # ------------------------------------------------------------------ plumbing
     def _apply(self, fn, *a, **k):
@@ -243,13 +410,22 @@ class MultiDimStacker(nn.Module):
         if self.compute_dtype == "f32":
             return cabi.MDS_F32
         if torch.is_autocast_enabled() or torch.is_autocast_enabled('cpu'):
-            return cabi.MDS_BF16              # fp16 autocast (the reference's AMP) also maps to bf16 storage
+            # The reference's AMP is fp16 autocast + GradScaler (src/argus_models.py:36,54).  The kernels store bf16: same
+            # range as fp32 (a GradScaler then never finds an overflow and simply keeps its scale), 3 mantissa bits fewer
+            # than fp16 - said once, not silently.
+            dt = torch.get_autocast_dtype("cuda" if torch.is_autocast_enabled() else "cpu")
+            if dt == torch.float16 and not self._warned_fp16 and not torch.compiler.is_compiling():
+                self._warned_fp16 = True
+                warnings.warn("mds.MultiDimStacker: fp16 autocast is executed with bf16 storage (fp32 accumulation); "
+                              "torch.autocast(dtype=torch.bfloat16) is the matching setting and needs no GradScaler.", stacklevel=3)
+            return cabi.MDS_BF16
         return cabi.MDS_F32
 
-    def _plan(self, x, kind, B, T, H, W, need_grad, ingest=None):
+    def _plan(self, x, kind, B, T, H, W, need_grad, ingest=None, code=None):
         lib = self._library(x)
         enc_grad = any(p.requires_grad for p in self.conv2d_encoder.parameters())
-        key = (kind, B, T, H, W, self._code(), self.training, need_grad, enc_grad, x.device, ingest)
+        code = self._code() if code is None else code
+        key = (kind, B, T, H, W, code, self.training, need_grad, enc_grad, x.device, ingest)
         cache = self._cache
         pool = cache.plans.setdefault(key, [])
         cache.plans.move_to_end(key)
@@ -257,18 +433,24 @@ class MultiDimStacker(nn.Module):
             if not plan.in_flight and not plan.stale():
                 return plan
         pool[:] = [p for p in pool if not p.stale()]
-        plan = Plan(self, lib, x.device, kind, B, T, H, W, self._code(), self.training, need_grad, enc_grad, ingest=ingest)
+        plan = Plan(self, lib, x.device, kind, B, T, H, W, code, self.training, need_grad, enc_grad, ingest=ingest)
         pool.append(plan)
         cache.evict(key)
         return plan
 
     # ------------------------------------------------------------------ reference API
-    @torch.compiler.disable
     def forward(self, x):
         b, t, h, w = x.shape
         assert t == self.num_frames and t % self.stack_size == 0
         x = x.float().contiguous()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if USE_CUSTOM_OP:      # the registered operator: traceable by torch.compile(fullgraph=True), one opaque node each way
+            return torch.ops.mds.forward(x, list(self.parameters()), self._handle, need_grad, self._code())[0]
+        return self._forward_untraced(x, need_grad)
+
+    @torch.compiler.disable
+    def _forward_untraced(self, x, need_grad):
+        b, t, h, w = x.shape
         plan = self._plan(x, "full", b, t, h, w, need_grad)
         if need_grad:
             return _MDSFunction.apply(x, self, plan, *plan.params)
@@ -278,39 +460,55 @@ class MultiDimStacker(nn.Module):
             plan.run("f2d"); plan.run("f3d"); plan.run("fhead")
             return plan.logits.tensor.view(b, -1).clone()
 
-    def _inference_only(self, what):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(f"mds: {what} called on its own is an inference path (src/predictors.py:50-72); "
-                                      f"wrap it in torch.no_grad() — training goes through forward()")
+    SUB_PARAMS = {"2d": ("conv2d_encoder.", "conv2d_projection."), "3d": ("conv3d_encoder.", "conv3d_projection."),
+                  "head": ("global_pool.", "classifier.")}
+
+    def _sub(self, kind, inp, B, T, H, W):
+        """one of the three sub-forwards: inference plan under no_grad (src/predictors.py:58-70), differentiable otherwise"""
+        names = self.SUB_PARAMS[kind]
+        params = [p for n, p in self.named_parameters() if n.startswith(names)]
+        need_grad = torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in params))
+        plan = self._plan(inp, kind, B, T, H, W, need_grad)
+        if need_grad:
+            return _SubFunction.apply(inp, self, plan, kind, *params)
+        return self._run_sub(plan, kind, inp)
+
+    def _run_sub(self, plan, kind, x):
+        with plan.device_guard():
+            if kind == "2d":
+                b, t, h, w = x.shape
+                plan.bind_input(x)
+                plan.begin_forward(self._mask_override)
+                plan.run("f2d")
+                f = plan.feat.tensor.view(b, t // self.stack_size, plan.h, plan.w, self.num_3d_features)
+                return f.permute(0, 1, 4, 2, 3).float().contiguous()      # (b, S, 192, h, w) like the reference
+            if kind == "3d":
+                b, t, c, h, w = x.shape
+                plan.feat.tensor.view(b, t, h, w, c).copy_(x.detach().permute(0, 1, 3, 4, 2))
+                plan.begin_forward(self._mask_override)
+                plan.run("f3d")
+                cq = self.num_features // t
+                y = plan.out3d.tensor.view(b, t, h, w, cq)
+                return y.permute(0, 1, 4, 2, 3).reshape(b, self.num_features, h, w).float().contiguous()
+            b, f, h, w = x.shape
+            t = self.num_stacks
+            cq = f // t
+            plan.yq.tensor.view(b, t, h, w, cq).copy_(x.detach().view(b, t, cq, h, w).permute(0, 1, 3, 4, 2))
+            plan.begin_forward(self._mask_override)
+            plan.run("fhead")
+            return plan.logits.tensor.view(b, -1).clone()
 
     @torch.compiler.disable
     def forward_2d(self, x):
-        self._inference_only("forward_2d")
         b, t, h, w = x.shape
         assert t % self.stack_size == 0
-        s = t // self.stack_size
-        x = x.float().contiguous()
-        plan = self._plan(x, "2d", b, t, h, w, False)
-        with plan.device_guard():
-            plan.bind_input(x)
-            plan.begin_forward(None)
-            plan.run("f2d")
-            f = plan.feat.tensor.view(b, s, plan.h, plan.w, self.num_3d_features)
-            return f.permute(0, 1, 4, 2, 3).float().contiguous()      # (b, S, 192, h, w) like the reference
+        return self._sub("2d", x.float().contiguous(), b, t, h, w)
 
     @torch.compiler.disable
     def forward_3d(self, x):
-        self._inference_only("forward_3d")
         b, t, c, h, w = x.shape
         assert c == self.num_3d_features and t == self.num_stacks
-        plan = self._plan(x, "3d", b, t * self.stack_size, h, w, False)
-        with plan.device_guard():
-            plan.feat.tensor.view(b, t, h, w, c).copy_(x.permute(0, 1, 3, 4, 2))
-            plan.begin_forward(None)
-            plan.run("f3d")
-            cq = self.num_features // t
-            y = plan.out3d.tensor.view(b, t, h, w, cq)
-            return y.permute(0, 1, 4, 2, 3).reshape(b, self.num_features, h, w).float().contiguous()
+        return self._sub("3d", x, b, t * self.stack_size, h, w)
 
     @torch.compiler.disable
     def forward_tail(self, feats):
@@ -324,13 +522,5 @@ class MultiDimStacker(nn.Module):
 
     @torch.compiler.disable
     def forward_head(self, x):
-        self._inference_only("forward_head")
         b, f, h, w = x.shape
-        t = self.num_stacks
-        cq = f // t
-        plan = self._plan(x, "head", b, t * self.stack_size, h, w, False)
-        with plan.device_guard():
-            plan.yq.tensor.view(b, t, h, w, cq).copy_(x.view(b, t, cq, h, w).permute(0, 1, 3, 4, 2))
-            plan.begin_forward(self._mask_override)
-            plan.run("fhead")
-            return plan.logits.tensor.view(b, -1).clone()
+        return self._sub("head", x, b, self.num_stacks * self.stack_size, h, w)

@@ -198,10 +198,62 @@ def test_second_backward_and_inplace_input_edit_raise():
         loss.backward()
 
 
-def test_pretrained_true_is_never_a_silent_random_init():
+def test_pretrained_true_is_never_a_silent_random_init(monkeypatch):
+    """timm.create_model(pretrained=True) fails hard in the reference when the weights are unreachable; so does this
+    (ADVICE r2), unless the caller opts in to a random encoder explicitly"""
+    monkeypatch.delenv("MDS_ALLOW_RANDOM_INIT", raising=False)
+    with pytest.raises(RuntimeError, match="could not be loaded"):
+        mds.MultiDimStacker(**dict(orc.BASIC_CONFIG_KWARGS, pretrained=True))
+    monkeypatch.setenv("MDS_ALLOW_RANDOM_INIT", "1")
     with pytest.warns(RuntimeWarning, match="RANDOMLY INITIALISED"):
         m = mds.MultiDimStacker(**dict(orc.BASIC_CONFIG_KWARGS, pretrained=True))
     assert m.pretrained_loaded is False
+
+
+def test_forward_is_a_registered_operator_traceable_with_fullgraph():
+    """torch.library.custom_op + register_fake + register_autograd - torch.compile(fullgraph=True) traces through
+    forward() (no graph break), eager and compiled results are identical, the EMA-style deep copy is its own operator target,
+    frozen parameters get no gradient, and a second backward raises."""
+    import torch._dynamo as dynamo
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    _, prod = _pair(kw)
+    prod.train()
+    x = torch.rand(1, 15, 32, 64, generator=torch.Generator().manual_seed(21))
+    tgt = torch.tensor([[1.0, 0.0]])
+    state = copy.deepcopy(prod.state_dict())
+    le, ge = _step(prod, x, tgt)
+    ema = copy.deepcopy(prod)                      # src/ema.py:40
+    assert ema._handle != prod._handle and ema._lib is prod._lib
+    prod.load_state_dict(state)
+    dynamo.reset()
+    cm = torch.compile(prod, fullgraph=True, backend="aot_eager")
+    lc, gc = _step(cm, x, tgt)
+    assert torch.equal(lc, le)
+    for n in ge:
+        assert torch.equal(gc[n if n in gc else "_orig_mod." + n], ge[n]), n
+    # the graph holds exactly one mds node
+    seen = []
+
+    def backend(gm, example_inputs):
+        seen.extend(str(n.target) for n in gm.graph.nodes if n.op == "call_function")
+        return gm.forward
+    dynamo.reset()
+    prod.load_state_dict(state)
+    torch.compile(prod, fullgraph=True, backend=backend)(x)
+    assert sum("mds.forward" in t for t in seen) == 1, seen
+    # frozen encoder (src/argus_models.py:104-110): no gradients there, the tail still trains
+    for p in prod.conv2d_encoder.parameters():
+        p.requires_grad_(False)
+    prod.zero_grad(set_to_none=True)
+    loss = orc.sigmoid_focal_loss(prod(x), tgt, alpha=-1.0, gamma=1.2)
+    loss.backward(retain_graph=True)
+    assert all(p.grad is None for p in prod.conv2d_encoder.parameters()) and prod.classifier.weight.grad is not None
+    with pytest.raises(RuntimeError, match="released"):
+        loss.backward()
+    # the copy runs on its own plans (validation uses the EMA copy in eval mode, src/argus_models.py:80-83)
+    ema.eval()
+    with torch.no_grad():
+        assert ema(x).shape == (1, 2)
 
 
 def test_plan_cache_is_bounded():
@@ -241,3 +293,43 @@ def test_pinned_plans_do_not_count_against_the_lru_budget():
             p.in_flight = False
         prod.forward_head(torch.rand(1, 1280, 3, 3))
         assert prod._cache.idle() <= mod.MAX_PLANS
+
+
+def test_sub_forwards_are_differentiable_and_compose_to_forward():
+    """multidim_stacker.py:210-243: forward == forward_head(forward_3d(forward_2d(x))) and every piece is an ordinary
+    differentiable method - logits and all parameter gradients of the composition equal those of forward() (and the oracle's)."""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    ref, prod = _pair(kw)
+    ref.train(); prod.train()
+    x = torch.rand(1, 15, 32, 64, generator=torch.Generator().manual_seed(31))
+    tgt = torch.tensor([[0.0, 1.0]])
+    state = copy.deepcopy(prod.state_dict())
+    lf, gf = _step(prod, x, tgt)
+    prod.load_state_dict(state)
+    prod.zero_grad(set_to_none=True)
+    f2 = prod.forward_2d(x)
+    assert f2.requires_grad and f2.shape == (1, 5, 192, 1, 2)
+    f3 = prod.forward_3d(f2)
+    logits = prod.forward_head(f3)
+    orc.sigmoid_focal_loss(logits, tgt, alpha=-1.0, gamma=1.2).backward()
+    _cmp("composed logits", logits, lf, 1e-6, 1e-6)
+    floor = 1e-2 * float(np.median([v.abs().max().item() for v in gf.values()]))
+    for n, p in prod.named_parameters():
+        assert p.grad is not None, n
+        err = (p.grad - gf[n]).abs().max().item() / max(gf[n].abs().max().item(), floor)
+        assert err < 2e-3, (n, err)      # (the 3D-tail -> projection seam sums in a different order: fp32 noise on zero-ish BN biases)
+    # the oracle composes the same way
+    lr, gr = _step(ref, x, tgt)
+    _cmp("oracle logits", logits, lr, 1e-3, 1e-4)
+    # gradient with respect to the INPUT of forward_3d / forward_head (cached-feature fine-tuning)
+    prod.load_state_dict(state)
+    feats = f2.detach().clone().requires_grad_(True)
+    out = prod.forward_head(prod.forward_3d(feats))
+    out.sum().backward()
+    fr = f2.detach().clone().requires_grad_(True)
+    ref.load_state_dict(state)
+    ref.forward_head(ref.forward_3d(fr)).sum().backward()
+    _cmp("d/dfeats", feats.grad, fr.grad, 2e-3, 1e-6 + 2e-3 * fr.grad.abs().max().item())
+    # under no_grad they are the predictor's inference calls, as before
+    with torch.no_grad():
+        assert not prod.forward_2d(x[:, :3]).requires_grad

@@ -137,3 +137,39 @@ def test_shape_chain_comments():
         y = m.forward_3d(f)
         assert y.shape == (2, 1280, 2, 3)
         assert m.forward_head(y).shape == (2, 2)
+
+
+def test_encoder_restatement_matches_timm_published_model_card():
+    """External pins for the un-vendored timm==0.9.2 encoder: timm's results table lists
+    tf_efficientnetv2_b0 with 7.14 M parameters, 0.73 GMACs / 4.77 M activations at 224 px and 0.54 GMACs / 3.51 M activations
+    at its 192 px train size.  The features-only restatement + timm's head (conv_head 1x1 192->1280, bn2,
+    classifier 1280->1000) must reproduce all five numbers, the stage strides and the feature channel counts."""
+    import torch
+    from oracle import multidim_stacker_ref as orc
+    enc = orc.EfficientNetV2B0Features(in_chans=3).eval()
+    params = sum(p.numel() for p in enc.parameters()) + 192 * 1280 + 2 * 1280 + 1280 * 1000 + 1000
+    assert params == 7139704
+
+    def profile(size):
+        acts, macs, shapes = [0], [0], []
+
+        def hook(m, i, o):
+            acts[0] += o.numel()
+            if isinstance(m, torch.nn.Conv2d):
+                macs[0] += o.numel() * m.in_channels // m.groups * m.kernel_size[0] * m.kernel_size[1]
+        hs = [m.register_forward_hook(hook) for m in enc.modules() if isinstance(m, torch.nn.Conv2d)]
+        hs += [st.register_forward_hook(lambda m, i, o: shapes.append(tuple(o.shape[1:]))) for st in enc.blocks]
+        with torch.no_grad():
+            enc(torch.zeros(1, 3, size, size))
+        for h in hs:
+            h.remove()
+        s = size // 32
+        return acts[0] + 1280 * s * s + 1000, macs[0] + 192 * 1280 * s * s + 1280 * 1000, shapes
+    a224, m224, shapes = profile(224)
+    a192, m192, _ = profile(192)
+    assert round(a224 / 1e6, 2) == 4.77 and round(a192 / 1e6, 2) == 3.51, (a224, a192)
+    # timm's GMACs come from a profiler that also counts normalisation / pooling arithmetic: conv + linear MACs alone are
+    # 0.718 G and 0.528 G - within 2 % of the published 0.73 / 0.54
+    assert abs(m224 / 1e9 - 0.73) < 0.015 and abs(m192 / 1e9 - 0.54) < 0.015, (m224, m192)
+    assert shapes == [(16, 112, 112), (32, 56, 56), (48, 28, 28), (96, 14, 14), (112, 14, 14), (192, 7, 7)]
+    assert [f["num_chs"] for f in enc.feature_info] == [16, 32, 48, 112, 192]
