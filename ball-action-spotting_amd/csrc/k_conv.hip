@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, i
       const int n = n0 + 16 * (e >> 2) + 4 * q + (e & 3);
       if (16 * (e >> 2) < BN && n < Cout) {
         const int slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7 + wave) % MDS_STAT_SLOTS;
-        float* st = a.stats + (long)slot * 2 * Cout;
-        atomicAdd(st + n, ps[0]);
-        atomicAdd(st + Cout + n, pss[0]);
+        double* st = a.stats + (long)slot * 2 * Cout;
+        atomicAdd(st + n, (double)ps[0]);
+        atomicAdd(st + Cout + n, (double)pss[0]);
       }
     }
     __syncthreads();  // the next N-tile restages LDS
@@ -468,9 +468,9 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
     }
     __syncthreads();
     if (tid < BNQ && n0 + tid < Cout) {
-      float* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * Cout;
-      atomicAdd(st + n0 + tid, st_s[tid]);
-      atomicAdd(st + Cout + n0 + tid, st_ss[tid]);
+      double* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * Cout;
+      atomicAdd(st + n0 + tid, (double)st_s[tid]);
+      atomicAdd(st + Cout + n0 + tid, (double)st_ss[tid]);
     }
   }
 }

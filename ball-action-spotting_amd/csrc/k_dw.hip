@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(mds_dw_fwd_args a, int nchu
       const int k = tid / CC, c = tid - k * CC;
       if (cbeg + c < C) {
         const int slot = (blockIdx.x + blockIdx.y * gridDim.x + n * 5) % MDS_STAT_SLOTS;
-        atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, st_l[tid]);
+        atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, (double)st_l[tid]);
       }
     }
   }
@@ -262,6 +262,23 @@ MDS_DEV f32x2 epi2(f32x2 v, int mode, f32x2 sc, f32x2 sh) {
 }
 
 struct DwStrips { int nchunks, nseg, L, nbands, spt, swap; long nstrips; };
+// Workgroup -> (strip block, channel chunk).  Consecutive workgroup ids go to consecutive XCDs (id % 8), each with its own L2.
+// Neighbouring strips share halo rows / columns ((R + 2) / R x (L + 2) / L = 1.5x the compulsory reads when every strip fetches
+// its own halo from HBM - the PMC FETCH_SIZE of round 2 showed 1.6x): XCD x takes a CONTIGUOUS range of the (chunk, strip)
+// sequence, so the strips that share a halo run on the same XCD at about the same time and the halo comes from its L2.
+// MDS_KNOB_DW_ORDER = 1 / 2 keep the former orders (channel chunk fastest / strip fastest, no remap) for A/B runs.
+struct DwBlock { int bx, chunk; };
+MDS_DEV DwBlock dw_block(const DwStrips& g) {
+  DwBlock b;
+  if (g.swap == 1) { b.bx = blockIdx.y; b.chunk = blockIdx.x; return b; }
+  if (g.swap == 2) { b.bx = blockIdx.x; b.chunk = blockIdx.y; return b; }
+  const unsigned nb = gridDim.x * gridDim.y, id = blockIdx.x + gridDim.x * blockIdx.y;
+  const unsigned q = nb >> 3, r = nb & 7, xcd = id & 7, slot = id >> 3;
+  const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;   // bijective for any nb
+  b.chunk = (int)(logical / gridDim.x);
+  b.bx = (int)(logical - (unsigned)b.chunk * gridDim.x);
+  return b;
+}
 
 template <typename T, int R>
 __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
@@ -270,8 +287,9 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
   typedef typename P::raw_t raw_t;
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
-  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
+  const DwBlock db = dw_block(g);   // (strip block, channel chunk) of this workgroup, XCD-aware
+  const int bx = db.bx;
+  const int C = a.C, cbeg = db.chunk * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   const int mode = a.pro.mode;
   const int emode = a.epi.mode;
@@ -362,7 +380,7 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
       float t = 0.f;
 #pragma unroll
       for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
     }
   }
 }
@@ -378,8 +396,9 @@ __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwSt
   __shared__ float dwl[8][9][64];
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
-  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
+  const DwBlock db = dw_block(g);   // (strip block, channel chunk) of this workgroup, XCD-aware
+  const int bx = db.bx;
+  const int C = a.C, cbeg = db.chunk * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
   f32x2 w[3][3], dwacc[3][3], sc = splat2(0.f), sh = splat2(0.f), mu = splat2(0.f), rs = splat2(0.f);
@@ -494,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwSt
     float t = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-    if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+    if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
   }
 }
 
@@ -513,8 +532,9 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
   __shared__ f32x2 wl[27][32];
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
-  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
+  const DwBlock db = dw_block(g);   // (strip block, channel chunk) of this workgroup, XCD-aware
+  const int bx = db.bx;
+  const int C = a.C, cbeg = db.chunk * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   const int mode = a.pro.mode;
   const int emode = a.epi.mode;
@@ -616,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
       float t = 0.f;
 #pragma unroll
       for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
     }
   }
 }
@@ -632,8 +652,9 @@ __global__ __launch_bounds__(256, 2) void dw3_bwd_kernel(mds_dw_bwd_args a, DwSt
   __shared__ float dwl[8][27][64];
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
-  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
+  const DwBlock db = dw_block(g);   // (strip block, channel chunk) of this workgroup, XCD-aware
+  const int bx = db.bx;
+  const int C = a.C, cbeg = db.chunk * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   for (int e = tid; e < 27 * 32; e += 256) {
     const int t = e >> 5, c = cbeg + 2 * (e & 31);
@@ -762,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void dw3_bwd_kernel(mds_dw_bwd_args a, DwSt
     float t = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-    if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+    if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
   }
 }
 
@@ -776,8 +797,9 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
   typedef typename P::raw_t raw_t;
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
-  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
+  const DwBlock db = dw_block(g);   // (strip block, channel chunk) of this workgroup, XCD-aware
+  const int bx = db.bx;
+  const int C = a.C, cbeg = db.chunk * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   const int mode = a.pro.mode;
   const int emode = a.epi.mode;
@@ -861,7 +883,7 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
       float t = 0.f;
 #pragma unroll
       for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
     }
   }
 }
@@ -878,8 +900,9 @@ __global__ __launch_bounds__(256, 2) void dw2s_bwd_kernel(mds_dw_bwd_args a, DwS
   __shared__ float dwl[8][9][64];
   __shared__ float red[8][4][32];
   const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
-  const int bx = g.swap ? blockIdx.y : blockIdx.x;   // strip block; the channel chunk is the FAST grid index (see dw_strips)
-  const int C = a.C, cbeg = (g.swap ? blockIdx.x : blockIdx.y) * 64, c0 = cbeg + 2 * cp;
+  const DwBlock db = dw_block(g);   // (strip block, channel chunk) of this workgroup, XCD-aware
+  const int bx = db.bx;
+  const int C = a.C, cbeg = db.chunk * 64, c0 = cbeg + 2 * cp;
   const bool cvalid = c0 < C;
   f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
   f32x2 w[3][3], dwacc[3][3], sc = splat2(0.f), sh = splat2(0.f), mu = splat2(0.f), rs = splat2(0.f);
@@ -1000,7 +1023,7 @@ __global__ __launch_bounds__(256, 2) void dw2s_bwd_kernel(mds_dw_bwd_args a, DwS
     float t = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
-    if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, t);
+    if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
   }
 }
 
@@ -1020,14 +1043,14 @@ static DwStrips dw_strips(int images, int H, int W, int C, int R, int want_L = 0
   g.spt = 1;   // strips per thread: 2 and 4 measured slower at every layer shape
   // optional grid order (MDS_KNOB_DW_ORDER = 1): channel chunk fastest - the blocks in flight together then cover ALL
   // chunks of the same pixels, so a pixel's whole channel row is fetched at about the same time
-  g.swap = mds_knob(MDS_KNOB_DW_ORDER) == 1 ? 1 : 0;   // (measured on MI355X: no difference - these kernels are bound by the SiLU prologue's transcendentals, not by HBM)
+  g.swap = mds_knob(MDS_KNOB_DW_ORDER);                // 0: XCD-aware remap (dw_block), 1 / 2: the former orders
   return g;
 }
 
 static dim3 dw_grid(DwStrips& g) {
   const int sb = cdiv(g.nstrips, 8 * g.spt);
-  if (sb >= 65536) g.swap = 0;   // grid.y limit
-  return g.swap ? dim3(g.nchunks, sb) : dim3(sb, g.nchunks);
+  if (sb >= 65536 && g.swap == 1) g.swap = 2;   // grid.y limit
+  return g.swap == 1 ? dim3(g.nchunks, sb) : dim3(sb, g.nchunks);
 }
 
 extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
@@ -1282,7 +1305,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(mds_dw_bwd_args a, int nchu
     const int k = tid / CC, c = tid - k * CC;
     if (cbeg + c < C) {
       const int slot = (blockIdx.x + blockIdx.y * gridDim.x + n * 5) % MDS_STAT_SLOTS;
-      atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, st_l[tid]);
+      atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, (double)st_l[tid]);
     }
   }
 }

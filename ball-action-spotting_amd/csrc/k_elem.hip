@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_ar
   }
   block_reduce_rows<2>(acc, m, red);
   if (m.valid && m.rsub == 0) {
-    float* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * a.C;
+    double* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * a.C;     // fp64 slots (include/mds.h)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      atomicAdd(st + c0 + j, acc[0][j]);
-      atomicAdd(st + a.C + c0 + j, acc[1][j]);
+      atomicAdd(st + c0 + j, (double)acc[0][j]);
+      atomicAdd(st + a.C + c0 + j, (double)acc[1][j]);
     }
   }
 }

@@ -83,10 +83,11 @@ extern "C" int mds_pack_weights(const mds_pack_job* jobs_dev, int njobs, int max
 // (all 8 loads independent and coalesced along c), then one LDS hop.
 #define FIN_CH 32
 static_assert(MDS_STAT_SLOTS == 32, "finalize kernels sum 8 groups of 4 slots");
-MDS_DEV void fin_slot_sums(const float* stats, int C, int c, int sg, double (&red)[2][8][FIN_CH], int cl) {
+template <typename S>   // S = float (forward statistics) or double (backward statistics)
+MDS_DEV void fin_slot_sums(const S* stats, int C, int c, int sg, double (&red)[2][8][FIN_CH], int cl) {
   double s = 0.0, ss = 0.0;
   if (c < C) {
-    float v[4], w[4];
+    S v[4], w[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       v[k] = stats[((sg * 4 + k) * 2 + 0) * C + c];
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(mds_se_fc_bwd_args a) {
   dp /= (float)a.rows_per_group;
   a.dpooled[(long)g * C + c] = dp;
   if (bn) {
-    atomicAdd(a.bn_stats + c, gt_c * bs[0] + dp * bs[2]);
-    atomicAdd(a.bn_stats + C + c, gt_c * bs[1] + dp * bs[3]);
+    atomicAdd(a.bn_stats + c, (double)gt_c * bs[0] + (double)dp * bs[2]);
+    atomicAdd(a.bn_stats + C + c, (double)gt_c * bs[1] + (double)dp * bs[3]);
   }
 }
 // launch B — parameter gradients: dw2[c][r], dw1[r][c] (thread per (r, c), c fastest); r == 0

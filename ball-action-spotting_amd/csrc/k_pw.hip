@@ -358,17 +358,21 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
           for (int r = 0; r < 4; ++r) { ps[nf * 4 + r] += v[nf][r]; pss[nf * 4 + r] += v[nf][r] * v[nf][r]; }
       }
     }
-    float* const stat_dst = POST ? a.post.stats : a.stats;
-    if (stat_dst) {
+    if (POST ? (a.post.stats != nullptr) : (a.stats != nullptr)) {
       // after the reduce-scatter every lane of the wave holds ONE column's partial sums: add them to
       // the slot straight away (no LDS staging, no block barrier at the end of every tile)
       const int e = reduce_scatter16(ps, i);
       reduce_scatter16(pss, i);
       const int n = n0 + 64 * wn + 16 * (e >> 2) + 4 * q + (e & 3);
       if (n < N) {
-        float* st = stat_dst + (long)((blockIdx.x + wm) % MDS_STAT_SLOTS) * 2 * N;
-        atomicAdd(st + n, ps[0]);
-        atomicAdd(st + N + n, pss[0]);
+        const long so = (long)((blockIdx.x + wm) % MDS_STAT_SLOTS) * 2 * N;
+        if (POST) {   // backward sums: fp64 slots (include/mds.h)
+          atomicAdd(a.post.stats + so + n, (double)ps[0]);
+          atomicAdd(a.post.stats + so + N + n, (double)pss[0]);
+        } else {
+          atomicAdd(a.stats + so + n, (double)ps[0]);
+          atomicAdd(a.stats + so + N + n, (double)pss[0]);
+        }
       }
     }
   }

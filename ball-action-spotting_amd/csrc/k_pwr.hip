@@ -240,15 +240,19 @@ __global__ __launch_bounds__(256, 2) void pw_fwd_wres_kernel(mds_pw_fwd_args a, 
       if (base + d * G < MT) tile(std::false_type{}, base + d * G, rx[d], rys[d], rys[(d + 1) % D]);
   }
 
-  float* const stat_dst = POST ? a.post.stats : a.stats;
-  if (stat_dst) {   // once per block: every lane ends up with one column's partial sums
+  if (POST ? (a.post.stats != nullptr) : (a.stats != nullptr)) {   // once per block: every lane ends up with one column's partial sums
     const int e = reduce_scatter16(ps, i);
     reduce_scatter16(pss, i);
     const int n = n0 + 16 * NF * wn + 16 * (e >> 2) + 4 * q + (e & 3);
     if ((e >> 2) < nfr && n < N) {
-      float* st = stat_dst + (long)((blockIdx.x + wm) % MDS_STAT_SLOTS) * 2 * N;
-      atomicAdd(st + n, ps[0]);
-      atomicAdd(st + N + n, pss[0]);
+      const long so = (long)((blockIdx.x + wm) % MDS_STAT_SLOTS) * 2 * N;
+      if (POST) {   // backward sums: fp64 slots (include/mds.h)
+        atomicAdd(a.post.stats + so + n, (double)ps[0]);
+        atomicAdd(a.post.stats + so + N + n, (double)pss[0]);
+      } else {
+        atomicAdd(a.stats + so + n, (double)ps[0]);
+        atomicAdd(a.stats + so + N + n, (double)pss[0]);
+      }
     }
   }
 }

@@ -96,12 +96,12 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(mds_stem_fwd_args a) {
     }
   }
   if (a.stats) {
-    float* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * a.Cout;
+    double* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * a.Cout;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float s = sum_over_i16(s_[e]), ss = sum_over_i16(ss_[e]);
       const int oc = 16 * (e >> 2) + 4 * q + (e & 3);
-      if (i == 0 && oc < a.Cout) { atomicAdd(st + oc, s); atomicAdd(st + a.Cout + oc, ss); }
+      if (i == 0 && oc < a.Cout) { atomicAdd(st + oc, (double)s); atomicAdd(st + a.Cout + oc, (double)ss); }
     }
   }
 }

@@ -22,7 +22,7 @@ HEADER = next((h for h in (os.path.join(REPO_ROOT, "include", "mds.h"), os.path.
 HIP_LIB = os.path.join(PKG_ROOT, "csrc", "libmds_hip.so")
 
 _SCALARS = {
-    "int": C.c_int, "long": C.c_long, "float": C.c_float, "long long": C.c_longlong, "unsigned char": C.c_ubyte,
+    "int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double, "long long": C.c_longlong, "unsigned char": C.c_ubyte,
 }
 
 

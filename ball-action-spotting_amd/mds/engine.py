@@ -79,8 +79,8 @@ class BNL:
     def __init__(self, pb, mod, C_, count):
         self.mod, self.C, self.count = mod, C_, int(count)
         self.buf = pb.f32(4 * C_)                      # scale | shift | mean | rstd
-        self.stats = pb.zero_fwd(SLOTS * 2 * C_) if pb.batch_stats else None
-        self.bstats = pb.zero_bwd(SLOTS * 2 * C_) if pb.need_grad else None
+        self.stats = pb.zero_fwd64(SLOTS * 2 * C_) if pb.batch_stats else None      # fp64 slots (include/mds.h)
+        self.bstats = pb.zero_bwd64(SLOTS * 2 * C_) if pb.need_grad else None      # fp64 slots (include/mds.h)
         self.coef = pb.f32(3 * C_) if pb.need_grad else None
         self.lin = pb.f32(3 * C_) if pb.need_grad else None     # A, B, D of dy = A*g + B*y + D (mds_dyp_t)
 
@@ -224,11 +224,15 @@ class Plan:
         self.segs: Dict[str, list] = {"pack": [], "f2d": [], "f3d": [], "fhead": [], "bhead": [], "b3d": [], "b2d": []}
         self._recs: Dict[str, list] = {"2d": [], "3d": [], "head": []}
         self.pack_jobs = []
+        self.taps = []           # block outputs in forward order: dict(tag, buf, bn (raw tensor read through BN+SiLU) or None, rows, C)
         self.masks = []          # (Lazy view, keep_prob)
         self._mask_total = 0
         self.mask_arena = Lazy("own", 0, torch.float32)
         self.zf_arena = Lazy("own", 0, torch.float32)
         self.zb_arena = Lazy("own", 0, torch.float32)
+        self.zb64_arena = Lazy("own", 0, torch.float64)     # backward BatchNorm sums (fp64 slots)
+        self.zf64_arena = Lazy("own", 0, torch.float64)     # forward BatchNorm statistics (fp64 slots)
+        self._zb64, self._zf64 = 0, 0
         # flat gradient arena over all parameters, in parameter order
         self.params = list(module.parameters())
         self.poff, off = {}, 0
@@ -260,6 +264,16 @@ class Plan:
     def zero_bwd(self, n):
         l = self.zb_arena.sub(self._zb, n)
         self._zb += n
+        return l
+
+    def zero_fwd64(self, n):
+        l = self.zf64_arena.sub(self._zf64, n)
+        self._zf64 += n
+        return l
+
+    def zero_bwd64(self, n):
+        l = self.zb64_arena.sub(self._zb64, n)
+        self._zb64 += n
         return l
 
     def grad(self, p):
@@ -489,6 +503,7 @@ class Plan:
         xout = self.act(Mout, cout)
         self.op(fseg, "bn_res", dtype=self.code, M=Mout, C=cout, y=y3, scale=bn3.scale, shift=bn3.shift, act=0, mask=mask,
                 rows_per_group=rpg, shortcut=xin if has_skip else None, out=xout)
+        self.taps.append(dict(tag=f"{fseg}.ir{len(self.taps)}", buf=xout, bn=None, rows=Mout, C=cout))
 
         fuse = self.fuse_bn_bwd
 
@@ -603,6 +618,7 @@ class Plan:
         feat = self.act(M, cf)
         self.op("f2d", "bn_res", dtype=self.code, M=M, C=cf, y=yp, scale=bnp.scale, shift=bnp.shift, act=1, mask=None,
                 rows_per_group=0, shortcut=None, out=feat)
+        self.taps.append(dict(tag="f2d.proj", buf=feat, bn=None, rows=M, C=cf))
         xenc = cur
 
         def proj_bwd(seg, dfeat, nxt_head):
@@ -627,6 +643,7 @@ class Plan:
                                           blk.stride, blk.conv.weight, blk.bn1)
         if self.eval_epilogues:
             return y, None, OH, OW       # activated output, no backward
+        self.taps.append(dict(tag=f"f2d.cn{len(self.taps)}", buf=y, bn=bn1, rows=N * OH * OW, C=blk.cout))
 
         def bwd(seg, u, nxt_head):
             if fr:
@@ -664,6 +681,7 @@ class Plan:
         xout = self.act(M, cout)
         self.op("f2d", "bn_res", dtype=self.code, M=M, C=cout, y=yb, scale=bn2.scale, shift=bn2.shift, act=0, mask=mask,
                 rows_per_group=rpg, shortcut=xin if has_skip else None, out=xout)
+        self.taps.append(dict(tag=f"f2d.er{len(self.taps)}", buf=xout, bn=None, rows=M, C=cout))
 
         fuse = self.fuse_bn_bwd
 
@@ -713,6 +731,7 @@ class Plan:
         M, cf, cq = B * S * h * w, m.num_3d_features, m.num_features // S
         bnq = BNL(self, m.conv3d_projection[1], cq, M)
         yq = self._pw("f3d", cur, M, cf, cq, m.conv3d_projection[0].weight, stats_bn=bnq)
+        self.taps.append(dict(tag="f3d.proj", buf=yq, bn=bnq, rows=M, C=cq))
         x3 = cur
 
         def bwd(seg, uq, nxt_head):
@@ -756,9 +775,10 @@ class Plan:
     # ------------------------------------------------------------------ binding
     def _finalize(self):
         dev = self.device
-        self.zf_arena.numel, self.zb_arena.numel, self.mask_arena.numel = self._zf, self._zb, self._mask_total
-        for arena in (self.zf_arena, self.zb_arena, self.mask_arena, self.grad_arena):
-            arena.tensor = torch.zeros(max(arena.numel, 1), dtype=torch.float32, device=dev)
+        self.zf_arena.numel, self.zb_arena.numel, self.mask_arena.numel, self.zb64_arena.numel = self._zf, self._zb, self._mask_total, self._zb64
+        self.zf64_arena.numel = self._zf64
+        for arena in (self.zf_arena, self.zb_arena, self.mask_arena, self.grad_arena, self.zb64_arena, self.zf64_arena):
+            arena.tensor = torch.zeros(max(arena.numel, 1), dtype=arena.dtype, device=dev)
         for l in self._lazy:
             l.tensor = torch.empty(max(l.numel, 1), dtype=l.dtype, device=dev)
         if self.masks:
@@ -904,6 +924,17 @@ class Plan:
                 self.lib.check(rc, name)
             self.profile.append((name, seg, e0, e1, cost))
 
+    def read_taps(self):
+        """[(tag, fp32 tensor [rows][C])] of every block output of the last forward (training plans materialise them; a tap
+        with a BatchNorm attached is stored raw and read through BN + SiLU here) - the per-layer parity tests' view"""
+        out = []
+        for t in self.taps:
+            v = t["buf"].resolve().view(t["rows"], t["C"]).float()
+            if t["bn"] is not None:
+                v = torch.nn.functional.silu(v * t["bn"].scale.resolve() + t["bn"].shift.resolve())
+            out.append((t["tag"], v))
+        return out
+
     def pack_weights(self):
         if self.pack_jobs:
             self.lib.check(self.lib.fn["pack_weights"](self.pack_table.data_ptr(), len(self.pack_jobs), self.pack_max,
@@ -922,6 +953,7 @@ class Plan:
 
     def begin_forward(self, mask_override=None):
         self.zf_arena.tensor.zero_()
+        self.zf64_arena.tensor.zero_()
         if self.masks:
             if mask_override is not None:
                 self.mask_arena.tensor.copy_(mask_override.to(self.device, torch.float32).view(-1))
@@ -935,6 +967,7 @@ class Plan:
 
     def begin_backward(self):
         self.zb_arena.tensor.zero_()
+        self.zb64_arena.tensor.zero_()
         self.grad_arena.tensor.zero_()
 
     def stale(self):

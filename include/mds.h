@@ -16,8 +16,12 @@
  *  - Activations are channels-last "rows": a tensor [rows][C] with C contiguous, rows =
  *    N*H*W (2D) or B*T*H*W (3D).  dtype selects the storage type of activations and packed
  *    weights (MDS_F32 / MDS_BF16); statistics, gates, parameters' grads are always fp32.
- *  - "stats" buffers are fp32 [MDS_STAT_SLOTS][2][C], zeroed by the caller before the producing
- *    launch: slot s, row 0 = partial sum, row 1 = partial sum of squares (or of g*xhat).
+ *  - "stats" buffers are fp64 [MDS_STAT_SLOTS][2][C], zeroed by the caller before the producing
+ *    launch: slot s, row 0 = partial sum, row 1 = partial sum of squares (or of g*xhat).  Blocks reduce their rows
+ *    in fp32 and add the partials to the slots with fp64 atomics: over 18 k - 4.7 M rows the sums behind a mean, a
+ *    variance (E[y^2] - mean^2) and above all the backward sums (sum g cancels to ~1e-3 of its absolute mass on the
+ *    residual stream) lose up to 1e-3 when thousands of partials are accumulated by fp32 atomics in a
+ *    run-dependent order (round 2); in fp64 the cross-block accumulation is exact to 1e-16 and order-independent.
  */
 #ifndef MDS_H
 #define MDS_H
@@ -25,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 113
+#define MDS_VERSION 114
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -41,7 +45,7 @@ const char* mds_last_error(void);
 /* Developer knobs (process-wide, 0 = default).  MDS_KNOB_CONV_BLOCKS caps the grid of the persistent convolution
  * kernel so that the parity tests can drive its multi-tile software pipeline at small sizes. */
 #define MDS_KNOB_CONV_BLOCKS 0
-#define MDS_KNOB_DW_ORDER 1      /* 1: depthwise kernels take the channel chunk as the fast grid index (A/B switch) */
+#define MDS_KNOB_DW_ORDER 1      /* depthwise grids: 0 = XCD-aware remap (default), 1 = channel chunk fastest, 2 = strip fastest (the former default) */
 #define MDS_KNOB_PW_WRES 2     /* 1: mds_pw_fwd never takes the filter-resident kernel (A/B switch); 2: takes it at any M (tests); 3: lower row bar */
 #define MDS_KNOB_PW_DEEP 3     /* 1: mds_pw_fwd keeps TWO K chunks in flight for the K-heavy layers (study variant: slower inside the step) */
 #define MDS_KNOB_WG_DBG 4      /* ablation bits of the 1x1 weight-gradient kernels (measurement only) */
@@ -127,7 +131,7 @@ typedef struct {
   const float* bn;     /* [4][N] */
   const float* mask;   /* [groups] (MASK) */
   long rows_per_group;
-  float* stats;        /* [SLOTS][2][N] caller-zeroed: sum g, sum g*xhat */
+  double* stats;       /* fp64 [SLOTS][2][N] caller-zeroed: sum g, sum g*xhat */
 } mds_poststat_t;
 
 /* ---- K4: 1x1 convolution = GEMM  y[M][N] = pro(x)[M][K] * w[N][K]^T  (+ residual)
@@ -142,7 +146,7 @@ typedef struct {
   void* y;              /* [M][N]            */
   mds_pro_t pro;
   const void* residual; /* optional [M][N], added after the product                            */
-  float* stats;         /* optional [SLOTS][2][N]                                               */
+  double* stats;         /* optional [SLOTS][2][N]                                               */
   mds_dyp_t xdy;        /* data-gradient use: xdy.mode == 1 -> the x operand is dy formed on load
                            (channels = K; `x` ignored, pro must be NONE)                         */
   mds_poststat_t post;  /* data-gradient use: BN-backward sums of the NEXT layer in the epilogue */
@@ -187,7 +191,7 @@ typedef struct {
   void* y;
   mds_pro_t pro;        /* modes NONE / AFFINE / BN_SILU                 */
   const void* residual; /* optional, same indexing as y                  */
-  float* stats;         /* optional [SLOTS][2][Cout]                     */
+  double* stats;         /* optional [SLOTS][2][Cout]                     */
   /* tap groups (ngroups = 2..4; 0/1 = none): the tap list is the concatenation of the groups' taps, every group is
    * evaluated from the SAME staged input patch and written to its own sub-grid (g_oy0 + a*os, g_ox0 + b*os), a < g_A,
    * b < g_B — the four output parities of the stride-2 data gradient in one launch (one read of dy instead of
@@ -233,7 +237,7 @@ typedef struct {
   const float* x; /* [N][3][H][W] fp32   */
   const void* w;  /* [Cout][32] packed: k = plane*9 + ky*3 + kx, zero padded to 32 */
   void* y;        /* [N][OH][OW][Cout]   */
-  float* stats;
+  double* stats;
   mds_ingest_t ingest;
   mds_epi_t epi;  /* eval-mode output transform */
 } mds_stem_fwd_args;
@@ -266,7 +270,7 @@ typedef struct {
   const float* w;      /* fp32 [C][kt*9] (PyTorch layout [C][1][kt][3][3]) */
   void* y;
   mds_pro_t pro;
-  float* stats;
+  double* stats;
   mds_epi_t epi;       /* eval-mode output transform (sliding-window kernels: kt == 1, or kt == 3 with T == 5) */
 } mds_dw_fwd_args;
 int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream);
@@ -287,7 +291,7 @@ typedef struct {
   mds_pro_t pro;      /* BN_SILU of the forward      */
   const float* mean;  /* [C] of x's BN (for xhat)    */
   const float* rstd;
-  float* stats;       /* [SLOTS][2][C]: sum g, sum g*xhat */
+  double* stats;      /* fp64 [SLOTS][2][C]: sum g, sum g*xhat */
 } mds_dw_bwd_args;
 int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream);
 
@@ -297,7 +301,7 @@ int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream);
 typedef struct {
   int C;
   long count;          /* elements per channel */
-  const float* stats;  /* [SLOTS][2][C]; ignored when training == 0 */
+  const double* stats;  /* [SLOTS][2][C]; ignored when training == 0 */
   const float* gamma;
   const float* beta;
   float eps, momentum;
@@ -414,7 +418,7 @@ typedef struct {
   float* db2;
   const float* bnsums; /* optional [groups][bn_nblk][4][C] from mds_se_bwd_reduce                  */
   int bn_nblk;         /* = mds_se_bwd_reduce_blocks(rows_per_group, C)                            */
-  float* bn_stats;     /* optional [SLOTS][2][C] (zeroed): slot 0 receives sum g, sum g*xhat       */
+  double* bn_stats;    /* optional fp64 [SLOTS][2][C] (zeroed): slot 0 receives sum g, sum g*xhat   */
   const float* w2t;    /* optional [R][C] copy of w2, see mds_se_fc_fwd_args                       */
 } mds_se_fc_bwd_args;
 int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream);
@@ -435,7 +439,7 @@ typedef struct {
   mds_gsrc_t g;
   const void* y;        /* raw conv output (pre-BN) */
   const float* bn;      /* [4][C] scale, shift, mean, rstd */
-  float* stats;         /* [SLOTS][2][C]: sum g, sum g*xhat */
+  double* stats;        /* fp64 [SLOTS][2][C]: sum g, sum g*xhat */
 } mds_bn_bwd_reduce_args;
 int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t stream);
 
@@ -443,7 +447,7 @@ int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t stream);
 typedef struct {
   int C;
   long count;
-  const float* stats;
+  const double* stats;  /* fp64 [SLOTS][2][C] */
   const float* gamma;
   const float* bn;  /* [4][C] */
   float* dgamma;    /* optional (NULL when the parameter is frozen) */

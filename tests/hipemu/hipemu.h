@@ -250,6 +250,7 @@ template <typename T> inline T __shfl_down(T v, unsigned d, int width = 64) { (v
 template <typename T> inline T __shfl(T v, int src, int width = 64) { (void)width; return hipemu::shfl_src(v, src); }
 
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 

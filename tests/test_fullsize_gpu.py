@@ -2,7 +2,7 @@
 
 Against the oracle, one full window (the oracle's fp32 fwd+bwd of 1 x 15 x 736 x 1280 takes ~3 s on the GPU
 box's host, see bench.py cpu_baseline):
-  * fp32 HIP vs oracle at 1 x 15 x 736 x 1280: logits and BN buffers within 1e-3, EVERY parameter gradient within 2e-3;
+  * fp32 HIP vs oracle at 1 x 15 x 736 x 1280: logits, BN buffers and EVERY parameter gradient within 1e-3;
   * config 4 (ball_finetune_long_004): 1 x 33 x 736 x 1280, encoder frozen (fwd only, BN in train mode), tail
     fwd+bwd, fp32, same bar;
   * bf16 HIP vs the fp32 oracle on the same window: logits and the direction/size of the gradient.
@@ -155,9 +155,9 @@ def test_fp32_full_window_vs_oracle_config2():
     gp = {n: p.grad for n, p in prod.named_parameters()}
     floor = 1e-2 * float(np.median([g.abs().max().item() for g in gr.values()]))
     errs = sorted(((_rel(gp[n], gr[n], floor), n) for n in gr), reverse=True)
-    # bar 2e-3: the cancellation-dominated BatchNorm-bias sums are atomically accumulated (order varies run to run);
-    # 6 runs on MI355X gave 2e-4 ... 1.05e-3 for the worst parameter
-    assert errs[0][0] < 2e-3, errs[:6]
+    # bar 1e-3 (north_star): the cancellation-dominated BatchNorm-bias sums are accumulated in fp64 slots since round 3
+    # (with fp32 slot atomics, in a run-dependent order, the worst parameter measured 2e-4 ... 1.05e-3 over runs)
+    assert errs[0][0] < 1e-3, errs[:6]
     for (n, b), (_, b2) in zip(ref.named_buffers(), prod.named_buffers()):
         assert _rel(b2, b, 1e-6) < 1e-3, n
     # bf16 kernels on the same window against the fp32 oracle: bf16 rounding through 25 blocks is ~1e-2 on the logits;
@@ -198,9 +198,9 @@ def test_fp32_full_window_vs_oracle_config4_frozen_encoder():
     assert set(gp) == set(gr) and not any(n.startswith("conv2d_encoder") for n in gp)
     floor = 1e-2 * float(np.median([g.abs().max().item() for g in gr.values()]))
     errs = sorted(((_rel(gp[n], gr[n], floor), n) for n in gr), reverse=True)
-    # bar 2e-3: the cancellation-dominated BatchNorm-bias sums are atomically accumulated (order varies run to run);
-    # 6 runs on MI355X gave 2e-4 ... 1.05e-3 for the worst parameter
-    assert errs[0][0] < 2e-3, errs[:6]
+    # bar 1e-3 (north_star): the cancellation-dominated BatchNorm-bias sums are accumulated in fp64 slots since round 3
+    # (with fp32 slot atomics, in a run-dependent order, the worst parameter measured 2e-4 ... 1.05e-3 over runs)
+    assert errs[0][0] < 1e-3, errs[:6]
     for (n, b), (_, b2) in zip(ref.named_buffers(), prod.named_buffers()):
         assert _rel(b2, b, 1e-6) < 1e-3, n          # frozen encoder still updates its running statistics
 
@@ -249,3 +249,55 @@ def test_config4_batch4_properties_with_its_own_recipe():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0], losses
+
+
+def test_bf16_block_outputs_layer_by_layer_vs_fp32_oracle():
+    """The benchmarked dtype checked LAYER BY LAYER at the real shape: one 15 x 736 x 1280 window in
+    train mode, bf16 kernels, every block output of the plan (26 taps: stage 0 ... stage 5, 2D projection, the four 3D blocks,
+    the 3D projection) against the fp32 oracle's output of the same block.  bf16 storage rounds each tensor once
+    (relative 2^-9 per element, ~2^-8 through a block's three convolutions): the bar for the relative L2 error of block d
+    (1-based depth) is 2^-7 * sqrt(d); a wrong layer shows up as O(1) from its block on."""
+    from det_init import fill_deterministic
+    ref = fill_deterministic(orc.MultiDimStacker(**KW), 21, scale=0.05).train()
+    prod = mds.MultiDimStacker(**KW)
+    prod.load_state_dict(ref.state_dict())
+    prod = prod.to(DEV).train()
+    x = torch.rand(1, 15, 736, 1280, generator=torch.Generator().manual_seed(121))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    want = []
+
+    def rows2d(t):                       # (N, C, H, W) -> [N*H*W][C]
+        return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+
+    def rows3d(t):                       # (B, C, T, H, W) -> [B*T*H*W][C]
+        return t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1])
+    hooks = []
+    for stage in ref.conv2d_encoder.blocks:
+        for blk in stage:
+            hooks.append(blk.register_forward_hook(lambda m, i, o: want.append(rows2d(o.detach()))))
+    hooks.append(ref.conv2d_projection.register_forward_hook(lambda m, i, o: want.append(rows2d(o.detach()))))
+    for blk in ref.conv3d_encoder:
+        hooks.append(blk.register_forward_hook(lambda m, i, o: want.append(rows3d(o.detach()))))
+    hooks.append(ref.conv3d_projection.register_forward_hook(lambda m, i, o: want.append(rows2d(o.detach()))))
+    with torch.no_grad():
+        lr = ref(x)
+    for h in hooks:
+        h.remove()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        lp = prod(x.to(DEV))
+    plan = next(p for pool in prod._cache.plans.values() for p in pool if p.kind == "full")
+    taps = plan.read_taps()
+    assert len(taps) == len(want) == 27, (len(taps), len(want))
+    report = []
+    for d, ((tag, got), w_) in enumerate(zip(taps, want), start=1):
+        assert got.shape == w_.shape, (tag, got.shape, w_.shape)
+        err = ((got.cpu() - w_).norm() / w_.norm()).item()
+        report.append((tag, round(err, 5)))
+        assert err < 2.0 ** -7 * d ** 0.5, (tag, err, report)
+    assert _rel(lp, lr) < 5e-2, report
+    # and the same taps in fp32 are tight: the structure of the check itself (tap order, layouts) is exact
+    with torch.no_grad():
+        prod(x.to(DEV))
+    plan32 = next(p for pool in prod._cache.plans.values() for p in pool if p.kind == "full" and p.tdt == torch.float32)
+    for (tag, got), w_ in zip(plan32.read_taps(), want):
+        assert ((got.cpu() - w_).norm() / w_.norm()).item() < 1e-4, tag

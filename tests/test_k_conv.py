@@ -58,7 +58,7 @@ def test_conv_fwd(be, dt, N, H, W, Cin, Cout, stride, mode):
     OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
     dy, dx, wi = geo.taps_fwd(pt, pl)
     y = torch.full((N, OH, OW, Cout), float("nan")).to(tdt).to(be.device)
-    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, Cout, device=be.device)
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, Cout, device=be.device, dtype=torch.float64)
     args = cabi.make("mds_conv_fwd_args", dtype=code, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout,
                      A=OH, B=OW, oy0=0, ox0=0, os=1, **{"is": stride}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9,
                      x=be.t(nhwc(x)), w=be.t(pack(w, "oi", tdt)), y=y,

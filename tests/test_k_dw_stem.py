@@ -66,7 +66,7 @@ def test_dw_fwd_bwd(be, dt, N, T, H, W, C, stride, kt):
     xd = be.t(to_rows(x)); wd = be.t(w.view(C, kt * 9))
     scd, shd = be.t(scale), be.t(shift)
     y = torch.full((N, T, OH, OW, C), float("nan")).to(tdt).to(be.device)
-    st = torch.zeros(SLOTS, 2, C, device=be.device)
+    st = torch.zeros(SLOTS, 2, C, device=be.device, dtype=torch.float64)
     pro = cabi.pro(2, scd, shd)
     be.call("dw_fwd", cabi.make("mds_dw_fwd_args", dtype=code, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=stride,
                                 pad_t=pt, pad_l=pl, kt=kt, x=xd, w=wd, y=y, pro=pro, stats=st))
@@ -80,7 +80,7 @@ def test_dw_fwd_bwd(be, dt, N, T, H, W, C, stride, kt):
     # backward kernel
     gout = torch.full((N, T, H, W, C), float("nan")).to(tdt).to(be.device)
     dw = torch.zeros(C, kt * 9, device=be.device)
-    st2 = torch.zeros(SLOTS, 2, C, device=be.device)
+    st2 = torch.zeros(SLOTS, 2, C, device=be.device, dtype=torch.float64)     # backward sums: fp64 slots
     be.call("dw_bwd", cabi.make("mds_dw_bwd_args", dtype=code, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=stride,
                                 pad_t=pt, pad_l=pl, kt=kt, x=xd, dy=be.t(to_rows(dyt)), w=wd, g=gout, dw=dw, pro=pro,
                                 mean=be.t(mean), rstd=be.t(rstd), stats=st2))
@@ -131,7 +131,7 @@ def test_stem_fwd_wgrad(be, dt, N, H, W):
     yref.backward(dyt.float())
     wp = torch.zeros(32, 32); wp[:, :27] = w.view(32, 27)
     y = torch.full((N, OH, OW, 32), float("nan")).to(tdt).to(be.device)
-    st = torch.zeros(SLOTS, 2, 32, device=be.device)
+    st = torch.zeros(SLOTS, 2, 32, device=be.device, dtype=torch.float64)
     xd = be.t(x)
     be.call("stem_fwd", cabi.make("mds_stem_fwd_args", dtype=code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
                                   x=xd, w=be.t(wp.to(tdt)), y=y, stats=st))

@@ -25,7 +25,7 @@ def bn_finalize(be, stats, count, gamma, beta, eps=1e-3, momentum=0.1, training=
 def test_bn_finalize_train_and_eval(be):
     C, M = 24, 1000
     y = torch.randn(M, C, generator=gen(0)) * 2 + 0.5
-    stats = torch.zeros(SLOTS, 2, C)
+    stats = torch.zeros(SLOTS, 2, C, dtype=torch.float64)
     stats[3, 0] = y[:400].sum(0); stats[3, 1] = (y[:400] ** 2).sum(0)
     stats[17, 0] = y[400:].sum(0); stats[17, 1] = (y[400:] ** 2).sum(0)
     gamma = 1 + 0.1 * torch.randn(C, generator=gen(1)); beta = 0.1 * torch.randn(C, generator=gen(2))
@@ -162,11 +162,11 @@ def test_bn_backward_chain(be, dt, mode, C):
     else:
         (z * mask[grp, None]).backward(uf)
     # kernels
-    stats = torch.zeros(SLOTS, 2, C)
+    stats = torch.zeros(SLOTS, 2, C, dtype=torch.float64)
     stats[0, 0] = y.float().sum(0); stats[0, 1] = (y.float() ** 2).sum(0)
     bn = bn_finalize(be, be.t(stats), M, be.t(gamma), be.t(beta), eps=eps)
     gs = cabi.gsrc(mode, be.t(u), be.t(gate), be.t(dpool), be.t(mask), rpg)
-    st2 = torch.zeros(SLOTS, 2, C, device=be.device)
+    st2 = torch.zeros(SLOTS, 2, C, device=be.device, dtype=torch.float64)     # backward sums: fp64 slots
     yd = be.t(y)
     be.call("bn_bwd_reduce", cabi.make("mds_bn_bwd_reduce_args", dtype=code, M=M, C=C, g=gs, y=yd, bn=bn, stats=st2))
     dgamma = torch.zeros(C, device=be.device); dbeta = torch.zeros(C, device=be.device)

@@ -56,7 +56,7 @@ def test_pw_fwd(be, dt, M, K, N, mode, res, stats):
     scale, shift, gate = _mk_pro(be, mode, K, groups, g)
     xd, wd, rd = be.t(x), be.t(w), be.t(r)
     y = torch.full((M, N), float("nan")).to(tdt).to(be.device)
-    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device)
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device, dtype=torch.float64)
     args = cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=xd, w=wd, y=y,
                      pro=cabi.pro(mode, scale, shift, gate, rpg),
                      residual=rd if res else None, stats=st if stats else None)
@@ -135,7 +135,7 @@ def test_pw_wgrad(be, dt, M, K, N, mode):
 def _bn_setup(be, y, gamma, beta, eps=1e-5):
     """forward statistics of a train-mode BN over raw input y -> the kernels' [4][C] buffer (scale, shift, mean, rstd)"""
     M, C = y.shape
-    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, C)
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, C, dtype=torch.float64)
     st[0, 0] = y.float().sum(0); st[0, 1] = (y.float() ** 2).sum(0)
     out = torch.empty(4, C, device=be.device)
     be.call("bn_finalize", cabi.make("mds_bn_finalize_args", C=C, count=M, stats=be.t(st), gamma=be.t(gamma), beta=be.t(beta), eps=eps,
@@ -148,7 +148,7 @@ def _bn_bwd_lin(be, g, y, bn, gamma):
     M, C = y.shape
     bnc = bn.cpu()
     xhat = (y.float() - bnc[2]) * bnc[3]
-    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, C)
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, C, dtype=torch.float64)          # backward sums: fp64 slots
     st[3, 0] = g.sum(0); st[5, 1] = (g * xhat).sum(0)
     coef = torch.empty(3, C, device=be.device); lin = torch.empty(3, C, device=be.device)
     be.call("bn_bwd_finalize", cabi.make("mds_bn_bwd_finalize_args", C=C, count=M, stats=be.t(st), gamma=be.t(gamma), bn=bn, dgamma=None,
@@ -193,7 +193,7 @@ def test_pw_fwd_bn_backward_fusion(be, dt, M, C, N, gmode, res, post):
     gamma2 = 1 + 0.2 * torch.randn(N, generator=g_); beta2 = 0.1 * torch.randn(N, generator=g_)
     mask2 = (torch.rand(groups, generator=g_) < 0.6).float() / 0.6
     bn2 = _bn_setup(be, ys, gamma2, beta2)
-    st2 = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device)
+    st2 = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device, dtype=torch.float64)
     kw = {}
     if post:
         kw["post"] = cabi.poststat(post, be.t(ys), bn2, st2, be.t(mask2), rpg)
@@ -311,7 +311,7 @@ def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken):
     w = (torch.randn(N, K, generator=g_) / K ** 0.5).to(tdt)
     r = torch.randn(M, N, generator=g_).to(tdt)
     out = torch.full((M, N), float("nan")).to(tdt).to(be.device)
-    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device)
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device, dtype=torch.float64)
     kw = {}
     if post:
         ys = (torch.randn(M, N, generator=g_) * 1.2 - 0.2).to(tdt)

@@ -47,7 +47,7 @@ def bench_dw(which):
         sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev) * 0.1
         mean = torch.randn(C, device=dev) * 0.1; rstd = torch.rand(C, device=dev) + 0.5
         y = torch.empty(N * T * OH * OW, C, device=dev, dtype=BF)
-        st = torch.zeros(SLOTS, 2, C, device=dev)
+        st = torch.zeros(SLOTS, 2, C, device=dev, dtype=torch.float64)
         pro = cabi.pro(2, sc, sh)
         nin, nout = x.numel(), y.numel()
         if which == "dw_fwd":
@@ -75,7 +75,7 @@ def bench_pw(which):
         sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
         rpg = M // 20
         gate = torch.rand(20, K, device=dev)
-        st = torch.zeros(SLOTS, 2, N, device=dev)
+        st = torch.zeros(SLOTS, 2, N, device=dev, dtype=torch.float64)
         pro = cabi.pro(mode, sc, sh, gate, rpg)
         if which == "pw_fwd":
             a = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=pro, residual=None,
@@ -103,7 +103,7 @@ def bench_conv(which):
         pro = cabi.pro(mode, sc, sh)
         flops = 2 * N * OH * OW * 9 * Cin * Cout
         if which == "conv_fwd":
-            y = torch.empty(N * OH * OW, Cout, device=dev, dtype=BF); st = torch.zeros(SLOTS, 2, Cout, device=dev)
+            y = torch.empty(N * OH * OW, Cout, device=dev, dtype=BF); st = torch.zeros(SLOTS, 2, Cout, device=dev, dtype=torch.float64)
             a = cabi.make("mds_conv_fwd_args", dtype=1, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout, A=OH, B=OW, oy0=0,
                           ox0=0, os=1, **{"is": s}, ntaps=9, dy=dy_, dx=dx_, wi=wi, wtaps=9, x=x, w=w, y=y, pro=pro,
                           residual=None, stats=st)
@@ -156,7 +156,7 @@ def bench_pw_as_conv():
         if mode not in (0, 2) or M % 16:
             continue
         x = rnd(M, K); w = rnd(N, K); y = torch.empty(M, N, device=dev, dtype=BF)
-        st = torch.zeros(SLOTS, 2, N, device=dev)
+        st = torch.zeros(SLOTS, 2, N, device=dev, dtype=torch.float64)
         sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
         a = cabi.make("mds_conv_fwd_args", dtype=1, N=1, IH=M // 16, IW=16, Cin=K, OH=M // 16, OW=16, Cout=N, A=M // 16, B=16, oy0=0,
                       ox0=0, os=1, **{"is": 1}, ntaps=1, dy=[0], dx=[0], wi=[0], wtaps=1, x=x, w=w, y=y, pro=cabi.pro(mode, sc, sh),
@@ -186,7 +186,7 @@ def bench_se1(G, R, C):
     pooled = torch.zeros(G, C, device=dev); act = torch.empty_like(y)
     c = cabi.make("mds_se_pool_args", dtype=1, groups=G, rows_per_group=R, C=C, y=y, scale=sc, shift=sh, pooled=pooled, act=act)
     timeit(f"se_pool (+act)          {G}x{R}x{C}", lambda: lib.call("se_pool", c, stream()), 2 * M * C * 2, 0)
-    st = torch.zeros(SLOTS, 2, C, device=dev); bn = torch.stack([sc, sh, mean, rstd]).contiguous()
+    st = torch.zeros(SLOTS, 2, C, device=dev, dtype=torch.float64); bn = torch.stack([sc, sh, mean, rstd]).contiguous()
     d = cabi.make("mds_bn_bwd_reduce_args", dtype=1, M=M, C=C, g=cabi.gsrc(1, u), y=y, bn=bn, stats=st)
     timeit(f"bn_bwd_reduce silu      {G}x{R}x{C}", lambda: lib.call("bn_bwd_reduce", d, stream()), 2 * M * C * 2, 0)
     coef = torch.rand(3, C, device=dev); dyo = torch.empty_like(y)
