@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
   }
 
   const long total_tiles = (long)a.N * tiles_ab;
-  long tl = (long)blockIdx.x * gq.tpb;
+  long tl = (long)xcd_contiguous(blockIdx.x, gridDim.x) * gq.tpb;      // consecutive tile rows (shared halo rows) on one XCD
   long tl_end = tl + gq.tpb;
   if (tl_end > total_tiles) tl_end = total_tiles;
   int xbase[MF];
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
   const float rcpp = 1.0f / (float)cpp, rTW = 1.0f / (float)TW;
   const int tiles_ab = tiles_a * tiles_b;
   const long total_tiles = (long)a.N * tiles_ab;
-  long tl = (long)blockIdx.x * tiles_per_block;
+  long tl = (long)xcd_contiguous(blockIdx.x, gridDim.x) * tiles_per_block;
   long tl_end = tl + tiles_per_block;
   if (tl_end > total_tiles) tl_end = total_tiles;
   if (PRO != MDS_PRO_NONE) {

@@ -273,8 +273,7 @@ MDS_DEV DwBlock dw_block(const DwStrips& g) {
   if (g.swap == 1) { b.bx = blockIdx.y; b.chunk = blockIdx.x; return b; }
   if (g.swap == 2) { b.bx = blockIdx.x; b.chunk = blockIdx.y; return b; }
   const unsigned nb = gridDim.x * gridDim.y, id = blockIdx.x + gridDim.x * blockIdx.y;
-  const unsigned q = nb >> 3, r = nb & 7, xcd = id & 7, slot = id >> 3;
-  const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;   // bijective for any nb
+  const unsigned logical = xcd_contiguous(id, nb);
   b.chunk = (int)(logical / gridDim.x);
   b.bx = (int)(logical - (unsigned)b.chunk * gridDim.x);
   return b;

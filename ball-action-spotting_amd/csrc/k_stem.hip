@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, DYP ? 2 : 3) void stem_wgrad_tiled_kernel(mds_
     noff[g] = n < 27 ? ((ky * 3 + pl) * 3 + kx) * SW_PITCH : -1;   // + (2 r) * 9 * SW_PITCH per output row r
   }
   const long total = (long)a.N * tiles_a * tiles_b;
-  long tl = (long)blockIdx.x * tiles_per_block, tl_end = tl + tiles_per_block;
+  long tl = (long)xcd_contiguous(blockIdx.x, gridDim.x) * tiles_per_block, tl_end = tl + tiles_per_block;
   if (tl_end > total) tl_end = total;
   f32x4 acc[2][2];
 #pragma unroll

@@ -260,6 +260,17 @@ MDS_DEV float wave_sum(float v) {
 }
 #endif
 
+// ------------------------------------------------------------------ XCD-aware work assignment
+// Workgroup id -> position in a kernel's work sequence.  The hardware hands consecutive workgroup ids to consecutive XCDs
+// (id % 8; 8 XCDs, each with its own 4 MiB L2 - MI355X_MICROARCH.md, a speed assumption only: any placement is correct).
+// Kernels whose neighbouring work items re-read the same rows (halos of the 3x3 / depthwise tiles, the tiles of one row
+// split of a weight gradient) give every XCD a CONTIGUOUS range of the sequence, so the shared rows come from that XCD's L2
+// instead of being fetched from HBM once per XCD.  Bijective for any n.
+MDS_DEV unsigned xcd_contiguous(unsigned id, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7, xcd = id & 7, slot = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 // ------------------------------------------------------------------ developer switches
 // MDS_*_OLD environment variables select the previous kernel generation of a family for A/B timing.
 // They are read ONCE per process (k_misc.hip), never on the launch path.
