@@ -39,9 +39,13 @@ template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 // count runs one all-zero phantom chunk instead of a branch.  Measured: the compiler still waits vmcnt(0) for the first set
 // (the second gets counted waits), the gated variant drops to two blocks per CU for registers, and the step is 1 % slower -
 // kept behind the knob with its tests as the starting point for a proper multi-stage K pipeline.
-template <typename T, int PRO, int WN, int BM, int TAIL, int DEEP = 0>
+// TWO: a second operand pair and a bias row (the LINEAR form of BatchNorm backward in a data gradient, mds_pw_fwd_args):
+//   y = x[M][K] w[:, 0:K]^T + x1[M][K1] w[:, Kp:Kp+K1]^T + bias,  Kp = K rounded up to 64 - the K loop simply runs over both
+// pairs, w rows hold both weight sets (zero padded), rows of x / x1 past their own K are staged as zeros.
+template <typename T, int PRO, int WN, int BM, int TAIL, int DEEP = 0, bool TWO = false>
 __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || TAIL == 1 || (DEEP && PRO == MDS_PRO_GATE) ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
   static_assert(!DEEP || ((PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && BM == 64 && WN == 2 && TAIL != 2), "DEEP variants");
+  static_assert(!TWO || (PRO == MDS_PRO_NONE && !DEEP && TAIL != 2), "two operand pairs: plain prologue, no output transform");
   constexpr bool POST = TAIL == 1, EPI = TAIL == 2;
   typedef typename Frag<T>::type frag_t;
   constexpr int KC = PwCfg<T>::KC, LD = PwCfg<T>::LD, VPR = KC / 8, RPP = 256 / VPR, NL = BM / RPP;
@@ -59,7 +63,10 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
   const int i = lane & 15, q = lane >> 4;
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const long m0 = (long)blockIdx.x * BM;
-  const int K = a.K, N = a.N;
+  const int N = a.N;
+  const int K0 = a.K, K0p = (K0 + 63) & ~63, K1 = TWO ? a.K1 : 0;
+  const int K = TWO ? K0p + ((K1 + 63) & ~63) : K0;       // length of the K loop = length of a packed weight row
+  const T* x1 = (const T*)a.x1;
   const T* x = (const T*)(PRO == PW_PRO_DY ? a.xdy.g.u : a.x);
   const T* w = (const T*)a.w;
   T* y = (T*)a.y;
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
   for (int l = 0; l < NL; ++l) {
     const long m = m0 + srow + RPP * l;
     xok[l] = m < a.M;
-    xrow[l] = x + (xok[l] ? m : 0) * K + 8 * svec;
+    xrow[l] = x + (xok[l] ? m : 0) * K0 + 8 * svec;
   }
   for (int n0 = blockIdx.y * BN; n0 < N; n0 += gridDim.y * BN) {
     int nfr = (N - n0 - 64 * wn) >> 4;  // valid 16-column fragments of this wave
@@ -96,7 +103,8 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
     // POST: the next BatchNorm's table entries and this lane's post.y fragments are requested HERE, ahead of the K loop
     // (they were three exposed memory round trips in the epilogue: the table, then one per fragment row)
     RawV4<T> rys[POST ? MFW : 1][4];
-    float pb[4] = {0.f, 0.f, 0.f, 0.f};
+    float pb[4] = {0.f, 0.f, 0.f, 0.f}, pbias = 0.f;
+    if (TWO && a.bias && tid < BN && n0 + tid < N) pbias = a.bias[n0 + tid];
     if (EPI && tid < BN && n0 + tid < N) { pb[0] = a.epi.scale[n0 + tid]; pb[1] = a.epi.shift[n0 + tid]; }   // same for the output transform's table
     if (POST) {
       if (tid < BN && n0 + tid < N) {
@@ -140,6 +148,22 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
         }
 #pragma unroll
         for (int l = 0; l < NLW; ++l) tw[l].ld(wrow[l] + ko);
+        return;
+      }
+      if (TWO) {   // which pair this chunk belongs to is uniform; the weight row is one contiguous [Kp | K1p] vector
+        const bool p1 = kc >= K0p;
+        const int kl = (p1 ? kc - K0p : kc) + 8 * svec;
+        const bool kin2 = kl < (p1 ? K1 : K0);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          const long m = m0 + srow + RPP * l;
+          const T* px = p1 ? x1 + (xok[l] ? m : 0) * K1 + kl : xrow[l] + kc;
+          if (xok[l] && kin2) tx[l].ld(px); else tx[l].zero();
+        }
+#pragma unroll
+        for (int l = 0; l < NLW; ++l) {
+          if (wok[l]) tw[l].ld(wrow[l] + kc); else tw[l].zero();
+        }
         return;
       }
 #pragma unroll
@@ -260,12 +284,15 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
     float ps[16], pss[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
-    float* pbn = (float*)smem;   // POST: [4][BN] scale, shift, mean, rstd of the tile's columns (over the finished x/w tiles)
-    if (POST) {
+    float* pbn = (float*)smem;   // POST: [4][BN] scale, shift, mean, rstd of the tile's columns (over the finished x/w tiles); TWO: [4][:] = bias
+    if (POST || TWO) {
       __syncthreads();           // every wave is done with the fragment reads of the last chunk
       if (tid < BN) {
+        if (POST) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pbn[k * BN + tid] = pb[k];
+          for (int k = 0; k < 4; ++k) pbn[k * BN + tid] = pb[k];
+        }
+        if (TWO) pbn[4 * BN + tid] = pbias;
       }
       __syncthreads();
     }
@@ -294,6 +321,14 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
             const float z = v[nf][r] * sc[r] + sh[r];
             v[nf][r] = a.epi.mode == MDS_EPI_BN_SILU ? siluf_(z) : z;
           }
+        }
+      }
+      if (TWO) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          const f32x4 bz = *(const f32x4*)(pbn + 4 * BN + 64 * wn + 16 * nf + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[nf][r] = ok ? v[nf][r] + bz[r] : 0.f;     // rows past M stay zero (statistics)
         }
       }
       if (a.residual && ok) {
@@ -403,7 +438,12 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
     MDS_REQUIRE(a->post.mode != MDS_POST_MASK || (a->post.mask && a->post.rows_per_group > 0), "pw_fwd: post mask");
     MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE && a->M < 4294967295L, "pw_fwd: post statistics are a data-gradient feature (no forward prologue)");
   }
-  { const int rc = pw_fwd_wres_try(a, stream); if (rc <= 0) return rc; }
+  const bool two = a->x1 != nullptr;
+  if (two) {
+    MDS_REQUIRE(a->K1 > 0 && a->K1 % 8 == 0 && a->x && !dy && !epi && a->pro.mode == MDS_PRO_NONE && !a->stats,
+                "pw_fwd: a second operand pair needs K1 %% 8 == 0, a plain first operand, no prologue, no output transform, no forward statistics");
+  }
+  if (!two) { const int rc = pw_fwd_wres_try(a, stream); if (rc <= 0) return rc; }
   // 128x64 tiles for the narrow projections (N <= 64: half of a 128-column tile would be padding;
   // 154 -> 119 us at 1.18 M x 128 -> 32); wider N measured 5-20 % slower with them despite 3 blocks/CU
   const int wn = a->N <= 64 ? 1 : 2;
@@ -429,7 +469,12 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
 #define PW_GODEEP(T, PRO, TAIL_) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
        MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_, 1>), grid, block, smem, stream, *a); } while (0)
-  const bool deep0 = wn == 2 && bm == 64 && !dy && !epi && (a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE) &&
+#define PW_GOTWO(T, TAIL_) \
+  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
+       if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, MDS_PRO_NONE, 2, 64, TAIL_, 0, true>), grid, block, smem, stream, *a); \
+       else if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, MDS_PRO_NONE, 2, 128, TAIL_, 0, true>), grid, block, smem, stream, *a); \
+       else MDS_LAUNCH((pw_fwd_kernel<T, MDS_PRO_NONE, 1, 128, TAIL_, 0, true>), grid, block, smem, stream, *a); } while (0)
+  const bool deep0 = !two && wn == 2 && bm == 64 && !dy && !epi && (a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE) &&
                      mds_knob(MDS_KNOB_PW_DEEP) == 1;   // opt-in: measured 4 % SLOWER inside the step (2.87 -> 3.00 ms of pw_fwd)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     if (deep0 && a->K >= 4 * PwCfg<T>::KC) {   // K-heavy layers: two K chunks in flight
@@ -437,6 +482,7 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
       else if (a->pro.mode == MDS_PRO_GATE) PW_GODEEP(T, MDS_PRO_GATE, 0);
       else PW_GODEEP(T, MDS_PRO_NONE, 0);
     }
+    else if (two) { if (post) PW_GOTWO(T, 1); else PW_GOTWO(T, 0); }
     else if (dy) { if (post) PW_GODY(T, 1); else PW_GODY(T, 0); }
     else if (post) PW_GO2(T, MDS_PRO_NONE, 1);
     else if (epi) { if (a->pro.mode == MDS_PRO_GATE) PW_GO2(T, MDS_PRO_GATE, 2); else if (a->pro.mode == MDS_PRO_BN_SILU) PW_GO2(T, MDS_PRO_BN_SILU, 2); else PW_GO2(T, MDS_PRO_NONE, 2); }
@@ -452,6 +498,7 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
 #undef PW_GO
 #undef PW_GO2
 #undef PW_GODY
+#undef PW_GOTWO
   return mds_check_launch("pw_fwd");
 }
 
@@ -635,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
-        if (n < N && k < K) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r]);
+        if (n < N && k < K) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r] * (a.nscale ? a.nscale[n] : 1.0f));
       }
     }
 }
@@ -846,7 +893,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
 #pragma unroll
           for (int g2 = 0; g2 < G; ++g2) t += red[(g2 * (NF * KF * 4) + (u * KF + v) * 4 + r) * 256 + tid];
           const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
-          if (n < N && k < K && !(dbg & 1)) atomicAdd(a.dw + (long)n * K + k, t);
+          if (n < N && k < K && !(dbg & 1)) atomicAdd(a.dw + (long)n * K + k, t * (a.nscale ? a.nscale[n] : 1.0f));
         }
       }
     return;
@@ -859,7 +906,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
-        if (n < N && k < K && !(dbg & 1)) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r]);
+        if (n < N && k < K && !(dbg & 1)) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r] * (a.nscale ? a.nscale[n] : 1.0f));
       }
     }
 }

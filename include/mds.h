@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 114
+#define MDS_VERSION 115
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -151,8 +151,41 @@ typedef struct {
                            (channels = K; `x` ignored, pro must be NONE)                         */
   mds_poststat_t post;  /* data-gradient use: BN-backward sums of the NEXT layer in the epilogue */
   mds_epi_t epi;        /* eval-mode output transform (no statistics, no post, no dy prologue with it) */
+  /* second operand pair + bias row - the LINEAR form of BatchNorm backward in a data gradient (mds_bn_lin_prep):
+   *   y[m][n] = sum_k x[m][k] w[n][k] + sum_j x1[m][j] w[n][Kp + j] + bias[n],   Kp = K rounded up to 64
+   * w is then [N][Kp + K1p] (K1p = K1 rounded up to 64, padding columns zero); plain prologue only            */
+  const void* x1;       /* optional [M][K1] */
+  int K1;
+  const float* bias;    /* optional [N] */
 } mds_pw_fwd_args;
 int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream);
+
+/* The linear form of BatchNorm backward (replaces mds_bn_bwd_apply for the BatchNorm behind a 1x1 expansion y = x W^T,
+ * W fp32 [Cmid][Cin], multidim_stacker.py:106 / timm conv_pw).  With dy = A*g + B*y + D (mds_bn_bwd_finalize `lin`):
+ *   dx = dy W = g (A.W) + y (B.W) + D W = g (A.W) + x (W^T diag(B) W) + D W     (no read of y, no dy tensor)
+ *   dW = dy^T x = A.(g^T x) + B.(W (x^T x)) + D (sum_m x)^T
+ * mds_bn_lin_prep packs the data-gradient operands: wcat [Cin][Kp + K1p] with row k = { A[n] W[n][k], n < Cmid | 0 |
+ * Q[j][k] = sum_n B[n] W[n][j] W[n][k], j < Cin | 0 } (Kp, K1p: Cmid, Cin rounded up to 64) and bias[k] = sum_n D[n] W[n][k];
+ * mds_bn_lin_wgrad adds the last two terms of dW from gram = x^T x [Cin][Cin] and colsum = sum_m x [Cin]
+ * (the first is mds_pw_wgrad with dy = g and nscale = A).                                                          */
+typedef struct {
+  int dtype;            /* storage type of wcat */
+  int Cmid, Cin;
+  const float* w;       /* [Cmid][Cin] */
+  const float* lin;     /* [3][Cmid] A, B, D */
+  void* wcat;           /* [Cin][Kp + K1p] */
+  float* bias;          /* [Cin] */
+} mds_bn_lin_prep_args;
+int mds_bn_lin_prep(const mds_bn_lin_prep_args* a, mds_stream_t stream);
+typedef struct {
+  int Cmid, Cin;
+  const float* w;       /* [Cmid][Cin] */
+  const float* lin;     /* [3][Cmid] */
+  const float* gram;    /* [Cin][Cin] x^T x (fp32, e.g. from mds_pw_wgrad with dy = x) */
+  const double* colsum; /* fp64 [SLOTS][2][Cin] statistic slots whose row 0 sums to sum_m x[m][:] */
+  float* dw;            /* [Cmid][Cin] += */
+} mds_bn_lin_wgrad_args;
+int mds_bn_lin_wgrad(const mds_bn_lin_wgrad_args* a, mds_stream_t stream);
 
 /* weight gradient of the 1x1 convolution: dw[N][K] += sum_m dy[m][n] * pro(x)[m][k] (fp32,
  * atomically accumulated into a caller-zeroed buffer laid out like the PyTorch parameter).     */
@@ -165,6 +198,7 @@ typedef struct {
   float* dw;      /* [N][K] fp32                                 */
   mds_pro_t pro;
   mds_dyp_t dyp;  /* dyp.mode == 1 -> the dy operand is formed on load (channels = N; `dy` ignored) */
+  const float* nscale;  /* optional [N]: row n of the accumulated tile is multiplied by nscale[n] before it is added to dw */
 } mds_pw_wgrad_args;
 int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream);
 

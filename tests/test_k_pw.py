@@ -342,3 +342,103 @@ def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken):
             s = st.sum(0).cpu()
             assert_close(s[0], v.sum(0), dt, scale=M ** 0.5, msg="sum")
             assert_close(s[1], (v * v).sum(0), dt, scale=M ** 0.5, msg="sumsq")
+
+
+# ------------------------------------------------------------------------------------------------ linear form of BatchNorm backward
+def _wcat(w0, w1):
+    """[N][K0] and [N][K1] -> the packed [N][Kp + K1p] weight rows of a two-pair mds_pw_fwd (zero padded to multiples of 64)"""
+    N, K0 = w0.shape
+    K1 = w1.shape[1]
+    Kp, K1p = (K0 + 63) // 64 * 64, (K1 + 63) // 64 * 64
+    out = torch.zeros(N, Kp + K1p, dtype=w0.dtype)
+    out[:, :K0] = w0
+    out[:, Kp:Kp + K1] = w1
+    return out
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K0,K1,N,res,post", [(300, 192, 48, 48, False, 0), (200, 672, 112, 112, True, 2), (130, 96, 24, 32, True, 0),
+                                                (260, 1152, 192, 192, False, 1), (400300, 64, 16, 16, False, 0)])
+def test_pw_fwd_two_operand_pairs_and_bias(be, dt, M, K0, K1, N, res, post):
+    """y = x w0^T + x1 w1^T + bias (+ residual) (+ the next BatchNorm's backward sums): the data gradient in its linear form"""
+    if M > 100000 and be.name == "emu":
+        pytest.skip("large-M tile path is exercised on the GPU")
+    code, tdt = DT[dt]
+    g_ = torch.Generator().manual_seed(M + K0 + N)
+    rpg = 50
+    groups = (M + rpg - 1) // rpg
+    x = torch.randn(M, K0, generator=g_).to(tdt)
+    x1 = torch.randn(M, K1, generator=g_).to(tdt)
+    w0 = (torch.randn(N, K0, generator=g_) / K0 ** 0.5).to(tdt)
+    w1 = (torch.randn(N, K1, generator=g_) / K1 ** 0.5).to(tdt)
+    bias = torch.randn(N, generator=g_)
+    r = torch.randn(M, N, generator=g_).to(tdt)
+    out = torch.full((M, N), float("nan")).to(tdt).to(be.device)
+    kw = {}
+    if post:
+        ys = (torch.randn(M, N, generator=g_) * 1.2 - 0.2).to(tdt)
+        gamma2 = 1 + 0.2 * torch.randn(N, generator=g_); beta2 = 0.1 * torch.randn(N, generator=g_)
+        mask2 = (torch.rand(groups, generator=g_) < 0.6).float() / 0.6
+        bn2 = _bn_setup(be, ys, gamma2, beta2)
+        st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device, dtype=torch.float64)
+        kw["post"] = cabi.poststat(post, be.t(ys), bn2, st, be.t(mask2), rpg)
+    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K0, N=N, x=be.t(x), w=be.t(_wcat(w0, w1)), y=out, pro=cabi.pro(0),
+                                residual=be.t(r) if res else None, stats=None, x1=be.t(x1), K1=K1, bias=be.t(bias), **kw))
+    be.sync()
+    v = x.float() @ w0.float().t() + x1.float() @ w1.float().t() + bias + (r.float() if res else 0.0)
+    assert_close(out, v, dt, msg="y")
+    if post:
+        b2 = bn2.cpu()
+        gq = v.to(tdt).float() if dt == "bf16" else v
+        if post == 2:
+            gq = gq * mask2[torch.arange(M) // rpg][:, None]
+        xhat = (ys.float() - b2[2]) * b2[3]
+        s = st.sum(0).cpu().float()
+        assert_close(s[0], gq.sum(0), dt, scale=M ** 0.5, msg="sum g")
+        assert_close(s[1], (gq * xhat).sum(0), dt, scale=M ** 0.5, msg="sum g xhat")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,Cin,Cmid", [(700, 48, 192), (333, 112, 672), (500, 192, 1152)])
+def test_bn_backward_linear_form_equals_the_materialised_dy(be, dt, M, Cin, Cmid):
+    """dx = dy W and dW = dy^T x for dy = A g + B y + D, y = x W^T (a train-mode BatchNorm behind a 1x1 expansion), computed
+    WITHOUT y and without a dy tensor: mds_bn_lin_prep + the two-pair mds_pw_fwd; mds_pw_wgrad(nscale = A) + the Gram matrix
+    (mds_pw_wgrad with dy = x) + column sums + mds_bn_lin_wgrad - against the direct evaluation in float64"""
+    code, tdt = DT[dt]
+    g_ = torch.Generator().manual_seed(M + Cin)
+    x = torch.randn(M, Cin, generator=g_).to(tdt)
+    W = torch.randn(Cmid, Cin, generator=g_) / Cin ** 0.5
+    g = torch.randn(M, Cmid, generator=g_).to(tdt)
+    lin = torch.stack([1 + 0.3 * torch.randn(Cmid, generator=g_), 0.2 * torch.randn(Cmid, generator=g_), 0.1 * torch.randn(Cmid, generator=g_)])
+    A, B, D = lin.double()
+    xd, Wd, gd = x.double(), W.double(), g.double()
+    y = xd @ Wd.t()
+    dy = A * gd + B * y + D
+    dx_ref, dW_ref = dy @ Wd, dy.t() @ xd
+    # ---- data gradient
+    Kp, K1p = (Cmid + 63) // 64 * 64, (Cin + 63) // 64 * 64
+    wcat = torch.full((Cin, Kp + K1p), float("nan")).to(tdt).to(be.device)
+    bias = torch.empty(Cin, device=be.device)
+    be.call("bn_lin_prep", cabi.make("mds_bn_lin_prep_args", dtype=code, Cmid=Cmid, Cin=Cin, w=be.t(W), lin=be.t(lin), wcat=wcat, bias=bias))
+    be.sync()
+    wc = wcat.float().cpu()
+    torch.testing.assert_close(wc[:, :Cmid], (A[:, None] * Wd).t().float(), rtol=1e-2 if dt == "bf16" else 1e-5, atol=1e-2 if dt == "bf16" else 1e-6)
+    Q = (Wd.t() * B) @ Wd
+    torch.testing.assert_close(wc[:, Kp:Kp + Cin], Q.t().float(), rtol=2e-2 if dt == "bf16" else 1e-4, atol=2e-2 if dt == "bf16" else 1e-5)
+    assert wc[:, Cmid:Kp].abs().sum() == 0 and wc[:, Kp + Cin:].abs().sum() == 0 and torch.isfinite(wc).all()
+    torch.testing.assert_close(bias.cpu(), (D @ Wd).float(), rtol=1e-4, atol=1e-4)
+    dx = torch.empty(M, Cin, device=be.device).to(tdt)
+    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=Cmid, N=Cin, x=be.t(g), w=wcat, y=dx, pro=cabi.pro(0), residual=None,
+                                stats=None, x1=be.t(x), K1=Cin, bias=bias))
+    be.sync()
+    assert_close(dx, dx_ref.float(), dt, scale=3.0, msg="dx")
+    # ---- weight gradient
+    dW = torch.zeros(Cmid, Cin, device=be.device)
+    gram = torch.zeros(Cin, Cin, device=be.device)
+    be.call("pw_wgrad", cabi.make("mds_pw_wgrad_args", dtype=code, M=M, K=Cin, N=Cmid, x=be.t(x), dy=be.t(g), dw=dW, pro=cabi.pro(0), nscale=be.t(lin[0].contiguous())))
+    be.call("pw_wgrad", cabi.make("mds_pw_wgrad_args", dtype=code, M=M, K=Cin, N=Cin, x=be.t(x), dy=be.t(x), dw=gram, pro=cabi.pro(0)))
+    cs = torch.zeros(cabi.MDS_STAT_SLOTS, 2, Cin, dtype=torch.float64)
+    cs[7, 0] = xd.sum(0)
+    be.call("bn_lin_wgrad", cabi.make("mds_bn_lin_wgrad_args", Cmid=Cmid, Cin=Cin, w=be.t(W), lin=be.t(lin), gram=gram, colsum=be.t(cs), dw=dW))
+    be.sync()
+    assert_close(dW, dW_ref.float(), dt, scale=M ** 0.5, msg="dW")
