@@ -475,13 +475,22 @@ __global__ __launch_bounds__(256) void bn_lin_prep_kernel(mds_bn_lin_prep_args a
   __syncthreads();
   for (int s_ = 128; s_ > 0; s_ >>= 1) { if (tid < s_) red[tid] += red[tid + s_]; __syncthreads(); }
   if (tid == 0) a.bias[k] = red[0];
-  // Q[j][k] = sum_n W[n][j] * (B[n] W[n][k]); thread = j (coalesced rows of W), K1p <= 192 <= 256 threads
-  if (tid < K1p) {
-    float q = 0.f;
-    if (tid < Cin)
-      for (int n = 0; n < Cmid; ++n) q += a.w[(long)n * Cin + tid] * wk[n];
-    Elem<T>::st(row + Kp + tid, q);
+  // Q[j][k] = sum_n W[n][j] * (B[n] W[n][k]): lane group tn (4 of them) takes the rows n = tn, tn + 4, ...; a thread holds up
+  // to four columns j = tj + 64 i (coalesced rows of W, four independent accumulators), then the four partial sums meet in LDS
+  __shared__ float part[4][256];
+  const int tj = tid & 63, tn = tid >> 6;
+  float q[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int n = tn; n < Cmid; n += 4) {
+    const float b = wk[n];
+    const float* wr = a.w + (long)n * Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (tj + 64 * i < Cin) q[i] += wr[tj + 64 * i] * b;
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) part[tn][tj + 64 * i] = q[i];
+  __syncthreads();
+  if (tid < K1p) Elem<T>::st(row + Kp + tid, tid < Cin ? (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]) : 0.f);
 }
 extern "C" int mds_bn_lin_prep(const mds_bn_lin_prep_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->w && a->lin && a->wcat && a->bias, "bn_lin_prep: null pointer");

@@ -214,6 +214,7 @@ class Plan:
         # vs 244 windows/s), kept with their tests.  0 = every reduce and apply is its own launch.
         self.fuse_mode = int(os.environ.get("MDS_FUSE_BN_BWD", "3"))
         self.fuse_bn_bwd = self.fuse_mode >= 1
+        self.bn1_lin = int(os.environ.get("MDS_BN1_LIN", "0"))      # 0 = off; else the smallest rows x channels the linear form is used for
         # inference plans (eval-mode BatchNorm, no gradient): producers store activated outputs (mds_epi_t)
         self.eval_epilogues = (not training) and (not need_grad) and os.environ.get("MDS_EVAL_EPI", "1") == "1"
         self.in_flight = False
@@ -540,6 +541,23 @@ class Plan:
                     pro=bn1.pro(), mean=bn1.mean, rstd=bn1.rstd, stats=bn1.bstats)
             if fuse and self.fuse_mode == 1:
                 dy1 = bn1.backward_fused(self, seg, gsrc(G_PLAIN, g1), y1, reduce=False, frozen=frozen)
+            elif self.bn1_lin and Min * mid >= self.bn1_lin:
+                # MDS_BN1_LIN=<min elements> (experiment): the data gradient in the LINEAR form of BatchNorm backward -
+                # dx = g1 (A.W) + x (W^T diag(B) W) + D W, no dy on the dependent chain; the apply pass and the weight gradient
+                # that needs its dy both move to the second stream
+                bn1.bwd_finalize(self, seg, frozen)
+                Kp, K1p = (mid + 63) // 64 * 64, (cin + 63) // 64 * 64
+                wcat, bias = self.act(cin, Kp + K1p), self.f32(cin)
+                self.op(seg, "bn_lin_prep", dtype=self.code, Cmid=mid, Cin=cin, w=P(blk.conv_pw.weight), lin=bn1.lin, wcat=wcat, bias=bias)
+                dx = self.act(Min, cin)
+                extra = {"post": nxt_head["bn"].post(nxt_head)} if nxt_head is not None else {}
+                self.op(seg, "pw_fwd", dtype=self.code, M=Min, K=mid, N=cin, x=g1, w=wcat, y=dx, pro=dict(mode=0),
+                        residual=dout.buf if has_skip else None, stats=None, x1=xin, K1=cin, bias=bias, **extra)
+                if not frozen:
+                    dy1 = self.act(Min, mid)
+                    self.op(seg, "bn_bwd_apply", dtype=self.code, M=Min, C=mid, g=gsrc(G_PLAIN, g1), y=y1, bn=bn1.buf, coef=bn1.coef, dy=dy1, _side=1)
+                    self.op(seg, "pw_wgrad", dtype=self.code, M=Min, K=cin, N=mid, x=xin, dy=dy1, dw=self.grad(blk.conv_pw.weight), pro=dict(mode=0))
+                return Grad(dx, nxt_head["bn"] if nxt_head is not None else None)
             else:
                 dy1 = self.act(Min, mid)
                 bn1.backward(self, seg, gsrc(G_PLAIN, g1), y1, dy1, reduce=False, frozen=frozen)
@@ -819,7 +837,7 @@ class Plan:
                 st = self._bind(kw.get("_struct", f"mds_{name}_args"), kw)
                 for _, field in self._input_fields:
                     self.input_slots.append((st, field))
-                out.append((name, self.lib.fn[name], st, C.byref(st)))
+                out.append((name if not kw.get("_side") else name + "@side", self.lib.fn[name], st, C.byref(st)))
             self.bound[seg] = out
             self.costs[seg] = [op_cost(name, kw, 2 if self.code == cabi.MDS_BF16 else 4) for name, kw in ops]
         self.nbytes = sum(l.tensor.numel() * l.tensor.element_size() for l in self._lazy)
@@ -827,7 +845,7 @@ class Plan:
     def _bind(self, struct_name, kw):
         vals = {}
         for k, v in kw.items():
-            if k == "_struct":
+            if k in ("_struct", "_side"):
                 continue
             if isinstance(v, dict):
                 v = self._bind(v.get("_struct", "mds_pro_t"), v)
@@ -874,7 +892,7 @@ class Plan:
             for k, (name, fn, st, ref) in enumerate(self.bound[seg]):
                 rc = fn(ref, stream)
                 if rc:
-                    self.lib.check(rc, name)
+                    self.lib.check(rc, name.split("@")[0])
                 if hook is not None and (seg, k + 1) in self.cuts:
                     hook(self, *self.cuts[(seg, k + 1)])
             return
@@ -885,7 +903,7 @@ class Plan:
         side_h = side.cuda_stream
         evs, n = self._side_events, 0
         for k, (name, fn, st, ref) in enumerate(self.bound[seg]):
-            if name in self.SIDE_OPS:
+            if name in self.SIDE_OPS or name.endswith("@side"):
                 if n == len(evs):
                     evs.append(torch.cuda.Event())
                 ev = evs[n]; n += 1
@@ -922,7 +940,7 @@ class Plan:
             e1.record()
             if rc:
                 self.lib.check(rc, name)
-            self.profile.append((name, seg, e0, e1, cost))
+            self.profile.append((name.split("@")[0], seg, e0, e1, cost))
 
     def read_taps(self):
         """[(tag, fp32 tensor [rows][C])] of every block output of the last forward (training plans materialise them; a tap
