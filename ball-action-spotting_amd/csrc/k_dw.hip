@@ -246,11 +246,7 @@ template <> struct Pair<float> {
 MDS_DEV f32x2 splat2(float v) { return (f32x2){v, v}; }
 MDS_DEV f32x2 sigmoid2(f32x2 z) {
   f32x2 t = z * splat2(-1.4426950408889634f);
-#ifndef MDS_EMU
-  f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + splat2(1.0f);
-#else
-  f32x2 d = (f32x2){exp2f(t[0]), exp2f(t[1])} + splat2(1.0f);
-#endif
+  f32x2 d = (f32x2){fast_exp2(t[0]), fast_exp2(t[1])} + splat2(1.0f);
   return (f32x2){fast_rcp(d[0]), fast_rcp(d[1])};
 }
 

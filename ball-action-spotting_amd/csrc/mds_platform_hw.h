@@ -1,0 +1,72 @@
+// mds_platform_hw.h - the gfx950 hardware touch-points of platform.h (included from there, after the vector typedefs).
+#pragma once
+// round-to-nearest-even in hardware
+MDS_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// two floats -> one dword of two bf16: exactly ONE v_cvt_pk_bf16_f32 (the scalar form followed by
+// shift/or costs three more VALU ops per pair — a quarter of the GEMM epilogues' instructions)
+MDS_DEV uint32_t pack2(float lo, float hi) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){lo, hi}, bf16x2_));
+}
+
+MDS_DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+MDS_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+MDS_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+MDS_DEV void mma16(const u16x8& a, const u16x8& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a),
+                                              __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+}
+#define MDS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define MDS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  /* wave-uniform value -> scalar register */
+#define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+// gfx950 has 160 KiB of LDS per CU; launches above the 64 KiB default opt in once per kernel.
+#define MDS_LAUNCH(kernel, grid, block, smem, stream, ...)                                          \
+  do {                                                                                              \
+    const size_t mds_smem_ = (size_t)(smem);                                                        \
+    if (mds_smem_ > 65536) { /* opt-in is idempotent; the high-water mark only avoids repeating it */ \
+      static std::atomic<size_t> mds_cur_{0};                                                       \
+      if (mds_smem_ > mds_cur_.load(std::memory_order_relaxed)) {                                   \
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mds_smem_); \
+        mds_cur_.store(mds_smem_, std::memory_order_relaxed);                                       \
+      }                                                                                             \
+    }                                                                                               \
+    hipLaunchKernelGGL(kernel, grid, block, mds_smem_, (hipStream_t)(stream), __VA_ARGS__);        \
+  } while (0)
+
+MDS_DEV u16x4 lds_tr4(const bf16_t* p) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(u16x4, v);
+}
+
+MDS_DEV void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+template <int CTRL, int BANK = 0xF>
+MDS_DEV float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xF, BANK, false));
+}
+template <int M> MDS_DEV float row_xor(float v);  // value of lane (i ^ M), M < 16
+template <> MDS_DEV float row_xor<1>(float v) { return dpp_f<0xB1>(v, v); }
+template <> MDS_DEV float row_xor<2>(float v) { return dpp_f<0x4E>(v, v); }
+template <> MDS_DEV float row_xor<4>(float v) { return dpp_f<0x114, 0xA>(dpp_f<0x104, 0x5>(v, v), v); }
+template <> MDS_DEV float row_xor<8>(float v) { return dpp_f<0x128>(v, v); }
+// sum over the 16 lanes that share q = lane >> 4 (i.e. over i = lane & 15); every lane gets it
+MDS_DEV float sum_over_i16(float v) {
+  v += dpp_f<0xB1>(v, v); v += dpp_f<0x4E>(v, v);
+  v += dpp_f<0x141>(v, v);  // row_half_mirror: pairs the two quads of each half row
+  v += dpp_f<0x140>(v, v);  // row_mirror: pairs the half rows
+  return v;
+}
+MDS_DEV float wave_sum(float v) {
+  v = sum_over_i16(v);
+  const int u = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48)));
+}

@@ -1,0 +1,4 @@
+// mds_platform_rt.h - runtime header of the product build (HIP).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <atomic>

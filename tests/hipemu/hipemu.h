@@ -3,7 +3,7 @@
 // A small host-side simulator of the HIP execution-model subset that csrc/*.hip uses, so that
 // the *same kernel sources* can be stepped through on a CPU-only CI box (index math, LDS tiling,
 // barrier placement, MFMA fragment bookkeeping).  It is force-included (-include) when building
-// libmds_emu.so with -DMDS_EMU and is never part of the product library (libmds_hip.so), which
+// libmds_emu.so (tests/hipemu first on its include path) and is never part of the product library (libmds_hip.so), which
 // is hipcc/gfx950 only.  Nothing here is a fallback: the Python product path cannot load it.
 //
 // Model: one OS thread; every HIP thread of a block is a fiber (own stack, hand-rolled context switch); blocks run one after
