@@ -935,8 +935,11 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   // INSIDE the training step these launches share the chip with the dependent chain, a 16-wave block with 128 KB of LDS owns
   // its CU, and the step measured 14.23 ms against 14.04 - so the default stays one group (MDS_KNOB_WG_GROUPS selects 2 / 4).
   int G = 1;
-  if (tr && !dyp && a->pro.mode != MDS_PRO_BN_SILU_GATE && (mds_knob(MDS_KNOB_WG_GROUPS) == 2 || mds_knob(MDS_KNOB_WG_GROUPS) == 4))
-    G = mds_knob(MDS_KNOB_WG_GROUPS);
+  {
+    const int kg = mds_knob(MDS_KNOB_WG_GROUPS);       // 2 / 4: every layer; 12 / 14: only the 18 400-row layers (stage 5, 3D tail)
+    const int g = kg % 10;
+    if (tr && !dyp && a->pro.mode != MDS_PRO_BN_SILU_GATE && (g == 2 || g == 4) && (kg < 10 || a->M <= 20000)) G = g;
+  }
   long want_blocks = (mds_knob(MDS_KNOB_WG_BLOCKS) > 0 ? mds_knob(MDS_KNOB_WG_BLOCKS) : (G > 1 ? 256 : 128)) / tiles;
   if (G == 1 && want_blocks < a->M / 2048) want_blocks = a->M / 2048;
   if (G > 1 && want_blocks < a->M / 16384) want_blocks = a->M / 16384;
