@@ -76,7 +76,8 @@ def test_pw_fwd(be, dt, M, K, N, mode, res, stats):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,K,N,pmode,emode,res", [(300, 48, 144, 0, 2, False), (200, 112, 32, 4, 1, True), (130, 192, 192, 0, 2, False)])
+@pytest.mark.parametrize("M,K,N,pmode,emode,res", [(300, 48, 144, 0, 2, False), (200, 112, 32, 4, 1, True), (130, 192, 192, 0, 2, False),
+                                                   (150, 704, 192, 4, 1, True), (140, 320, 128, 0, 2, False)])   # K-heavy inference shapes (the predictor's one-image plans)
 def test_pw_fwd_output_transform(be, dt, M, K, N, pmode, emode, res):
     """mds_epi_t: y = act(acc*scale + shift) (+ residual) - the inference plans' producers store activated outputs"""
     code, tdt = DT[dt]
