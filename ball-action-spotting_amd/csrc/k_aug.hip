@@ -30,9 +30,17 @@ MDS_DEV void normal4(uint32_t seed, unsigned long long quad, float (&z)[4]) {
   z[2] = rb * cosf(6.28318530718f * u3); z[3] = rb * sinf(6.28318530718f * u3);
 }
 
-// zeros outside - branch-free (clamped address, masked value): a conditional load would serialise the four corners of a
-// bilinear sample and the four pixels of a lane behind each other's memory latency
-MDS_DEV float px(const float* plane, int H, int W, int x, int y) {
+// One block = one output tile of AUG_TR rows x AUG_TC columns of one frame; one thread = 4 consecutive pixels (one 16-byte store).
+// WARP / SHARP / TAPS first stage the SOURCE box the tile needs (the affine image of the tile, or the tile plus its halo) in
+// LDS with coalesced row reads - zeros outside the frame, which is exactly the padding all three stages use - and gather
+// from there: a direct gather costs 4...48 scalar global loads per pixel (1.1-1.7 TB/s for a rotation, 0.45 TB/s for the
+// motion blur, measured), the staged form one 16-byte load per 4 source pixels.  A source box that does not fit (a map far
+// from the identity) falls back to direct gathers.
+#define AUG_TR 8
+#define AUG_TC 128
+#define AUG_LDS_FLOATS 7168      // 28 KiB: e.g. 40 rows x 176 columns
+
+MDS_DEV float px(const float* plane, int H, int W, int x, int y) {   // zeros outside, branch-free (clamped address, masked value)
   const bool in = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
   const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x), yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
   const float v = plane[(long)yc * W + xc];
@@ -40,102 +48,155 @@ MDS_DEV float px(const float* plane, int H, int W, int x, int y) {
 }
 
 __global__ __launch_bounds__(256) void aug_kernel(mds_aug_args a) {
+  __shared__ float tile[AUG_LDS_FLOATS];
   const int b = blockIdx.z, t = blockIdx.y;
   const mds_aug_job& jb = a.jobs[b];
   if (!jb.active) return;
-  const int H = a.H, W = a.W, W4 = (W + 3) >> 2;
+  const int H = a.H, W = a.W, tiles_x = (W + AUG_TC - 1) / AUG_TC;
+  const int ty0 = (int)(blockIdx.x / tiles_x) * AUG_TR, tx0 = (int)(blockIdx.x % tiles_x) * AUG_TC;
   const long plane_off = ((long)b * a.T + t) * H * W;
   const float* src = a.buf[jb.src] + plane_off;
   float* dst = a.buf[jb.dst] + plane_off;
-  const int mode = jb.mode;
-  float m[6];
+  const int mode = jb.mode, tid = threadIdx.x;
+  const int y = ty0 + (tid >> 5), x0 = tx0 + 4 * (tid & 31);
+  float m[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+  // ---- the source box of this tile: [bx0, bx0 + bw) x [by0, by0 + bh)
+  int bx0 = tx0, by0 = ty0, bw = 0, bh = 0;
   if (mode == MDS_AUG_WARP) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) m[j] = a.maps[((long)b * a.T + t) * 6 + j];
+    const float xa = (float)tx0, xb = (float)(tx0 + AUG_TC - 1 < W - 1 ? tx0 + AUG_TC - 1 : W - 1);
+    const float ya = (float)ty0, yb = (float)(ty0 + AUG_TR - 1 < H - 1 ? ty0 + AUG_TR - 1 : H - 1);
+    float sxl = 1e30f, sxh = -1e30f, syl = 1e30f, syh = -1e30f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float cx = (c & 1) ? xb : xa, cy = (c & 2) ? yb : ya;
+      const float sx = m[0] * cx + m[1] * cy + m[2], sy = m[3] * cx + m[4] * cy + m[5];
+      sxl = fminf(sxl, sx); sxh = fmaxf(sxh, sx); syl = fminf(syl, sy); syh = fmaxf(syh, sy);
+    }
+    // clamp to a band around the frame (everything beyond contributes zeros anyway) so the int conversions stay defined
+    sxl = fmaxf(sxl, -2.0f); syl = fmaxf(syl, -2.0f); sxh = fminf(sxh, (float)W + 1.0f); syh = fminf(syh, (float)H + 1.0f);
+    bx0 = ((int)floorf(sxl)) & ~3; by0 = (int)floorf(syl);
+    bw = (int)floorf(sxh) + 2 - bx0; bh = (int)floorf(syh) + 2 - by0;
+  } else if (mode == MDS_AUG_SHARP) {
+    bx0 = tx0 - 4; by0 = ty0 - 1; bw = AUG_TC + 8; bh = AUG_TR + 2;
+  } else if (mode == MDS_AUG_TAPS) {
+    bx0 = tx0 - 8; by0 = ty0 - 5; bw = AUG_TC + 16; bh = AUG_TR + 10;      // motion kernel: |dx|, |dy| <= 5 (11 x 11)
   }
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < (long)H * W4; q += (long)gridDim.x * 256) {
-    const int y = (int)(q / W4), x0 = 4 * (int)(q - (long)y * W4);
-    float v[4];
+  bw = (bw + 3) & ~3;
+  bool staged = mode != MDS_AUG_COPY && bw > 0 && bh > 0 && (long)bw * bh <= AUG_LDS_FLOATS;
+  if (mode == MDS_AUG_TAPS) {      // taps beyond the staged halo (a larger kernel than 11 x 11): direct gathers
+    for (int k = 0; k < jb.ntaps; ++k) staged = staged && jb.tap_dx[k] >= -8 && jb.tap_dx[k] <= 8 && jb.tap_dy[k] >= -5 && jb.tap_dy[k] <= 5;
+  }
+  __shared__ float tapw[MDS_AUG_MAX_TAPS];
+  __shared__ int tapo[MDS_AUG_MAX_TAPS];
+  const int ntaps = mode == MDS_AUG_TAPS ? jb.ntaps : 0;
+  if (staged && tid < ntaps) { tapw[tid] = jb.tap_w[tid]; tapo[tid] = jb.tap_dy[tid] * bw + jb.tap_dx[tid]; }   // (read once, not per pixel and tap)
+  if (staged) {
+    const int nq = (bw >> 2) * bh;
+    const bool vec = (W & 3) == 0;           // rows start 16-byte aligned and bx0 is a multiple of 4
+    for (int e = tid; e < nq; e += 256) {
+      const int r = e / (bw >> 2), c4 = (e - r * (bw >> 2)) << 2;
+      const int gy = by0 + r, gx = bx0 + c4;
+      f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)gy < (unsigned)H) {
+        if (vec && gx >= 0 && gx + 3 < W) v4 = *(const f32x4*)(src + (long)gy * W + gx);
+        else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int x = x0 + j;
-      float r = 0.0f;
-      if (x < W) {
-        if (mode == MDS_AUG_COPY) {
-          r = src[(long)y * W + x];
-        } else if (mode == MDS_AUG_WARP) {
-          // torch grid_sample(bilinear, zeros, align_corners=True): pixel coordinates, each corner weighted if inside
-          const float sx = m[0] * (float)x + m[1] * (float)y + m[2], sy = m[3] * (float)x + m[4] * (float)y + m[5];
-          const float fx = floorf(sx), fy = floorf(sy);
-          const int ix = (int)fx, iy = (int)fy;
-          const float wx1 = sx - fx, wy1 = sy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-          // (far outside the frame every corner is masked; the clamp below only keeps float -> int conversions defined)
-          const bool near = sx > -2.0f && sx < (float)W + 1.0f && sy > -2.0f && sy < (float)H + 1.0f;
-          const int jx = near ? ix : -2, jy = near ? iy : -2;
-          r = px(src, H, W, jx, jy) * (wx0 * wy0) + px(src, H, W, jx + 1, jy) * (wx1 * wy0) +
-              px(src, H, W, jx, jy + 1) * (wx0 * wy1) + px(src, H, W, jx + 1, jy + 1) * (wx1 * wy1);
-        } else if (mode == MDS_AUG_SHARP) {
-          const float c = src[(long)y * W + x];
-          if (x >= 1 && x < W - 1 && y >= 1 && y < H - 1) {
-            const float* p = src + (long)y * W + x;
-            float s = p[-W - 1] + p[-W] + p[-W + 1] + p[-1] + 5.0f * c + p[1] + p[W - 1] + p[W] + p[W + 1];
-            s = fminf(fmaxf(s * (1.0f / 13.0f), 0.0f), 1.0f);
-            r = s + (c - s) * jb.sharp_factor;         // factor in (0, 1): no clamp (kornia _blend_one)
-          } else {
-            r = c;                                     // border pixels keep their value
-          }
-        } else {   // MDS_AUG_TAPS
-          for (int k = 0; k < jb.ntaps; ++k) r += jb.tap_w[k] * px(src, H, W, x + jb.tap_dx[k], y + jb.tap_dy[k]);
+          for (int j = 0; j < 4; ++j) v4[j] = (unsigned)(gx + j) < (unsigned)W ? src[(long)gy * W + gx + j] : 0.f;
         }
       }
-      v[j] = r;
+      *(f32x4*)(tile + r * bw + c4) = v4;
     }
-    if (jb.point) {
-      if (jb.bright_on) {
+    __syncthreads();
+  }
+  if (y >= H || x0 >= W) return;
+  auto tap = [&](int gx, int gy) -> float {    // source pixel (gx, gy), zeros outside the frame
+    if (staged) {
+      const int lx = gx - bx0, ly = gy - by0;
+      return ((unsigned)lx < (unsigned)bw && (unsigned)ly < (unsigned)bh) ? tile[ly * bw + lx] : 0.f;
+    }
+    return px(src, H, W, gx, gy);
+  };
+  float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j] + jb.bright_add, 0.0f), 1.0f);
-      }
-      if (jb.contrast_on) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j] * jb.contrast_mul, 0.0f), 1.0f);
-      }
-      if (jb.posterize_bits > 0) {
-        const int sh = 8 - jb.posterize_bits;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned u = (unsigned)(unsigned char)(int)(v[j] * 255.0f);     // torch .to(uint8): truncation
-          v[j] = (float)((u >> sh) << sh) / 255.0f;
-        }
-      }
-      if (jb.noise_on) {
-        float z[4];
-        if (a.noise) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) z[j] = (x0 + j < W) ? a.noise[plane_off + (long)y * W + x0 + j] : 0.0f;
+  for (int j = 0; j < 4; ++j) {
+    const int x = x0 + j;
+    float r = 0.0f;
+    if (x < W) {
+      if (mode == MDS_AUG_COPY) {
+        r = src[(long)y * W + x];
+      } else if (mode == MDS_AUG_WARP) {
+        // torch grid_sample(bilinear, zeros, align_corners=True): pixel coordinates, each corner weighted if inside
+        const float sx = m[0] * (float)x + m[1] * (float)y + m[2], sy = m[3] * (float)x + m[4] * (float)y + m[5];
+        const float fx = floorf(sx), fy = floorf(sy);
+        const float wx1 = sx - fx, wy1 = sy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        // (far outside the frame every corner is masked; the select only keeps the float -> int conversions defined)
+        const bool near = sx > -2.0f && sx < (float)W + 1.0f && sy > -2.0f && sy < (float)H + 1.0f;
+        const int jx = near ? (int)fx : -2, jy = near ? (int)fy : -2;
+        r = tap(jx, jy) * (wx0 * wy0) + tap(jx + 1, jy) * (wx1 * wy0) + tap(jx, jy + 1) * (wx0 * wy1) + tap(jx + 1, jy + 1) * (wx1 * wy1);
+      } else if (mode == MDS_AUG_SHARP) {
+        const float c = tap(x, y);
+        if (x >= 1 && x < W - 1 && y >= 1 && y < H - 1) {
+          float s_ = tap(x - 1, y - 1) + tap(x, y - 1) + tap(x + 1, y - 1) + tap(x - 1, y) + 5.0f * c + tap(x + 1, y) +
+                     tap(x - 1, y + 1) + tap(x, y + 1) + tap(x + 1, y + 1);
+          s_ = fminf(fmaxf(s_ * (1.0f / 13.0f), 0.0f), 1.0f);
+          r = s_ + (c - s_) * jb.sharp_factor;         // factor in (0, 1): no clamp (kornia _blend_one)
         } else {
-          normal4((uint32_t)jb.noise_seed, (unsigned long long)(((long)b * a.T + t) * (long)H * W4 + q), z);
+          r = c;                                       // border pixels keep their value
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] + z[j] * jb.noise_std + jb.noise_mean;
+      } else if (staged) {   // MDS_AUG_TAPS from the staged box: every tap of every pixel of the tile lies inside it (checked above)
+        const float* c0 = tile + (y - by0) * bw + (x - bx0);
+        for (int k = 0; k < ntaps; ++k) r += tapw[k] * c0[tapo[k]];
+      } else {
+        for (int k = 0; k < jb.ntaps; ++k) r += jb.tap_w[k] * px(src, H, W, x + jb.tap_dx[k], y + jb.tap_dy[k]);
       }
     }
-    float* o = dst + (long)y * W + x0;
-    if (x0 + 3 < W && ((W & 3) == 0)) {
-      *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
-    } else {
+    v[j] = r;
+  }
+  if (jb.point) {
+    if (jb.bright_on) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (x0 + j < W) o[j] = v[j];
+      for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j] + jb.bright_add, 0.0f), 1.0f);
     }
+    if (jb.contrast_on) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j] * jb.contrast_mul, 0.0f), 1.0f);
+    }
+    if (jb.posterize_bits > 0) {
+      const int sh = 8 - jb.posterize_bits;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned u = (unsigned)(unsigned char)(int)(v[j] * 255.0f);     // torch .to(uint8): truncation
+        v[j] = (float)((u >> sh) << sh) / 255.0f;
+      }
+    }
+    if (jb.noise_on) {
+      float z[4];
+      if (a.noise) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = (x0 + j < W) ? a.noise[plane_off + (long)y * W + x0 + j] : 0.0f;
+      } else {     // counter = this quad's index in the (B, T, H, ceil(W / 4)) order: a function of (seed, element) only
+        normal4((uint32_t)jb.noise_seed, (unsigned long long)((((long)b * a.T + t) * H + y) * (long)((W + 3) >> 2) + (x0 >> 2)), z);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] + z[j] * jb.noise_std + jb.noise_mean;
+    }
+  }
+  float* o = dst + (long)y * W + x0;
+  if (x0 + 3 < W && ((W & 3) == 0)) {
+    *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (x0 + j < W) o[j] = v[j];
   }
 }
 
 extern "C" int mds_aug_pass(const mds_aug_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && a->jobs && a->buf[0] && a->buf[1], "aug_pass: bad args");
   MDS_REQUIRE((long)a->H * a->W < 2147483647L, "aug_pass: frame too large");
-  const long quads = (long)a->H * ((a->W + 3) / 4);
-  int bx = cdiv(quads, 256 * 4);          // four quads per thread
-  if (bx < 1) bx = 1;
+  const int bx = cdiv(a->H, AUG_TR) * cdiv(a->W, AUG_TC);      // one block per 8 x 128 output tile
   MDS_REQUIRE(a->T <= 65535 && a->B <= 65535, "aug_pass: grid");
   MDS_LAUNCH(aug_kernel, dim3(bx, a->T, a->B), dim3(256), 0, stream, *a);
   return mds_check_launch("aug_pass");

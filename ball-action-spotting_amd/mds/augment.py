@@ -52,18 +52,17 @@ def motion_kernel(ksize: int, angle: float, direction: float) -> np.ndarray:
     """kornia get_motion_kernel2d(mode='nearest'): a horizontal line with weights going linearly from d to 1 - d
     (d = (direction + 1) / 2), rotated by `angle` about the kernel centre with nearest sampling, normalised to sum 1"""
     d = (min(max(direction, -1.0), 1.0) + 1.0) / 2.0
-    line = np.array([d + ((1 - 2 * d) / (ksize - 1)) * i for i in range(ksize)], dtype=np.float32)
+    line = (d + ((1 - 2 * d) / (ksize - 1)) * np.arange(ksize)).astype(np.float32)
     base = np.zeros((ksize, ksize), dtype=np.float32)
     base[ksize // 2] = line
     c = (ksize - 1) / 2.0
     inv = np.linalg.inv(_rotation_matrix(c, c, angle))
-    out = np.zeros_like(base)
-    for y in range(ksize):
-        for x in range(ksize):
-            sx, sy = inv[0, 0] * x + inv[0, 1] * y + inv[0, 2], inv[1, 0] * x + inv[1, 1] * y + inv[1, 2]
-            ix, iy = int(np.rint(np.float32(sx))), int(np.rint(np.float32(sy)))     # grid_sample 'nearest' rounds half to even
-            if 0 <= ix < ksize and 0 <= iy < ksize:
-                out[y, x] = base[iy, ix]
+    ys, xs = np.mgrid[0:ksize, 0:ksize]
+    sx = (inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]).astype(np.float32)
+    sy = (inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]).astype(np.float32)
+    ix, iy = np.rint(sx).astype(np.int64), np.rint(sy).astype(np.int64)      # grid_sample 'nearest' rounds half to even
+    ok = (ix >= 0) & (ix < ksize) & (iy >= 0) & (iy < ksize)
+    out = np.where(ok, base[np.clip(iy, 0, ksize - 1), np.clip(ix, 0, ksize - 1)], 0.0).astype(np.float32)
     return out / out.sum()
 
 
@@ -148,9 +147,10 @@ class TrainAugmentations(nn.Module):
             sc = np.asarray(p["scale"], dtype=np.float64); an = np.asarray(p["angle"], dtype=np.float64)
             tx, ty = lin(tr[0, 0], tr[1, 0]), lin(tr[0, 1], tr[1, 1])
             cx, cy = lin(ce[0, 0], ce[1, 0]), lin(ce[0, 1], ce[1, 1])
-            ss, aa = lin(sc[0, 0], sc[1, 0]), lin(an[0], an[1])
-            for f in range(t):
-                fwd[f] = _affine_matrix(tx[f], ty[f], cx[f], cy[f], ss[f], aa[f])
+            ss, aa = lin(sc[0, 0], sc[1, 0]), np.radians(-lin(an[0], an[1]))        # get_affine_matrix2d rotates by -angle
+            al, be = ss * np.cos(aa), ss * np.sin(aa)
+            fwd[:, 0, 0], fwd[:, 0, 1], fwd[:, 0, 2] = al, be, (1 - al) * cx - be * cy + tx
+            fwd[:, 1, 0], fwd[:, 1, 1], fwd[:, 1, 2] = -be, al, be * cx + (1 - al) * cy + ty
         if "rotation" in s:
             fwd = _rotation_matrix((w - 1) / 2.0, (h - 1) / 2.0, float(s["rotation"])) @ fwd
         if "crop" in s:
@@ -224,32 +224,40 @@ class TrainAugmentations(nn.Module):
             raise cabi.MdsError("mds.augment runs on MI355X only: move the batch to cuda")
         return cabi.load()
 
+    def prepare(self, params: List[dict], t: int, h: int, w: int, device) -> dict:
+        """host side of one batch: job tables + maps in ONE device upload (parameters -> what the launches need)"""
+        passes, used, maps, need_scratch = self._jobs(params, t, h, w)
+        b = len(params)
+        raw = b"".join(bytes(p) for p, u_ in zip(passes, used) if u_) + maps.tobytes()
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device, non_blocking=True)
+        return dict(table=table, used=used, nused=sum(used), need_scratch=need_scratch, shape=(b, t, h, w), jsz=C.sizeof(cabi.STRUCTS["mds_aug_job"]) * b)
+
     @torch.no_grad()
-    def forward(self, x: torch.Tensor, params: Optional[List[dict]] = None, noise: Optional[torch.Tensor] = None):
+    def forward(self, x: torch.Tensor, params: Optional[List[dict]] = None, noise: Optional[torch.Tensor] = None, prepared: Optional[dict] = None):
         """x: (B, T, H, W) float32 in [0, 1].  `params` (a list of per-sample dicts as `sample_params` returns) and `noise`
-        (standard-normal draws, (B, T, H, W)) are injection points for parity tests; normally both are drawn here."""
+        (standard-normal draws, (B, T, H, W)) are injection points for parity tests; normally both are drawn here.
+        `prepared` = the result of `prepare()` for this shape (bench: the launches alone)."""
         assert x.dim() == 4 and x.dtype == torch.float32, "augmentations take the (B, T, H, W) float32 frame batch"
         x = x.contiguous()
         b, t, h, w = x.shape
         lib = self._library(x)
-        if params is None:
-            params = self.sample_params(b, t, h, w)
-        passes, used, maps, need_scratch = self._jobs(params, t, h, w)
         dev = x.device
+        if prepared is None:
+            if params is None:
+                params = self.sample_params(b, t, h, w)
+            prepared = self.prepare(params, t, h, w, dev)
+            self.last_params = params
+        assert prepared["shape"] == (b, t, h, w)
+        table, used, jsz = prepared["table"], prepared["used"], prepared["jsz"]
         out = torch.empty_like(x)
         bufs = [x.data_ptr(), out.data_ptr(), 0, 0]
-        keep = [x, out]
-        for k in range(need_scratch):
+        for k in range(prepared["need_scratch"]):
             key = (k, x.shape, dev)
             if key not in self._scratch:
                 self._scratch = {kk: v for kk, v in self._scratch.items() if kk[1:] == (x.shape, dev)}
                 self._scratch[key] = torch.empty_like(x)
             bufs[2 + k] = self._scratch[key].data_ptr()
-        raw = b"".join(bytes(p) for p, u_ in zip(passes, used) if u_) + maps.tobytes()
-        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev, non_blocking=True)     # ONE host -> device copy per batch
-        jsz = C.sizeof(cabi.STRUCTS["mds_aug_job"]) * b
-        nused = sum(used)
-        maps_ptr = table.data_ptr() + nused * jsz
+        maps_ptr = table.data_ptr() + prepared["nused"] * jsz
         stream = torch.cuda.current_stream(dev).cuda_stream if x.is_cuda else 0
         if noise is not None:
             noise = noise.to(device=dev, dtype=torch.float32).contiguous()
@@ -261,8 +269,7 @@ class TrainAugmentations(nn.Module):
                 args = cabi.make("mds_aug_args", B=b, T=t, H=h, W=w, buf=bufs, jobs=table.data_ptr() + k * jsz, maps=maps_ptr, noise=noise)
                 lib.check(lib.fn["aug_pass"](C.byref(args), stream), "aug_pass")
                 k += 1
-        self._last = (table, keep, noise)      # the launches are asynchronous: their operands outlive this call
-        self.last_params = params
+        self._last = (table, x, out, noise)      # the launches are asynchronous: their operands outlive this call
         return out
 
 

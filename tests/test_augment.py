@@ -175,3 +175,31 @@ def test_augmentations_at_the_training_shape():
     s = mod(x[:1], params=[sh])
     assert torch.equal(s[0, 0, 4:, 8:], x[0, 0, :-4, :-8]) and torch.equal(s[0, -1, 4:, 8:], x[0, -1, :-4, :-8])
     assert (s[0, :, 4:, 8:] - x[0, :, :-4, :-8]).abs().max().item() < 1e-3 and s[0, :, :4].abs().max().item() < 1e-4
+
+
+def test_ragged_sizes_and_the_long_window(be):
+    """width not a multiple of 4 (scalar store tail), a single-frame window, and config 4's 33 frames: fused passes vs the oracle"""
+    g = torch.Generator().manual_seed(13)
+    for (b, t, h, w) in [(2, 1, 13, 19), (1, 33, 10, 22), (3, 2, 9, 5)]:
+        x = torch.rand(b, t, h, w, generator=g)
+        noise = torch.randn(b, t, h, w, generator=g)
+        ps = [dict(rotation=2.0, flip=True, sharpness=0.5, brightness=0.9, noise=dict(std=0.05, mean=0.0, seed=1)),
+              dict(motion_blur=dict(ksize=11, angle=-3.0, direction=0.2), contrast=1.1, posterize=6),
+              dict(crop=(1, 1, w - 2, h - 2))][:b]
+        mod = augment.TrainAugmentations((w, h))
+        mod._lib = be.lib if be.name == "emu" else None
+        out = mod(be.t(x), params=ps, noise=be.t(noise)).cpu()
+        be.sync()
+        ref = aug.apply_single_resampling(x, [_oracle_params(s) for s in ps], noise)
+        d = (out - ref).abs()
+        # (posterize may flip a level at isolated pixels where the fp32 operation order differs by an ulp)
+        assert (d > 1e-4).float().mean().item() < 5e-3 and d.max().item() <= 4 / 255 + 1e-6, ((b, t, h, w), d.max().item())
+
+
+def test_inputs_are_validated(be):
+    mod = augment.TrainAugmentations((8, 8))
+    mod._lib = be.lib if be.name == "emu" else None
+    with pytest.raises(AssertionError):
+        mod(be.t(torch.rand(2, 8, 8)))                      # not (B, T, H, W)
+    with pytest.raises(AssertionError):
+        mod(be.t(torch.rand(1, 1, 8, 8)).double())          # not float32

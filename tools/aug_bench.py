@@ -15,10 +15,15 @@ def t_ms(fn, reps=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
 cases = {"copy (nothing fires)": [{}] * 4, "flip": [dict(flip=True)] * 4, "rotation": [dict(rotation=2.0)] * 4,
          "crop+flip+rot+camera": [dict(rotation=2.0, flip=True, crop=(10, 5, 1240, 700), camera=dict(angle=[1, -1], translations=[[5, 3], [-8, 2]], center=[[639.5, 367.5]] * 2, scale=[[1.0, 1.0], [1.02, 1.02]]))] * 4,
+         "rot+flip": [dict(rotation=2.0, flip=True)] * 4, "rot+crop": [dict(rotation=2.0, crop=(10, 5, 1240, 700))] * 4,
+         "camera": [dict(camera=dict(angle=[1, -1], translations=[[5, 3], [-8, 2]], center=[[639.5, 367.5]] * 2, scale=[[1.0, 1.0], [1.02, 1.02]]))] * 4,
+         "crop": [dict(crop=(10, 5, 1240, 700))] * 4,
          "sharpness": [dict(sharpness=0.4)] * 4, "motion blur": [dict(motion_blur=dict(ksize=11, angle=5.0, direction=0.3))] * 4,
          "all point ops + noise": [dict(brightness=1.1, contrast=0.9, posterize=4, noise=dict(std=0.05, mean=0.0, seed=3))] * 4}
 for k, p in cases.items():
-    ms = t_ms(lambda: mod(x, params=p))
-    print(f"{k:28s} {ms:7.3f} ms   {2 * nb / ms / 1e6:7.1f} GB/s (read + write once)")
+    prep = mod.prepare(p, 15, 736, 1280, dev)
+    ms = t_ms(lambda: mod(x, prepared=prep))
+    host = t_ms(lambda: mod.prepare(p, 15, 736, 1280, dev), reps=5)
+    print(f"{k:28s} {ms:7.3f} ms   {2 * nb / ms / 1e6:7.1f} GB/s (read + write once; launches alone)   host tables {host:6.3f} ms")
 ms = t_ms(lambda: mod(x), reps=50)
 print(f"{'sampled (reference p)':28s} {ms:7.3f} ms per batch incl. host sampling + table upload")
