@@ -277,9 +277,9 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
   const int npix = gq.TH * TW, cpp = Cin >> 3, nitems = npix * cpp;
   T* xs = (T*)smem;                        // [npix][LDX]
   T* ws = xs + npix * LDX;                 // [BNQ][LDW]
-  float* st_s = (float*)(ws + BNQ * LDW);  // [BNQ]
-  float* st_ss = st_s + BNQ;
-  float* psc = st_ss + BNQ;                // [Cin] prologue scale / shift
+  double* st_s = (double*)(ws + BNQ * LDW);  // [BNQ] block-level statistic sums: fp64, so the order the four waves add in does not matter
+  double* st_ss = st_s + BNQ;
+  float* psc = (float*)(st_ss + BNQ);       // [Cin] prologue scale / shift
   float* psh = psc + Cin;
   float* pes = psh + Cin;                  // [BNQ] output-transform scale / shift (mds_epi_t)
   float* peh = pes + BNQ;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
     }
     r.st(ws + n * LDW + k);
   }
-  if (tid < BNQ) { st_s[tid] = 0.f; st_ss[tid] = 0.f; }
+  if (tid < BNQ) { st_s[tid] = 0.0; st_ss[tid] = 0.0; }
   if (HASPRO) {
     for (int c = tid; c < Cin; c += 256) { psc[c] = a.pro.scale[c]; psh[c] = a.pro.shift[c]; }
   }
@@ -463,14 +463,14 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
     reduce_scatter16(q16, i);
     const int nl = 16 * (e >> 2) + 4 * q + (e & 3);
     if (nl < BNQ) {
-      atomicAdd(&st_s[nl], p16[0]);
-      atomicAdd(&st_ss[nl], q16[0]);
+      atomicAdd(&st_s[nl], (double)p16[0]);
+      atomicAdd(&st_ss[nl], (double)q16[0]);
     }
     __syncthreads();
     if (tid < BNQ && n0 + tid < Cout) {
       double* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * Cout;
-      atomicAdd(st + n0 + tid, (double)st_s[tid]);
-      atomicAdd(st + Cout + n0 + tid, (double)st_ss[tid]);
+      atomicAdd(st + n0 + tid, st_s[tid]);
+      atomicAdd(st + Cout + n0 + tid, st_ss[tid]);
     }
   }
 }
@@ -524,7 +524,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
           if (!nf || !mf) continue;
           const int th = (4 * mf - 1) * a->is + eh + 1, tw = (CV_TB - 1) * a->is + ew + 1;
           const size_t sm = ((size_t)th * tw * cvp_pitch_h(a->Cin, esz) + (size_t)16 * nf * cvp_pitch_h(KS * 32, esz)) * esz +
-                            4 * 16 * nf * sizeof(float) + 2 * (size_t)a->Cin * sizeof(float) + (size_t)KS * 16;
+                            6 * 16 * nf * sizeof(float) + 2 * (size_t)a->Cin * sizeof(float) + (size_t)KS * 16;
           if (th * tw * (a->Cin / 8) <= CVQ_MAXX * 256 && sm <= (lim ? 160 : 76) * 1024) { MFs = mf; NFRs = nf; THq = th; TWq = tw; smem = sm; }
         }
       }

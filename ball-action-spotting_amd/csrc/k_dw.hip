@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(mds_dw_fwd_args a, int nchu
   MDS_DYN_SMEM(smem);
   T* tile = (T*)smem;                             // [KT][NPIX][CC]
   float* wl = (float*)(tile + KT * NPIX * CC);    // [NTAP][CC]
-  float* st_l = wl + NTAP * CC;                   // [2][CC]
+  double* st_l = (double*)(wl + NTAP * CC);        // [2][CC] fp64: the waves' order of arrival does not matter
   const int tid = threadIdx.x, ch = tid % NCH, pt = tid / NCH;
   const int C = a.C;
   const int cz = blockIdx.z % nchunks, n = blockIdx.z / nchunks;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(mds_dw_fwd_args a, int nchu
     const int t = e / CC, c = e - t * CC;
     wl[e] = (cbeg + c < C) ? a.w[(long)(cbeg + c) * NTAP + t] : 0.f;
   }
-  if (tid < 2 * CC) st_l[tid] = 0.f;
+  if (tid < 2 * CC) st_l[tid] = 0.0;
   const int mode = a.pro.mode;
   float sc[V], sh[V];
   if (cvalid && mode != MDS_PRO_NONE) { ldv<V>(a.pro.scale + c0, sc); ldv<V>(a.pro.shift + c0, sh); }
@@ -205,14 +205,14 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(mds_dw_fwd_args a, int nchu
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         float s = sum_same_chunk<NCH>(st[k][j]);
-        if ((tid & 63) < NCH) atomicAdd(&st_l[k * CC + ch * V + j], s);
+        if ((tid & 63) < NCH) atomicAdd(&st_l[k * CC + ch * V + j], (double)s);
       }
     __syncthreads();
     if (tid < 2 * CC) {
       const int k = tid / CC, c = tid - k * CC;
       if (cbeg + c < C) {
         const int slot = (blockIdx.x + blockIdx.y * gridDim.x + n * 5) % MDS_STAT_SLOTS;
-        atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, (double)st_l[tid]);
+        atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, st_l[tid]);
       }
     }
   }
@@ -1085,7 +1085,7 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
     const int tiles_x = cdiv(a->OW, 16), tpb = 1;  // forward: parallelism beats amortisation
     dim3 grid(cdiv(tiles_x, tpb), cdiv(a->OH, 8), a->N * nchunks), block(256);
     const int S = a->stride, TH = 7 * S + 3, TW = 15 * S + 3;
-    const size_t smem = (size_t)a->kt * TH * TW * CC * sizeof(T) + ((size_t)a->kt * 9 * CC + 2 * CC) * sizeof(float);
+    const size_t smem = (size_t)a->kt * TH * TW * CC * sizeof(T) + ((size_t)a->kt * 9 * CC + 4 * CC) * sizeof(float);
     if (a->kt == 3) MDS_LAUNCH((dw_fwd_kernel<T, 1, 3>), grid, block, smem, stream, *a, nchunks, tpb);
     else if (S == 1) MDS_LAUNCH((dw_fwd_kernel<T, 1, 1>), grid, block, smem, stream, *a, nchunks, tpb);
     else MDS_LAUNCH((dw_fwd_kernel<T, 2, 1>), grid, block, smem, stream, *a, nchunks, tpb);
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(mds_dw_bwd_args a, int nchu
   T* dyt = (T*)smem;                             // [KT][DNPIX][CC]
   float* wl = (float*)(dyt + KT * DNPIX * CC);   // [NTAP][CC]
   float* dwl = wl + NTAP * CC;                   // [CC][NTAP]
-  float* st_l = dwl + NTAP * CC;                 // [2][CC]
+  double* st_l = (double*)(dwl + NTAP * CC);      // [2][CC] fp64
   const int tid = threadIdx.x, ch = tid % NCH, pt = tid / NCH;
   const int C = a.C;
   const int cz = blockIdx.z % nchunks, n = blockIdx.z / nchunks;
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(mds_dw_bwd_args a, int nchu
     wl[e] = (cbeg + c < C) ? a.w[(long)(cbeg + c) * NTAP + t] : 0.f;
     dwl[e] = 0.f;
   }
-  if (tid < 2 * CC) st_l[tid] = 0.f;
+  if (tid < 2 * CC) st_l[tid] = 0.0;
   float sc[V], sh[V], mu[V], rs[V];
   if (cvalid) {
     ldv<V>(a.pro.scale + c0, sc); ldv<V>(a.pro.shift + c0, sh);
@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(mds_dw_bwd_args a, int nchu
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float s = sum_same_chunk<NCH>(st[k][j]);
-      if ((tid & 63) < NCH) atomicAdd(&st_l[k * CC + ch * V + j], s);
+      if ((tid & 63) < NCH) atomicAdd(&st_l[k * CC + ch * V + j], (double)s);
     }
   __syncthreads();
   for (int e = tid; e < NTAP * CC; e += 256) {
@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(mds_dw_bwd_args a, int nchu
     const int k = tid / CC, c = tid - k * CC;
     if (cbeg + c < C) {
       const int slot = (blockIdx.x + blockIdx.y * gridDim.x + n * 5) % MDS_STAT_SLOTS;
-      atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, (double)st_l[tid]);
+      atomicAdd(a.stats + ((long)slot * 2 + k) * C + cbeg + c, st_l[tid]);
     }
   }
 }
@@ -1348,7 +1348,7 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
     int tpb = a->kt == 3 ? 2 : (tiles_x < 8 ? tiles_x : 8);
     dim3 grid(cdiv(tiles_x, tpb), cdiv(a->IH, 8), a->N * nchunks), block(256);
     const int dnpix = a->stride == 1 ? 10 * 18 : 6 * 10;
-    const size_t smem = (size_t)a->kt * dnpix * CC * sizeof(T) + ((size_t)2 * a->kt * 9 * CC + 2 * CC) * sizeof(float);
+    const size_t smem = (size_t)a->kt * dnpix * CC * sizeof(T) + ((size_t)2 * a->kt * 9 * CC + 4 * CC) * sizeof(float);
     if (a->kt == 3) MDS_LAUNCH((dw_bwd_kernel<T, 1, 1, 3>), grid, block, smem, stream, *a, nchunks, tpb);
     else if (a->stride == 1) MDS_LAUNCH((dw_bwd_kernel<T, 1, 1, 1>), grid, block, smem, stream, *a, nchunks, tpb);
     else if (a->pad_l == 0) MDS_LAUNCH((dw_bwd_kernel<T, 2, 0, 1>), grid, block, smem, stream, *a, nchunks, tpb);

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
   if (m.valid && m.rsub == 0) {
     const float inv = 1.0f / (float)a.rows_per_group;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(a.pooled + (long)blockIdx.y * a.C + c0 + j, acc[0][j] * inv);
+    for (int j = 0; j < 8; ++j) atomicAdd(a.pooled + (long)blockIdx.y * a.C + c0 + j, (double)(acc[0][j] * inv));
   }
 }
 // blocks per group of a reduce kernel: every block ends with O(C) atomics / partial stores, so it
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 3) void se_bwd_reduce_kernel(mds_se_bwd_reduce
   block_reduce_rows<1>(acc, m, red);
   if (m.valid && m.rsub == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(a.dgate + (long)blockIdx.y * a.C + c0 + j, acc[0][j]);
+    for (int j = 0; j < 8; ++j) atomicAdd(a.dgate + (long)blockIdx.y * a.C + c0 + j, (double)acc[0][j]);
   }
   if (fuse_bn) {
 #pragma unroll
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void gem_fwd_kernel(mds_gem_fwd_args a) {
 // row-split variant: grid (groups, splits); partial sums by atomics into the zeroed accumulator
 template <typename T, int BWD>
 __global__ __launch_bounds__(256) void gem_partial_kernel(int groups, long rows_per_group, int C, const void* yv, mds_pro_t pro,
-                                                          const float* pp, float eps, float* accum) {
+                                                          const float* pp, float eps, double* accum) {
   __shared__ float red[256 * 8];
   const RowMap m = rowmap(C);
   const int c0 = m.chunk * 8;
@@ -344,12 +344,12 @@ __global__ __launch_bounds__(256) void gem_partial_kernel(int groups, long rows_
   block_reduce_rows<1>(acc, m, red);
   if (m.valid && m.rsub == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(accum + (long)blockIdx.x * C + c0 + j, acc[0][j]);
+    for (int j = 0; j < 8; ++j) atomicAdd(accum + (long)blockIdx.x * C + c0 + j, (double)acc[0][j]);
   }
 }
-__global__ void gem_finish_kernel(int n, float rows, const float* pp, const float* accum, float* pooled) {
+__global__ void gem_finish_kernel(int n, float rows, const float* pp, const double* accum, float* pooled) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) pooled[e] = expf(logf(accum[e] / rows) / pp[0]);
+  if (e < n) pooled[e] = expf(logf((float)(accum[e] / rows)) / pp[0]);
 }
 static inline int gem_splits(int groups, long rows, int C) {
   long per = (rows + rows_per_pass(C) - 1) / rows_per_pass(C);   // block passes per group

@@ -218,14 +218,14 @@ extern "C" int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream
 // (c = tid, tid + 256, ...) with R accumulators, so the R*C/256 loads of a thread are independent
 // and coalesced; then wave shuffles + one LDS hop.  (R dots done one after another by a wave cost
 // 40 us of dependent latency.)
-template <int RB>  // RB = R rounded up to 16: no per-r branches, so the loads stay back-to-back
-MDS_DEV void se_matvec_rc(const float* w, const float* v, int R, int C, float (&part)[4][SE_RMAX], float* out) {
+template <int RB, typename V>  // RB = R rounded up to 16: no per-r branches, so the loads stay back-to-back; V: float or double vector
+MDS_DEV void se_matvec_rc(const float* w, const V* v, int R, int C, float (&part)[4][SE_RMAX], float* out) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float acc[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) acc[r] = 0.f;
   for (int c = tid; c < C; c += 256) {
-    const float vc = v[c];
+    const float vc = (float)v[c];
     float wv[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) wv[r] = w[(long)(r < R ? r : R - 1) * C + c];  // rows past R: a legal dummy

@@ -457,7 +457,7 @@ class Plan:
         self.op(fseg, "dw_fwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
                 pad_l=pl, kt=kt, x=a1, w=P(blk.conv_dw.weight), y=a2, pro=dict(mode=0), stats=None, epi=epi(bn2, EPI_BN_SILU))
         R = blk.se.rd
-        pooled, hidden, gate = self.zero_fwd(groups * mid), self.f32(groups * R), self.f32(groups * mid)
+        pooled, hidden, gate = self.zero_fwd64(groups * mid), self.f32(groups * R), self.f32(groups * mid)
         self.op(fseg, "se_pool", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, y=a2, scale=None, shift=None,
                 pooled=pooled, act=None)
         se = blk.se
@@ -489,7 +489,7 @@ class Plan:
                 pad_l=pl, kt=kt, x=y1, w=wdw, y=y2, pro=bn1.pro(), stats=bn2.stats)
         bn2.finalize(self, fseg)
         R = blk.se.rd
-        pooled, hidden, gate = self.zero_fwd(groups * mid), self.f32(groups * R), self.f32(groups * mid)
+        pooled, hidden, gate = self.zero_fwd64(groups * mid), self.f32(groups * R), self.f32(groups * mid)
         a2 = self.act(Mout, mid)   # silu(bn2(y2)), written by the pooling pass it shares its reads with
         self.op(fseg, "se_pool", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, y=y2, scale=bn2.scale,
                 shift=bn2.shift, pooled=pooled, act=a2)
@@ -517,7 +517,7 @@ class Plan:
                 dy3 = self.act(Mout, cout)
                 bn3.backward(self, seg, g3, y3, dy3, reduce=dout.reduced is not bn3, frozen=frozen)
             u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen).buf
-            dgate, dpool = self.zero_bwd(groups * mid), self.f32(groups * mid)
+            dgate, dpool = self.zero_bwd64(groups * mid), self.f32(groups * mid)
             nblk = self.lib.fn["se_bwd_reduce_blocks"](rpg, mid)
             bnsums = self.f32(groups * nblk * 4 * mid)
             self.op(seg, "se_bwd_reduce", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, u=u2, y=y2,
@@ -770,7 +770,7 @@ class Plan:
         gp = m.global_pool
         pooled = self.f32(B * F_)
         self.op("fhead", "gem_fwd", dtype=self.code, groups=B * S, rows_per_group=h * w, C=cq, y=yq, pro=pro, p=P(gp.p),
-                eps=float(gp.eps), pooled=pooled, accum=self.zero_fwd(B * S * cq))
+                eps=float(gp.eps), pooled=pooled, accum=self.zero_fwd64(B * S * cq))
         dmask = self.mask(B * F_, m.drop_rate) if m.drop_rate > 0 else None
         ncls = m.classifier.out_features
         self.logits = self.f32(B * ncls)
@@ -784,7 +784,7 @@ class Plan:
                     dlogits=self.dlogits, dpooled=dpo, dw=self.grad(m.classifier.weight), db=self.grad(m.classifier.bias))
             uq = self.act(B * S * h * w, cq)
             self.op(seg, "gem_bwd", dtype=self.code, groups=B * S, rows_per_group=h * w, C=cq, y=yq, pro=pro, p=P(gp.p),
-                    eps=float(gp.eps), pooled=pooled, dpooled=dpo, u=uq, dp=self.grad(gp.p), accum=self.zero_bwd(B * S * cq))
+                    eps=float(gp.eps), pooled=pooled, dpooled=dpo, u=uq, dp=self.grad(gp.p), accum=self.zero_bwd64(B * S * cq))
             return Grad(uq)
 
         bwd.lo = self._lo(gp, m.classifier)

@@ -22,6 +22,9 @@
  *    variance (E[y^2] - mean^2) and above all the backward sums (sum g cancels to ~1e-3 of its absolute mass on the
  *    residual stream) lose up to 1e-3 when thousands of partials are accumulated by fp32 atomics in a
  *    run-dependent order (round 2); in fp64 the cross-block accumulation is exact to 1e-16 and order-independent.
+ *    The same holds for the other cross-block sums that feed activations or their gradients - the squeeze-excite pool
+ *    (`pooled`), its backward (`dgate`) and the row-split GeM accumulators: all fp64.  What is left to fp32 atomics
+ *    are the parameter-gradient accumulations (weight-gradient arena, GeM's dp), which feed nothing else in the step.
  */
 #ifndef MDS_H
 #define MDS_H
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 115
+#define MDS_VERSION 116
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -387,7 +390,7 @@ typedef struct {
   const void* y;
   const float* scale;   /* NULL (with shift): y already IS the activation (producer with an mds_epi_t) */
   const float* shift;
-  float* pooled;  /* [groups][C], caller-zeroed (atomic accumulation of sums/rows) */
+  double* pooled; /* fp64 [groups][C], caller-zeroed (atomic accumulation of sums/rows; fp64: order-independent) */
   void* act;      /* optional [rows][C]: the activation silu(bn(y)) is also written out, so that the
                      three later consumers (gated 1x1 conv, its weight gradient, the SE backward
                      reduction) do not redo the exp/rcp work (they are VALU-bound otherwise) */
@@ -397,7 +400,7 @@ int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream);
 /* gate = sigmoid(W2 * silu(W1 * pooled + b1) + b2)   (:83-86).  hidden pre-activations are kept. */
 typedef struct {
   int groups, C, R;
-  const float* pooled;  /* [groups][C] */
+  const double* pooled; /* fp64 [groups][C] (mds_se_pool) */
   const float* w1;      /* [R][C] */
   const float* b1;      /* [R]    */
   const float* w2;      /* [C][R] */
@@ -419,7 +422,7 @@ typedef struct {
   const void* y;      /* raw conv output, or the materialised activation when scale == NULL */
   const float* scale;
   const float* shift;
-  float* dgate; /* [groups][C] caller-zeroed */
+  double* dgate; /* fp64 [groups][C] caller-zeroed */
   /* optional fusion of the following BatchNorm-backward reduction (needs raw y + scale/shift):
    * with s' = silu'(z), xh = (y-mean)*rstd, per (group, channel) partial sums
    *   bnsums[g][blk][0..3][c] = sum u*s', sum u*s'*xh, sum s', sum s'*xh   over block blk's rows
@@ -438,10 +441,10 @@ int mds_se_bwd_reduce(const mds_se_bwd_reduce_args* a, mds_stream_t stream);
 typedef struct {
   int groups, C, R;
   long rows_per_group;
-  const float* dgate;
+  const double* dgate;  /* fp64 (mds_se_bwd_reduce) */
   const float* gate;
   const float* hidden;
-  const float* pooled;
+  const double* pooled; /* fp64 (mds_se_pool) */
   const float* w1;
   const float* w2;
   float* dpooled; /* [groups][C] */
@@ -518,7 +521,7 @@ typedef struct {
   const float* p;       /* [1] learnable exponent */
   float eps;
   float* pooled;        /* [groups][C] == [b][t*C + c] */
-  float* accum;         /* optional caller-zeroed [groups][C]: the rows of a group are then split over
+  double* accum;        /* optional caller-zeroed fp64 [groups][C]: the rows of a group are then split over
                            several blocks (sum of clamp(a)^p by atomics + a finishing launch); without
                            it one block walks a whole group                                         */
 } mds_gem_fwd_args;
@@ -538,7 +541,7 @@ typedef struct {
   const float* dpooled; /* [groups][C] */
   void* u;              /* [rows][C] */
   float* dp;            /* [1] += */
-  float* accum;         /* optional caller-zeroed [groups][C] (sum of c^p log c), as in mds_gem_fwd    */
+  double* accum;        /* optional caller-zeroed fp64 [groups][C] (sum of c^p log c), as in mds_gem_fwd */
 } mds_gem_bwd_args;
 int mds_gem_bwd(const mds_gem_bwd_args* a, mds_stream_t stream);
 

@@ -39,12 +39,12 @@ def test_gem_reference_vectors(be, golden):
     p = be.t(torch.tensor([3.0]))
     for split in (False, True):
         pooled = torch.empty(B, C, device=be.device)
-        acc = torch.zeros(B, C, device=be.device) if split else None
+        acc = torch.zeros(B, C, device=be.device, dtype=torch.float64) if split else None
         be.call("gem_fwd", cabi.make("mds_gem_fwd_args", dtype=0, groups=B, rows_per_group=H * W, C=C, y=rows,
                                      pro=cabi.pro(0), p=p, eps=1e-6, pooled=pooled, accum=acc))
         u = torch.empty_like(rows)
         dp = torch.zeros(1, device=be.device)
-        acc2 = torch.zeros(B, C, device=be.device) if split else None
+        acc2 = torch.zeros(B, C, device=be.device, dtype=torch.float64) if split else None
         be.call("gem_bwd", cabi.make("mds_gem_bwd_args", dtype=0, groups=B, rows_per_group=H * W, C=C, y=rows,
                                      pro=cabi.pro(0), p=p, eps=1e-6, pooled=pooled, dpooled=be.t(T(d["g"])), u=u, dp=dp,
                                      accum=acc2))
@@ -65,14 +65,14 @@ def test_se3d_reference_vectors(be, golden):
     gr = be.t(g.permute(0, 2, 3, 4, 1).reshape(B * rpg, C))
     w1 = be.t(se.conv_reduce.weight.detach().reshape(R, C)); b1 = be.t(se.conv_reduce.bias.detach())
     w2 = be.t(se.conv_expand.weight.detach().reshape(C, R)); b2 = be.t(se.conv_expand.bias.detach())
-    pooled = xr.view(B, rpg, C).mean(1).contiguous()       # x is the block's activation: its mean IS se_pool's output
+    pooled = xr.view(B, rpg, C).mean(1).double().contiguous()       # x is the block's activation: its mean IS se_pool's output (fp64 buffer)
     hidden = torch.empty(B, R, device=be.device); gate = torch.empty(B, C, device=be.device)
     be.call("se_fc_fwd", cabi.make("mds_se_fc_fwd_args", groups=B, C=C, R=R, pooled=pooled, w1=w1, b1=b1, w2=w2, b2=b2,
                                    hidden=hidden, gate=gate, w2t=None))
     be.sync()
     y = xr.view(B, rpg, C) * gate[:, None, :]
     close(y.reshape(B, *x.shape[2:], C).permute(0, 4, 1, 2, 3), d["y"], msg="se y")
-    dgate = torch.zeros(B, C, device=be.device)
+    dgate = torch.zeros(B, C, device=be.device, dtype=torch.float64)
     be.call("se_bwd_reduce", cabi.make("mds_se_bwd_reduce_args", dtype=0, groups=B, rows_per_group=rpg, C=C, u=gr, y=xr,
                                        scale=None, shift=None, dgate=dgate, mean=None, rstd=None, bnsums=None))
     dpooled = torch.empty(B, C, device=be.device)

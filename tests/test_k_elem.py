@@ -97,7 +97,7 @@ def test_se_forward_backward(be, dt, packed, C, RD):
     (out * u.float().view(G, R_, C)).sum().backward()
     # kernels
     yd = be.t(y); ud = be.t(u); scd = be.t(scale); shd = be.t(shift)
-    pooled = torch.zeros(G, C, device=be.device)
+    pooled = torch.zeros(G, C, device=be.device, dtype=torch.float64)      # cross-block sums that feed activations: fp64
     be.call("se_pool", cabi.make("mds_se_pool_args", dtype=code, groups=G, rows_per_group=R_, C=C, y=yd,
                                  scale=scd, shift=shd, pooled=pooled))
     hidden = torch.empty(G, RD, device=be.device); gate = torch.empty(G, C, device=be.device)
@@ -112,7 +112,7 @@ def test_se_forward_backward(be, dt, packed, C, RD):
         assert torch.equal(w2t.cpu(), w2.t().contiguous())
     be.call("se_fc_fwd", cabi.make("mds_se_fc_fwd_args", groups=G, C=C, R=RD, pooled=pooled, w1=w1d, b1=b1d,
                                    w2=w2d, b2=b2d, hidden=hidden, gate=gate, w2t=w2t))
-    dgate = torch.zeros(G, C, device=be.device)
+    dgate = torch.zeros(G, C, device=be.device, dtype=torch.float64)
     be.call("se_bwd_reduce", cabi.make("mds_se_bwd_reduce_args", dtype=code, groups=G, rows_per_group=R_, C=C,
                                        u=ud, y=yd, scale=scd, shift=shd, dgate=dgate))
     dpooled = torch.empty(G, C, device=be.device)
@@ -199,8 +199,8 @@ def test_gem_fwd_bwd(be, dt, pro_mode, split, R_, C, golden):
     yd = be.t(y)
     pro = cabi.pro(pro_mode, be.t(scale), be.t(shift))
     pooled = torch.empty(G, C, device=be.device); pd = be.t(p)
-    acc1 = torch.zeros(G, C, device=be.device) if split else None
-    acc2 = torch.zeros(G, C, device=be.device) if split else None
+    acc1 = torch.zeros(G, C, device=be.device, dtype=torch.float64) if split else None
+    acc2 = torch.zeros(G, C, device=be.device, dtype=torch.float64) if split else None
     be.call("gem_fwd", cabi.make("mds_gem_fwd_args", dtype=code, groups=G, rows_per_group=R_, C=C, y=yd, pro=pro,
                                  p=pd, eps=1e-6, pooled=pooled, accum=acc1))
     u = torch.empty(G * R_, C, dtype=tdt, device=be.device); dp = torch.zeros(1, device=be.device)

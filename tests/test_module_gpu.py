@@ -255,3 +255,34 @@ def test_fp16_autocast_with_gradscaler():
     # (measured over builds and boxes: cosine 0.98-0.99, norm ratio within 2-6 %)
     assert cos > 0.95 and abs(a.norm().item() / b.norm().item() - 1) < 0.12, (cos, a.norm().item(), b.norm().item())
     assert relerr(grads["classifier.weight"], g_plain["classifier.weight"]) < 0.3     # measured 0.15 between two bf16 runs
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_run_to_run_reproducibility(amp):
+    """Every cross-block sum that feeds an activation or its gradient (BatchNorm statistics forward and backward, the
+    squeeze-excite pool and its backward, GeM) is accumulated in fp64: two runs of the same step give BIT-IDENTICAL logits,
+    running statistics and gradients of every BatchNorm / squeeze-excite / GeM / bias parameter, whatever order the blocks
+    arrive in.  The convolution and Linear WEIGHT gradients are still fp32 atomics into the gradient arena (they feed nothing
+    else): equal up to summation order."""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    _, prod = build_pair(kw, seed=9)
+    prod.train()
+    x = torch.rand(2, 15, 256, 320, device=DEV, generator=torch.Generator(DEV).manual_seed(4))
+    tgt = torch.tensor([[1.0, 0.0], [0.0, 1.0]], device=DEV)
+    state = {k: v.clone() for k, v in prod.state_dict().items()}
+
+    def run():
+        prod.load_state_dict(state)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            return step(prod, x, tgt) + ({k: v.clone() for k, v in prod.state_dict().items() if "running" in k},)
+    l1, g1, b1 = run()
+    for _ in range(2):
+        l2, g2, b2 = run()
+        assert torch.equal(l1, l2)
+        assert all(torch.equal(b1[k], b2[k]) for k in b1)
+        exact = [n for n in g1 if ".bn" in n or "bn1." in n or ".se." in n or n.endswith(".bias") or n == "global_pool.p" or ".1.weight" in n or ".1.bias" in n]
+        assert len(exact) > 150
+        bad = [n for n in exact if not torch.equal(g1[n], g2[n]) and n != "global_pool.p"]
+        assert not bad, bad[:8]
+        for n in g1:      # the atomically accumulated weight gradients: same values up to fp32 summation order
+            assert relerr(g2[n], g1[n], 1e-12) < (1e-2 if amp else 1e-4), n

@@ -176,14 +176,14 @@ def bench_se1(G, R, C):
     u = rnd(M, C); y = rnd(M, C)
     sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev) * 0.1
     mean = torch.randn(C, device=dev) * 0.1; rstd = torch.rand(C, device=dev) + 0.5
-    dgate = torch.zeros(G, C, device=dev); bns = torch.zeros(G, 64, 4, C, device=dev)
+    dgate = torch.zeros(G, C, device=dev, dtype=torch.float64); bns = torch.zeros(G, 64, 4, C, device=dev)
     a = cabi.make("mds_se_bwd_reduce_args", dtype=1, groups=G, rows_per_group=R, C=C, u=u, y=y, scale=sc, shift=sh,
                   dgate=dgate, mean=mean, rstd=rstd, bnsums=bns)
     timeit(f"se_bwd_reduce fused-bn {G}x{R}x{C}", lambda: lib.call("se_bwd_reduce", a, stream()), 2 * M * C * 2, 0)
     b = cabi.make("mds_se_bwd_reduce_args", dtype=1, groups=G, rows_per_group=R, C=C, u=u, y=y, scale=sc, shift=sh,
                   dgate=dgate)
     timeit(f"se_bwd_reduce plain     {G}x{R}x{C}", lambda: lib.call("se_bwd_reduce", b, stream()), 2 * M * C * 2, 0)
-    pooled = torch.zeros(G, C, device=dev); act = torch.empty_like(y)
+    pooled = torch.zeros(G, C, device=dev, dtype=torch.float64); act = torch.empty_like(y)
     c = cabi.make("mds_se_pool_args", dtype=1, groups=G, rows_per_group=R, C=C, y=y, scale=sc, shift=sh, pooled=pooled, act=act)
     timeit(f"se_pool (+act)          {G}x{R}x{C}", lambda: lib.call("se_pool", c, stream()), 2 * M * C * 2, 0)
     st = torch.zeros(SLOTS, 2, C, device=dev, dtype=torch.float64); bn = torch.stack([sc, sh, mean, rstd]).contiguous()
