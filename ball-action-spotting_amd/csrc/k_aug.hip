@@ -201,3 +201,21 @@ extern "C" int mds_aug_pass(const mds_aug_args* a, mds_stream_t stream) {
   MDS_LAUNCH(aug_kernel, dim3(bx, a->T, a->B), dim3(256), 0, stream, *a);
   return mds_check_launch("aug_pass");
 }
+
+// ------------------------------------------------------------------ SURVEY 8(f) N4, device side: pitched luma plane -> frames
+// HBM streaming copy: 16 bytes per lane where source row and destination row are both 16-byte aligned, bytes otherwise.
+__global__ __launch_bounds__(256) void frame_luma_kernel(mds_frame_luma_args a) {
+  const int f = blockIdx.z, y = blockIdx.y;
+  const unsigned char* s = a.src + (long)f * a.surface_stride + (long)y * a.pitch;
+  unsigned char* d = a.dst + ((long)f * a.height + y) * a.width;
+  const bool vec = ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0;
+  const int nv = vec ? a.width >> 4 : 0;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) ((u32x4*)d)[v] = ((const u32x4*)s)[v];
+  for (int x = 16 * nv + blockIdx.x * 256 + threadIdx.x; x < a.width; x += gridDim.x * 256) d[x] = s[x];
+}
+extern "C" int mds_frame_luma(const mds_frame_luma_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->src && a->dst && a->width > 0 && a->height > 0 && a->count > 0, "frame_luma: bad args");
+  MDS_REQUIRE(a->pitch >= a->width && a->height <= 65535 && a->count <= 65535, "frame_luma: pitch must cover a row; at most 65535 rows / surfaces");
+  MDS_LAUNCH(frame_luma_kernel, dim3(cdiv(a->width, 16 * 256) > 0 ? cdiv(a->width, 16 * 256) : 1, a->height, a->count), dim3(256), 0, stream, *a);
+  return mds_check_launch("frame_luma");
+}

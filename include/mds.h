@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 116
+#define MDS_VERSION 117
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -685,6 +685,21 @@ typedef struct {
   const float* noise;         /* optional device (B, T, H, W) standard-normal draws; NULL = generate */
 } mds_aug_args;
 int mds_aug_pass(const mds_aug_args* a, mds_stream_t stream);
+
+/* ---- SURVEY 8(f) N4 (device side): the luma plane of a decoded NV12 surface -> a contiguous (H, W) uint8 frame.
+ * What `NvDecFrameFetcher._convert` does with PySurfaceConverter(NV12 -> Y) + makefromDevicePtrUint8 + resize_
+ * (src/frame_fetchers/nvdec.py:44-55): the decoder (rocDecode on AMD) hands over a pitched surface whose first `height`
+ * rows are the Y plane; the frames the model sees are those bytes (MPEG range, no conversion).  `count` surfaces of one
+ * shape go to consecutive frames of dst (a clip for fetch_frames, or slots of the predictor's frame ring).        */
+typedef struct {
+  int width, height;
+  long pitch;                 /* bytes between rows of a surface */
+  int count;
+  const unsigned char* src;   /* first surface */
+  long surface_stride;        /* bytes between consecutive surfaces (ignored for count == 1) */
+  unsigned char* dst;         /* [count][height][width] */
+} mds_frame_luma_args;
+int mds_frame_luma(const mds_frame_luma_args* a, mds_stream_t stream);
 
 /* ---- parameter packing: fp32 PyTorch parameters -> the layouts/dtypes the kernels read.
  * One launch handles a device-resident table of jobs.                                          */
