@@ -48,3 +48,22 @@ def test_errors_are_codes_not_aborts():
     a = cabi.make("mds_pw_fwd_args", dtype=0, M=4, K=7, N=16, x=torch.zeros(32), w=torch.zeros(128), y=torch.zeros(64),
                   pro=cabi.pro(0), residual=None, stats=None)
     assert lib.fn["pw_fwd"](ctypes.byref(a), 0) == cabi.MDS_ERR_BAD_ARG
+
+
+def test_product_never_touches_the_oracle_or_the_simulator():
+    """the oracle and the kernel simulator are test infrastructure: nothing under ball-action-spotting_amd/ may import, open or
+    name them (a product path routed through either would void every parity claim)"""
+    import re
+    pkg = os.path.join(ROOT, "ball-action-spotting_amd")
+    bad = []
+    for base, _, files in os.walk(pkg):
+        if "build" in base.split(os.sep) or "__pycache__" in base:
+            continue
+        for f in files:
+            if not f.endswith((".py", ".hip", ".h", "Makefile")):
+                continue
+            text = open(os.path.join(base, f), errors="ignore").read()
+            for pat in (r"^\s*(from|import)\s+oracle", r"libmds_emu", r"from\s+hipemu|import\s+hipemu", r"#\s*if(n)?def\s+MDS_EMU"):
+                if re.search(pat, text, flags=re.M) and not (f == "Makefile" and pat == r"libmds_emu"):
+                    bad.append((os.path.relpath(os.path.join(base, f), ROOT), pat))
+    assert not bad, bad
