@@ -36,7 +36,8 @@ static inline int rows_per_pass(int C, int nslices = 1) { int cpr = C / 8 / nsli
 // host: number of blocks for a row-streaming kernel over M rows (cap ~2048 blocks, grid-stride)
 static inline int stream_blocks(long M, int C) {
   long b = (M + rows_per_pass(C) - 1) / rows_per_pass(C);
-  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+  const long cap = mds_knob(MDS_KNOB_STREAM_BLOCKS) ? mds_knob(MDS_KNOB_STREAM_BLOCKS) : 2048;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 MDS_DEV void load8f(const float* p, float (&v)[8]) { load8(p, v); }

@@ -1042,6 +1042,31 @@ static DwStrips dw_strips(int images, int H, int W, int C, int R, int want_L = 0
   return g;
 }
 
+// Strip length of the 3x3 stride-1 sliding-window kernels: the LONGEST strips (least halo: a strip of L columns reads L + 2) that
+// still give 2.5 blocks per CU.  Measured at 46 x 80 x 672 (20 images): forward 71.5 / 67.3 / 64.3 / 62.8 / 63.6 us and backward
+// 99.6 / 91.2 / 89.7 / 82.7 / 89.2 us at L = 8 / 16 / 20 / 27 / 40 (forward 1760 ... 440 blocks, backward 2640 ... 660);
+// at 23 x 40 x 1152 everything from L = 8 to 20 is within the noise and L = 40 (180 blocks) loses 40 %.
+static int dw2_len(int images, int H, int W, int C, int R) {
+  if (mds_knob(MDS_KNOB_DW2_L)) return mds_knob(MDS_KNOB_DW2_L) == 1 ? 0 : mds_knob(MDS_KNOB_DW2_L);   // 1: the former rule (dw_strips)
+  const long chunks = cdiv(C, 64), bands = cdiv(H, R);
+  int nseg = 1;
+  while (cdiv(W, nseg + 1) >= 8 && cdiv((long)images * bands * nseg, 8) * chunks < 640) ++nseg;
+  return cdiv(W, nseg);
+}
+
+// Strip length of the 3x3x3 sliding-window kernels.  They hold two blocks per CU (230-256 VGPRs), i.e. 512 blocks in flight, and a
+// launch of the headline shape (4 x 23 x 40 x 576 x 5 slices) is a few hundred blocks: the time is set by the number of ROUNDS, not by
+// the strip length (forward 40 / 39 / 42 / 33 / 43 us, backward 66 / 77 / 78 / 54 / 81 us at L = 16-20 / 4 / 8 / 10 / 20: 207, 1035, 522,
+// 414, 207 blocks - L = 8 is one block past a full round).  So: the shortest strips (>= 5 columns) that still fit ONE round.
+static int dw3_len(int images, int H, int W, int C, int former) {
+  if (mds_knob(MDS_KNOB_DW3_L)) return mds_knob(MDS_KNOB_DW3_L) == 1 ? former : mds_knob(MDS_KNOB_DW3_L);   // 1: the former fixed length
+  const long chunks = cdiv(C, 64);
+  int best = 1;
+  for (int nseg = 1; nseg <= 8 && cdiv(W, nseg) >= 5; ++nseg)
+    if (cdiv((long)images * H * nseg, 8) * chunks <= 512) best = nseg;
+  return cdiv(W, best);
+}
+
 static dim3 dw_grid(DwStrips& g) {
   const int sb = cdiv(g.nstrips, 8 * g.spt);
   if (sb >= 65536 && g.swap == 1) g.swap = 2;   // grid.y limit
@@ -1062,7 +1087,7 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
               "dw_fwd: an output transform needs scale/shift, no statistics, and a sliding-window kernel (kt == 1, or T == %d)", DW3_T);
   if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE(a->pad_t == 1 && a->pad_l == 1 && a->OH == a->IH && a->OW == a->IW, "dw_fwd: stride-1 geometry");
-    DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6);
+    DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6, dw2_len(a->N * a->T, a->OH, a->OW, a->C, 6));
     dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
@@ -1074,7 +1099,7 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
     return mds_check_launch("dw_fwd");
   }
   if (a->kt == 3 && a->T == DW3_T && !mds_switch(MDS_SW_DW_OLD)) {
-    DwStrips g = dw_strips(a->N, a->OH, a->OW, a->C, 1, 20);   // strip length measured: 8/16/20/40 -> 38/39/36/63 us
+    DwStrips g = dw_strips(a->N, a->OH, a->OW, a->C, 1, dw3_len(a->N, a->OH, a->OW, a->C, 20));
     dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_fwd_kernel<T>, grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
@@ -1316,7 +1341,7 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_bwd: grid.z");
   if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE(a->OH == a->IH && a->OW == a->IW, "dw_bwd: stride-1 geometry");
-    DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4);
+    DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4, dw2_len(a->N * a->T, a->IH, a->IW, a->C, 4));
     dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_bwd_kernel<T, 4>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_bwd");
@@ -1334,7 +1359,7 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
     return mds_check_launch("dw_bwd");
   }
   if (a->kt == 3 && a->T == DW3_T && !mds_switch(MDS_SW_DW_OLD)) {
-    DwStrips g = dw_strips(a->N, a->IH, a->IW, a->C, 1, 16);   // 8/16/20/40 -> 80/67/82/145 us
+    DwStrips g = dw_strips(a->N, a->IH, a->IW, a->C, 1, dw3_len(a->N, a->IH, a->IW, a->C, 16));
     dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_bwd_kernel<T>, grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_bwd");

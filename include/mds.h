@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 117
+#define MDS_VERSION 118
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -54,7 +54,10 @@ const char* mds_last_error(void);
 #define MDS_KNOB_WG_DBG 4      /* ablation bits of the 1x1 weight-gradient kernels (measurement only) */
 #define MDS_KNOB_WG_BLOCKS 5   /* split-M block budget of mds_pw_wgrad (0 = default) */
 #define MDS_KNOB_WG_GROUPS 6   /* 2 / 4: mds_pw_wgrad runs that many four-wave groups per block (faster alone, slower inside the step) */
-#define MDS_KNOB_COUNT 7
+#define MDS_KNOB_DW3_L 7       /* strip length of the 3x3x3 sliding-window kernels (0 = default) */
+#define MDS_KNOB_STREAM_BLOCKS 8  /* block cap of the grid-stride elementwise kernels (0 = default) */
+#define MDS_KNOB_DW2_L 9         /* strip length of the 3x3 stride-1 sliding-window kernels (0 = default rule) */
+#define MDS_KNOB_COUNT 10
 int mds_dev_set(int knob, int value);
 
 /* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /

@@ -41,6 +41,23 @@ DW_CASES = [  # N,T,H,W,C,stride,kt
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("N,T,H,W,C,stride,kt", DW_CASES)
 def test_dw_fwd_bwd(be, dt, N, T, H, W, C, stride, kt):
+    _dw_fwd_bwd(be, dt, N, T, H, W, C, stride, kt)
+
+
+@pytest.mark.parametrize("length", [5, 7, 13])
+@pytest.mark.parametrize("N,T,H,W,C,stride,kt", [(1, 1, 14, 37, 72, 1, 1), (2, 5, 6, 23, 136, 1, 3)])
+def test_dw_strip_lengths(be, length, N, T, H, W, C, stride, kt):
+    """the launchers pick the strip length from the block count (dw2_len / dw3_len); any length gives the same result:
+    forced lengths with ragged last segments, several segments per row"""
+    knob = cabi.MDS_KNOB_DW2_L if kt == 1 else cabi.MDS_KNOB_DW3_L
+    be.lib.check(be.lib.fn["dev_set"](knob, length), "dev_set")
+    try:
+        _dw_fwd_bwd(be, "bf16", N, T, H, W, C, stride, kt)
+    finally:
+        be.lib.fn["dev_set"](knob, 0)
+
+
+def _dw_fwd_bwd(be, dt, N, T, H, W, C, stride, kt):
     code, tdt = DT[dt]
     g = gen(H * W + C + kt)
     x = (torch.randn(N, C, T, H, W, generator=g) * 1.3).to(tdt)
