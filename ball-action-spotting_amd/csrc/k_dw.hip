@@ -236,12 +236,16 @@ template <> struct Pair<bf16_t> {
   static MDS_DEV raw_t ld(const bf16_t* p) { return *(const uint32_t*)p; }
   static MDS_DEV f32x2 up(raw_t u) { return (f32x2){bits2f(u << 16), bits2f(u & 0xffff0000u)}; }
   static MDS_DEV void st(bf16_t* p, f32x2 v) { *(uint32_t*)p = pack2(v[0], v[1]); }
+  static MDS_DEV raw_t pk(f32x2 v) { return pack2(v[0], v[1]); }
+  static MDS_DEV void str(bf16_t* p, raw_t r) { *(uint32_t*)p = r; }
 };
 template <> struct Pair<float> {
   typedef f32x2 raw_t;
   static MDS_DEV raw_t ld(const float* p) { return *(const f32x2*)p; }
   static MDS_DEV f32x2 up(raw_t u) { return u; }
   static MDS_DEV void st(float* p, f32x2 v) { *(f32x2*)p = v; }
+  static MDS_DEV raw_t pk(f32x2 v) { return v; }
+  static MDS_DEV void str(float* p, raw_t r) { *(f32x2*)p = r; }
 };
 MDS_DEV f32x2 splat2(float v) { return (f32x2){v, v}; }
 MDS_DEV f32x2 sigmoid2(f32x2 z) {
@@ -258,6 +262,31 @@ MDS_DEV f32x2 epi2(f32x2 v, int mode, f32x2 sc, f32x2 sh) {
 }
 
 struct DwStrips { int nchunks, nseg, L, nbands, spt, swap; long nstrips; };
+
+// Squeeze-excite pooling of an inference plan inside the producing pass (mds_dw_fwd_args.pool): `sp` is this thread's sum of
+// the STORED outputs of its strip (what mds_se_pool would read back), `img` the strip's batch element.  The 8 strips of a block
+// are reduced in LDS; a block whose strips straddle two images flushes once per image.
+MDS_DEV void dw_pool_flush(float (&red)[8][4][32], f32x2 sp, int img, bool strip_ok, double* pool, float inv, int C, int cbeg) {
+  __shared__ int img_s[8];
+  const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
+  red[sl][0][cp] = sp[0]; red[sl][1][cp] = sp[1];
+  if (cp == 0) img_s[sl] = strip_ok ? img : -1;
+  __syncthreads();
+  if (tid < 64 && cbeg + tid < C) {
+    float t = 0.f;
+    int cur = -1;
+    for (int s = 0; s < 8; ++s) {
+      const int n = img_s[s];
+      if (n < 0) continue;
+      if (n != cur) {
+        if (cur >= 0) atomicAdd(pool + (long)cur * C + cbeg + tid, (double)(t * inv));
+        t = 0.f; cur = n;
+      }
+      t += red[s][tid & 1][tid >> 1];
+    }
+    if (cur >= 0) atomicAdd(pool + (long)cur * C + cbeg + tid, (double)(t * inv));
+  }
+}
 // Workgroup -> (strip block, channel chunk).  Consecutive workgroup ids go to consecutive XCDs (id % 8), each with its own L2.
 // Neighbouring strips share halo rows / columns ((R + 2) / R x (L + 2) / L = 1.5x the compulsory reads when every strip fetches
 // its own halo from HBM - the PMC FETCH_SIZE of round 2 showed 1.6x): XCD x takes a CONTIGUOUS range of the (chunk, strip)
@@ -290,7 +319,9 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
   const int emode = a.epi.mode;
   f32x2 esc = splat2(1.f), esh = splat2(0.f);
   if (emode != MDS_EPI_NONE && c0 < a.C) { esc = *(const f32x2*)(a.epi.scale + c0); esh = *(const f32x2*)(a.epi.shift + c0); }
-  f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f), sp = splat2(0.f);
+  int pimg = 0;
+  bool pok = false;
   f32x2 w[3][3], sc = splat2(1.f), sh = splat2(0.f);
   if (cvalid) {
 #pragma unroll
@@ -299,6 +330,7 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
   }
   for (int k = 0; k < g.spt; ++k) {
     const long strip = ((long)bx * g.spt + k) * 8 + sl;
+    if (strip < g.nstrips) { pimg = (int)(strip / ((long)g.nseg * g.nbands)); pok = true; }
     if (!cvalid || strip >= g.nstrips) continue;
     const int seg = (int)(strip % g.nseg);
     const long bt = strip / g.nseg;
@@ -355,8 +387,9 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) acc += win[r + ky][kx] * w[ky][kx];
           if (oy0 + r < a.OH) {
-            P::st(yim + ((long)r * a.OW + ox0 + o) * C, epi2(acc, emode, esc, esh));
-            s1 += acc; s2 += acc * acc;
+            const raw_t pk = P::pk(epi2(acc, emode, esc, esh));
+            P::str(yim + ((long)r * a.OW + ox0 + o) * C, pk);
+            s1 += acc; s2 += acc * acc; sp += P::up(pk);
           }
         }
       }
@@ -378,6 +411,7 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
       if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
     }
   }
+  if (a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
 }
 
 // backward, same decomposition over INPUT pixels: window = dy rows iy-1..iy+R, cols ix-1..ix+1.
@@ -540,11 +574,14 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
     wl[t][e & 31] = c < C ? (f32x2){a.w[(long)c * 27 + t], a.w[(long)(c + 1) * 27 + t]} : splat2(0.f);
   }
   __syncthreads();
-  f32x2 s1 = splat2(0.f), s2 = splat2(0.f), sc = splat2(1.f), sh = splat2(0.f);
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f), sp = splat2(0.f), sc = splat2(1.f), sh = splat2(0.f);
+  int pimg = 0;
+  bool pok = false;
   if (cvalid && mode != MDS_PRO_NONE) { sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0); }
   const int tstr = a.IH * a.IW * C;   // slice stride (elements)
   for (int k = 0; k < g.spt; ++k) {
     const long strip = ((long)bx * g.spt + k) * 8 + sl;
+    if (strip < g.nstrips) { pimg = (int)(strip / ((long)g.nseg * g.nbands)); pok = true; }
     if (!cvalid || strip >= g.nstrips) continue;
     const int seg = (int)(strip % g.nseg);
     const long bt = strip / g.nseg;
@@ -618,8 +655,9 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
           }
 #pragma unroll
       for (int ot = 0; ot < TT; ++ot) {
-        P::st(yim + (long)ot * tstr + (long)(ox0 + o) * C, epi2(acc[ot], emode, esc, esh));
-        s1 += acc[ot]; s2 += acc[ot] * acc[ot];
+        const raw_t pk = P::pk(epi2(acc[ot], emode, esc, esh));
+        P::str(yim + (long)ot * tstr + (long)(ox0 + o) * C, pk);
+        s1 += acc[ot]; s2 += acc[ot] * acc[ot]; sp += P::up(pk);
       }
     }
   }
@@ -634,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
       if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
     }
   }
+  if (a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
 }
 
 // backward: window of dy [5 slices][3 rows][3 cols] around the thread's input row; per input pixel
@@ -800,7 +839,9 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
   const int emode = a.epi.mode;
   f32x2 esc = splat2(1.f), esh = splat2(0.f);
   if (emode != MDS_EPI_NONE && c0 < a.C) { esc = *(const f32x2*)(a.epi.scale + c0); esh = *(const f32x2*)(a.epi.shift + c0); }
-  f32x2 s1 = splat2(0.f), s2 = splat2(0.f);
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f), sp = splat2(0.f);
+  int pimg = 0;
+  bool pok = false;
   f32x2 w[3][3], sc = splat2(1.f), sh = splat2(0.f);
   if (cvalid) {
 #pragma unroll
@@ -809,6 +850,7 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
   }
   for (int k = 0; k < g.spt; ++k) {
     const long strip = ((long)bx * g.spt + k) * 8 + sl;
+    if (strip < g.nstrips) { pimg = (int)(strip / ((long)g.nseg * g.nbands)); pok = true; }
     if (!cvalid || strip >= g.nstrips) continue;
     const int seg = (int)(strip % g.nseg);
     const long bt = strip / g.nseg;
@@ -864,8 +906,9 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) acc += win[2 * r + ky][kx] * w[ky][kx];
         if (oy0 + r < a.OH) {
-          P::st(yim + ((long)r * a.OW + ox0 + o) * C, epi2(acc, emode, esc, esh));
-          s1 += acc; s2 += acc * acc;
+          const raw_t pk = P::pk(epi2(acc, emode, esc, esh));
+          P::str(yim + ((long)r * a.OW + ox0 + o) * C, pk);
+          s1 += acc; s2 += acc * acc; sp += P::up(pk);
         }
       }
     }
@@ -881,6 +924,7 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
       if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
     }
   }
+  if (a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
 }
 
 // Backward over INPUT pixels: a thread owns 4 input rows x pairs of input columns; the dy values that
@@ -1085,11 +1129,22 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_fwd: grid.z");
   MDS_REQUIRE(a->epi.mode == MDS_EPI_NONE || (a->epi.scale && a->epi.shift && !a->stats && !mds_switch(MDS_SW_DW_OLD) && (a->kt == 1 || a->T == DW3_T)),
               "dw_fwd: an output transform needs scale/shift, no statistics, and a sliding-window kernel (kt == 1, or T == %d)", DW3_T);
+  MDS_REQUIRE(!a->pool || (a->epi.mode != MDS_EPI_NONE && !a->stats && a->pool_inv > 0.f && !mds_switch(MDS_SW_DW_OLD) &&
+                           ((a->kt == 1 && a->T == 1) || (a->kt == 3 && a->T == DW3_T))),
+              "dw_fwd: pooling needs an output transform, no statistics, pool_inv, and a sliding-window kernel (kt == 1 with T == 1, or kt == 3 with T == %d)", DW3_T);
   if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
     MDS_REQUIRE(a->pad_t == 1 && a->pad_l == 1 && a->OH == a->IH && a->OW == a->IW, "dw_fwd: stride-1 geometry");
-    DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 6, dw2_len(a->N * a->T, a->OH, a->OW, a->C, 6));
+    // one or two images (the frame-by-frame predictor): 6-row bands with the shortest strips are 50-110 blocks - under one wave per
+    // SIMD, every column a full memory round trip.  Two-row bands give three times the threads ((R + 2) / R = 2x the row reads,
+    // served by L2).  MDS_KNOB_DW2_R: 1 = always six rows.
+    const int images = a->N * a->T;
+    const bool small = mds_knob(MDS_KNOB_DW2_R) != 1 &&
+                       cdiv((long)images * cdiv(a->OH, 6) * cdiv(a->OW, 8), 8) * cdiv(a->C, 64) < 256;
+    const int R = small ? 2 : 6;
+    DwStrips g = dw_strips(images, a->OH, a->OW, a->C, R, dw2_len(images, a->OH, a->OW, a->C, R));
     dim3 grid = dw_grid(g), block(256);
-    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
+    if (small) MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 2>), grid, block, 0, stream, *a, g));
+    else MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
   if (a->kt == 1 && a->stride == 2 && !mds_switch(MDS_SW_DW_OLD)) {

@@ -42,8 +42,11 @@ template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 // TWO: a second operand pair and a bias row (the LINEAR form of BatchNorm backward in a data gradient, mds_pw_fwd_args):
 //   y = x[M][K] w[:, 0:K]^T + x1[M][K1] w[:, Kp:Kp+K1]^T + bias,  Kp = K rounded up to 64 - the K loop simply runs over both
 // pairs, w rows hold both weight sets (zero padded), rows of x / x1 past their own K are staged as zeros.
-template <typename T, int PRO, int WN, int BM, int TAIL, int DEEP = 0, bool TWO = false>
-__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || TAIL == 1 || (DEEP && PRO == MDS_PRO_GATE) ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+// SPLIT (inference plans, small M): grid.z blocks share an output tile, each over its own K range; partial tiles go to
+//   split_part[z][M][N] (fp32), the last block to finish the tile (ticket) adds them in z order and runs the epilogue.
+template <typename T, int PRO, int WN, int BM, int TAIL, int DEEP = 0, bool TWO = false, bool SPLIT = false>
+__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || TAIL == 1 || (DEEP && PRO == MDS_PRO_GATE) || SPLIT ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+  static_assert(!SPLIT || (!DEEP && !TWO && TAIL != 1 && (PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && WN == 2 && BM == 64), "SPLIT variants");
   static_assert(!DEEP || ((PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && BM == 64 && WN == 2 && TAIL != 2), "DEEP variants");
   static_assert(!TWO || (PRO == MDS_PRO_NONE && !DEEP && TAIL != 2), "two operand pairs: plain prologue, no output transform");
   constexpr bool POST = TAIL == 1, EPI = TAIL == 2;
@@ -66,6 +69,10 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
   const int N = a.N;
   const int K0 = a.K, K0p = (K0 + 63) & ~63, K1 = TWO ? a.K1 : 0;
   const int K = TWO ? K0p + ((K1 + 63) & ~63) : K0;       // length of the K loop = length of a packed weight row
+  // SPLIT: this block's K range [KB, KE) (whole chunks); K stays the row pitch
+  const int kper = SPLIT ? ((K + (int)gridDim.z * PwCfg<T>::KC - 1) / ((int)gridDim.z * PwCfg<T>::KC)) * PwCfg<T>::KC : K;
+  const int KB = SPLIT ? (int)blockIdx.z * kper : 0;
+  const int KE = SPLIT ? (KB + kper < K ? KB + kper : K) : K;
   const T* x1 = (const T*)a.x1;
   const T* x = (const T*)(PRO == PW_PRO_DY ? a.xdy.g.u : a.x);
   const T* w = (const T*)a.w;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       wrow[l] = w + (long)(wok[l] ? n : 0) * K + 8 * svec;
     }
     auto issue = [&](int kc, RawV8<T> (&tx)[NL], RawV8<T> (&tw)[NLW], float (&tg)[GPRE ? NL : 1][8]) {  // all global loads of one K-chunk
-      const bool kok = kc + 8 * svec < K;
+      const bool kok = kc + 8 * svec < KE;
       if (DEEP) {   // straight-line: rows are clamped in xrow / wrow, channels past K read channel 0; zeroed when staged
         const int ko = kok ? kc : -8 * svec;
 #pragma unroll
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
     };
     auto chunk = [&](int kc, RawV8<T> (&tx)[NL], RawV8<T> (&tw)[NLW], float (&tg)[GPRE ? NL : 1][8]) {
       const int kk = kc + 8 * svec;
-      const bool kin = kk < K;
+      const bool kin = kk < KE;
       __syncthreads();  // previous chunk's fragment reads are done
       if (PRO == MDS_PRO_NONE) {
 #pragma unroll
@@ -250,8 +257,8 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       }
       __syncthreads();
       if (DEEP) issue(kc + 2 * KC, tx, tw, tg);            // refill this set (past K: clamped reads, never staged as data)
-      else if (kc + KC < K) issue(kc + KC, tx, tw, tg);    // in flight while the MFMAs below run
-      const int ksteps = (K - kc >= KC) ? KC / 32 : ((K - kc + 31) >> 5);   // <= 0 for the phantom chunk of an odd count
+      else if (kc + KC < KE) issue(kc + KC, tx, tw, tg);    // in flight while the MFMAs below run
+      const int ksteps = (KE - kc >= KC) ? KC / 32 : ((KE - kc + 31) >> 5);   // <= 0 for the phantom chunk of an odd count
 #pragma unroll
       for (int ks = 0; ks < KC / 32; ++ks) {
         if (DEEP || ks < ksteps) {   // DEEP: no branch between a refill and its wait (channels past K are staged as zeros)
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
         }
       }
     };
-    issue(0, rx[0], rw[0], rg[0]);
+    if (!SPLIT || KB < KE) issue(KB, rx[0], rw[0], rg[0]);
     if (DEEP) {
       issue(KC, rx[NS - 1], rw[NS - 1], rg[NS - 1]);
       for (int kc = 0; kc < K; kc += 2 * KC) {
@@ -275,7 +282,59 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
         chunk(kc + KC, rx[NS - 1], rw[NS - 1], rg[NS - 1]);
       }
     } else {
-      for (int kc = 0; kc < K; kc += KC) chunk(kc, rx[0], rw[0], rg[0]);
+      for (int kc = KB; kc < KE; kc += KC) chunk(kc, rx[0], rw[0], rg[0]);
+    }
+    if (SPLIT) {
+      // partial tile -> split_part[z]; ticket; the last block of the tile sums the partials in z order (its own included:
+      // the order is fixed, so the result does not depend on which block came last) and goes on to the epilogue
+      const long MN = a.M * (long)N;
+#pragma unroll
+      for (int mf = 0; mf < MFW; ++mf) {
+        const long m = m0 + 16 * MFW * wm + 16 * mf + i;
+        if (m < a.M) {
+          float* prow = a.split_part + (long)blockIdx.z * MN + m * N + n0 + 64 * wn + 4 * q;
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf)
+            if (nf < nfr) st_coherent4(prow + 16 * nf, acc[mf][nf]);
+        }
+      }
+      int* lastp = (int*)smem;    // (the operand tiles are dead: every wave passed the K loop's last barrier)
+      __syncthreads();            // every lane has waited for the acknowledgements of its device-scope stores (vmcnt(0) is part of the barrier)
+      if (tid == 0) {
+        int* tk = a.split_ticket + ((long)blockIdx.x * ((N + BN - 1) / BN) + n0 / BN) * MDS_PW_SPLIT_TICKET_STRIDE;
+        const int t = atomicAdd(tk, 1);
+        const int last = t == (int)gridDim.z - 1;
+        if (last) atomicExch(tk, 0);   // ready for the next launch
+        *lastp = last;
+      }
+      __syncthreads();
+      const bool last = *lastp != 0;
+      __syncthreads();            // (smem is reused by the epilogue tables)
+      if (!last) continue;
+#pragma unroll
+      for (int mf = 0; mf < MFW; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // four partial tiles are requested at a time (one memory round trip per four splits, not one per split and fragment row)
+      for (int z0 = 0; z0 < (int)gridDim.z; z0 += 4) {
+        f32x4 t[4][MFW][4];
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+          for (int mf = 0; mf < MFW; ++mf) {
+            const long m = m0 + 16 * MFW * wm + 16 * mf + i;
+            const bool ok = m < a.M && z0 + zz < (int)gridDim.z;
+            const float* prow = a.split_part + (long)(z0 + zz) * MN + m * N + n0 + 64 * wn + 4 * q;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) t[zz][mf][nf] = (ok && nf < nfr) ? ld_coherent4(prow + 16 * nf) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz)      // z order: the sum does not depend on which block came last
+#pragma unroll
+          for (int mf = 0; mf < MFW; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) acc[mf][nf] += t[zz][mf][nf];
+      }
     }
 
     // ---- epilogue: residual, store, statistics.  One row-validity test per m-fragment (not per
@@ -443,19 +502,29 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
     MDS_REQUIRE(a->K1 > 0 && a->K1 % 8 == 0 && a->x && !dy && !epi && a->pro.mode == MDS_PRO_NONE && !a->stats,
                 "pw_fwd: a second operand pair needs K1 %% 8 == 0, a plain first operand, no prologue, no output transform, no forward statistics");
   }
-  if (!two) { const int rc = pw_fwd_wres_try(a, stream); if (rc <= 0) return rc; }
+  const bool split = a->split > 1;
+  if (split) {
+    MDS_REQUIRE(a->split <= MDS_PW_MAX_SPLIT && a->split_part && a->split_ticket, "pw_fwd: split-K needs split <= %d, a partial buffer and tickets", MDS_PW_MAX_SPLIT);
+    MDS_REQUIRE(!dy && !post && !two && !a->stats && (a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE),
+                "pw_fwd: split-K is an inference-plan feature (NONE / GATE prologue, no statistics, no post statistics, no dy prologue, one operand pair)");
+  }
+  if (!two && !split) { const int rc = pw_fwd_wres_try(a, stream); if (rc <= 0) return rc; }
   // 128x64 tiles for the narrow projections (N <= 64: half of a 128-column tile would be padding;
   // 154 -> 119 us at 1.18 M x 128 -> 32); wider N measured 5-20 % slower with them despite 3 blocks/CU
-  const int wn = a->N <= 64 ? 1 : 2;
+  const int wn = (a->N <= 64 && !split) ? 1 : 2;
   const int BN = 64 * wn;
   // 64-row tiles below 400 k rows: twice the blocks for the stage-3..5 / 3D layers (isolated: -10...25 %;
   // inside the step, where the weight-gradient stream fills the idle CUs anyway, +1 %)
   // (the dy-prologue variant keeps two operand tiles in flight: its 128-row form would spill)
   const int bm = (wn == 2 && (a->M <= 400000 || dy)) ? 64 : PW_BM;
+  MDS_REQUIRE(!split || bm == 64, "pw_fwd: split-K is for small M (64-row tiles)");
   const int mt = cdiv(a->M, bm), nt = cdiv(a->N, BN);
   int gy = 1;
   if (nt > 1) { gy = cdiv(1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
-  dim3 grid(mt, gy), block(256);
+  dim3 grid(mt, gy, split ? a->split : 1), block(256);
+#define PW_GOSPLIT(T, PRO, TAIL_) \
+  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
+       MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_, 0, false, true>), grid, block, smem, stream, *a); } while (0)
 #define PW_GO2(T, PRO, TAIL_) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
        if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_>), grid, block, smem, stream, *a); \
@@ -477,7 +546,11 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   const bool deep0 = !two && wn == 2 && bm == 64 && !dy && !epi && (a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE) &&
                      mds_knob(MDS_KNOB_PW_DEEP) == 1;   // opt-in: measured 4 % SLOWER inside the step (2.87 -> 3.00 ms of pw_fwd)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
-    if (deep0 && a->K >= 4 * PwCfg<T>::KC) {   // K-heavy layers: two K chunks in flight
+    if (split) {
+      if (epi) { if (a->pro.mode == MDS_PRO_GATE) PW_GOSPLIT(T, MDS_PRO_GATE, 2); else PW_GOSPLIT(T, MDS_PRO_NONE, 2); }
+      else { if (a->pro.mode == MDS_PRO_GATE) PW_GOSPLIT(T, MDS_PRO_GATE, 0); else PW_GOSPLIT(T, MDS_PRO_NONE, 0); }
+    }
+    else if (deep0 && a->K >= 4 * PwCfg<T>::KC) {   // K-heavy layers: two K chunks in flight
       if (post) PW_GODEEP(T, MDS_PRO_NONE, 1);
       else if (a->pro.mode == MDS_PRO_GATE) PW_GODEEP(T, MDS_PRO_GATE, 0);
       else PW_GODEEP(T, MDS_PRO_NONE, 0);
@@ -499,7 +572,26 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
 #undef PW_GO2
 #undef PW_GODY
 #undef PW_GOTWO
+#undef PW_GOSPLIT
   return mds_check_launch("pw_fwd");
+}
+
+// split-K factor for a shape.  Measured on the fp32 inference shapes of one 736 x 1280 frame (tools/probes/split_bench.py, us):
+//   920 x 1152 -> 192 (30 tiles, 36 chunks): 56 unsplit, 38 / 32 / 30 / 30 / 32 / 40 at split 2 / 3 / 4 / 6 / 8 / 12
+//   3680 x 672 -> 112 (58 tiles, 21 chunks): 34 unsplit, 27 / 24 / 24 / 34 / 30 / 36
+//   4600 x 576 -> 192 (144 tiles): 31 unsplit, 31-37 split - no gain;  920 x 192 -> 1152 (6 chunks): 13 unsplit, 24+ split - a loss.
+// What bounds the split form is the last block's pass over the partial tiles (~10 us at 6 splits) and ~6 us of ticket + barrier, so:
+// only launches of < 100 tiles that walk >= 16 chunks, four splits.  MDS_KNOB_PW_SPLIT: 1 = never, n >= 2 = that factor instead of 4.
+extern "C" int mds_pw_fwd_split(long M, int K, int N, int dtype) {
+  const int knob = mds_knob(MDS_KNOB_PW_SPLIT);
+  if (knob == 1 || M <= 0 || K <= 0 || N <= 0) return 1;
+  const int kc = dtype == MDS_BF16 ? PwCfg<bf16_t>::KC : PwCfg<float>::KC;
+  const long chunks = cdiv(K, kc), tiles = cdiv(M, MDS_PW_SPLIT_TILE_ROWS) * cdiv(N, 128);
+  if (tiles >= 100 || chunks < 16) return 1;
+  long s = knob >= 2 ? knob : 4;
+  if (s > chunks / 3) s = chunks / 3;
+  if (s > MDS_PW_MAX_SPLIT) s = MDS_PW_MAX_SPLIT;
+  return s < 2 ? 1 : (int)s;
 }
 
 // ------------------------------------------------------------------------------------ wgrad

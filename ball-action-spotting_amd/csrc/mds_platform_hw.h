@@ -23,6 +23,28 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
 }
+// Handing data from one workgroup to another INSIDE a launch (the split-K partial tiles of pw_fwd).  The 8 XCDs' L2s are not
+// coherent with each other for ordinary accesses.  Measured alternatives: an agent-scope release fence is an L2 write-back per block
+// and an acquire fence an L2 invalidate for the whole XCD (a 360-block launch ran 2.5x slower than not splitting); returning atomic
+// exchanges are bounded by the atomic units (~0.14 us per block of 4096 exchanges).  What is used: agent-scope atomic STORES (sc1:
+// written through, acknowledged at device scope), the block barrier (every lane waits for its acknowledgements), then the ticket;
+// the consumer reads with agent-scope atomic loads (sc1), which go to the same coherence point.  No fence, no cache maintenance.
+MDS_DEV void st_coherent4(float* p, const f32x4& v) {
+  typedef unsigned long long u64;
+  // (elements are copied to scalars first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 on this compiler)
+  const float f0 = v[0], f1 = v[1], f2 = v[2], f3 = v[3];
+  const u64 lo = (u64)__builtin_bit_cast(uint32_t, f0) | ((u64)__builtin_bit_cast(uint32_t, f1) << 32);
+  const u64 hi = (u64)__builtin_bit_cast(uint32_t, f2) | ((u64)__builtin_bit_cast(uint32_t, f3) << 32);
+  __hip_atomic_store((u64*)p, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((u64*)(p + 2), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+MDS_DEV f32x4 ld_coherent4(const float* p) {
+  typedef unsigned long long u64;
+  const u64 a = __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 b = __hip_atomic_load((const u64*)(p + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (f32x4){__builtin_bit_cast(float, (uint32_t)a), __builtin_bit_cast(float, (uint32_t)(a >> 32)),
+                 __builtin_bit_cast(float, (uint32_t)b), __builtin_bit_cast(float, (uint32_t)(b >> 32))};
+}
 #define MDS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MDS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  /* wave-uniform value -> scalar register */
 #define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]

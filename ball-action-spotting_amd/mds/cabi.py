@@ -107,6 +107,8 @@ class Lib:
                 self.fn[op].argtypes = [C.POINTER(st), C.c_void_p]
         if "se_bwd_reduce_blocks" in self.fn:
             self.fn["se_bwd_reduce_blocks"].argtypes = [C.c_long, C.c_int]
+        if "pw_fwd_split" in self.fn:
+            self.fn["pw_fwd_split"].argtypes = [C.c_long, C.c_int, C.c_int, C.c_int]
         if "pack_weights" in self.fn:
             self.fn["pack_weights"].argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         if "dev_set" in self.fn:

@@ -257,6 +257,22 @@ class Plan:
     def f32(self, n):
         return self._own(n, torch.float32)
 
+    def _split(self, M, K, N_):
+        """split-K fields of an inference-plan pw_fwd (mds_pw_fwd_args.split): the factor comes from the library's own rule; the
+        partial buffer and the (self-resetting) tickets are shared by every layer of the plan - launches of one stream"""
+        if not self.eval_epilogues:
+            return {}
+        S = int(self.lib.fn["pw_fwd_split"](int(M), int(K), int(N_), int(self.code)))
+        if S <= 1:
+            return {}
+        if getattr(self, "_split_part", None) is None:
+            self._split_part = self._own(0, torch.float32)
+            self._split_ticket = Lazy("own0", 0, torch.int32)
+            self._lazy.append(self._split_ticket)
+        self._split_part.numel = max(self._split_part.numel, S * int(M) * int(N_))
+        self._split_ticket.numel = max(self._split_ticket.numel, -(-int(M) // cabi.MDS_PW_SPLIT_TILE_ROWS) * -(-int(N_) // 128) * cabi.MDS_PW_SPLIT_TICKET_STRIDE)
+        return dict(split=S, split_part=self._split_part, split_ticket=self._split_ticket)
+
     def zero_fwd(self, n):
         l = self.zf_arena.sub(self._zf, n)
         self._zf += n
@@ -364,7 +380,7 @@ class Plan:
             assert self.eval_epilogues and stats_bn is not None
             stats_bn.finalize(self, seg)      # eval table
             self.op(seg, "pw_fwd", dtype=self.code, M=M, K=K, N=N_, x=x, w=w, y=y, pro=pro or dict(mode=0), residual=residual,
-                    stats=None, epi=dict(_struct="mds_epi_t", mode=epi_mode, scale=stats_bn.scale, shift=stats_bn.shift))
+                    stats=None, epi=dict(_struct="mds_epi_t", mode=epi_mode, scale=stats_bn.scale, shift=stats_bn.shift), **self._split(M, K, N_))
             return y
         self.op(seg, "pw_fwd", dtype=self.code, M=M, K=K, N=N_, x=x, w=w, y=y, pro=pro or dict(mode=0),
                 residual=residual, stats=stats_bn.stats if stats_bn is not None else None)
@@ -452,14 +468,18 @@ class Plan:
             return dict(_struct="mds_epi_t", mode=mode, scale=bn.scale, shift=bn.shift)
         a1 = self.act(Min, mid)
         self.op(fseg, "pw_fwd", dtype=self.code, M=Min, K=cin, N=mid, x=xin, w=self.pack(blk.conv_pw.weight, cabi.MDS_PACK_OI, mid, cin, 1),
-                y=a1, pro=dict(mode=0), residual=None, stats=None, epi=epi(bn1, EPI_BN_SILU))
+                y=a1, pro=dict(mode=0), residual=None, stats=None, epi=epi(bn1, EPI_BN_SILU), **self._split(Min, cin, mid))
         a2 = self.act(Mout, mid)
-        self.op(fseg, "dw_fwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
-                pad_l=pl, kt=kt, x=a1, w=P(blk.conv_dw.weight), y=a2, pro=dict(mode=0), stats=None, epi=epi(bn2, EPI_BN_SILU))
         R = blk.se.rd
         pooled, hidden, gate = self.zero_fwd64(groups * mid), self.f32(groups * R), self.f32(groups * mid)
-        self.op(fseg, "se_pool", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, y=a2, scale=None, shift=None,
-                pooled=pooled, act=None)
+        # the depthwise pass stores the activation AND takes its per-image channel means (the squeeze-excite input): no se_pool launch
+        fuse_pool = groups == N and os.environ.get("MDS_EVAL_POOL", "1") == "1"
+        self.op(fseg, "dw_fwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
+                pad_l=pl, kt=kt, x=a1, w=P(blk.conv_dw.weight), y=a2, pro=dict(mode=0), stats=None, epi=epi(bn2, EPI_BN_SILU),
+                pool=pooled if fuse_pool else None, pool_inv=1.0 / rpg if fuse_pool else 0.0)
+        if not fuse_pool:
+            self.op(fseg, "se_pool", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, y=a2, scale=None, shift=None,
+                    pooled=pooled, act=None)
         se = blk.se
         w2t = self.pack(se.conv_expand.weight, cabi.MDS_PACK_IO_F32, mid, R, 1)
         self.op(fseg, "se_fc_fwd", groups=groups, C=mid, R=R, pooled=pooled, w1=P(se.conv_reduce.weight),
@@ -469,7 +489,7 @@ class Plan:
         self.op(fseg, "pw_fwd", dtype=self.code, M=Mout, K=mid, N=cout, x=a2,
                 w=self.pack(blk.conv_pwl.weight, cabi.MDS_PACK_OI, cout, mid, 1), y=xout,
                 pro=dict(mode=PRO_GATE, scale=None, shift=None, gate=gate, rows_per_group=rpg),
-                residual=xin if has_skip else None, stats=None, epi=epi(bn3, EPI_AFFINE))
+                residual=xin if has_skip else None, stats=None, epi=epi(bn3, EPI_AFFINE), **self._split(Mout, mid, cout))
         return xout, OH, OW
 
     # -- inverted-residual block (2D: T=1, kt=1 ; 3D: kt=3), shared by encoder stages 3-5 and conv3d_encoder
@@ -798,7 +818,7 @@ class Plan:
         for arena in (self.zf_arena, self.zb_arena, self.mask_arena, self.grad_arena, self.zb64_arena, self.zf64_arena):
             arena.tensor = torch.zeros(max(arena.numel, 1), dtype=arena.dtype, device=dev)
         for l in self._lazy:
-            l.tensor = torch.empty(max(l.numel, 1), dtype=l.dtype, device=dev)
+            l.tensor = (torch.zeros if l.kind == "own0" else torch.empty)(max(l.numel, 1), dtype=l.dtype, device=dev)
         if self.masks:
             keep = torch.empty(self._mask_total, dtype=torch.float32)
             for off, n, kp in self.masks:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 118
+#define MDS_VERSION 119
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -57,7 +57,9 @@ const char* mds_last_error(void);
 #define MDS_KNOB_DW3_L 7       /* strip length of the 3x3x3 sliding-window kernels (0 = default) */
 #define MDS_KNOB_STREAM_BLOCKS 8  /* block cap of the grid-stride elementwise kernels (0 = default) */
 #define MDS_KNOB_DW2_L 9         /* strip length of the 3x3 stride-1 sliding-window kernels (0 = default rule) */
-#define MDS_KNOB_COUNT 10
+#define MDS_KNOB_PW_SPLIT 10       /* split-K of the small-M inference GEMMs: 0 = rule (mds_pw_fwd_split), 1 = never, n >= 2 = at most n */
+#define MDS_KNOB_DW2_R 11          /* 1: the 3x3 stride-1 forward keeps six-row bands for small launches too (A/B) */
+#define MDS_KNOB_COUNT 12
 int mds_dev_set(int knob, int value);
 
 /* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
@@ -163,8 +165,19 @@ typedef struct {
   const void* x1;       /* optional [M][K1] */
   int K1;
   const float* bias;    /* optional [N] */
+  /* split-K for the small-M launches of inference plans (a 920-row layer is 15-30 blocks that each walk 36 K chunks
+   * one memory round trip at a time): grid.z = split blocks share a tile, each stores its fp32 partial tile to
+   * split_part[z][M][N]; the LAST block to finish a tile (split_ticket, self-resetting) adds the partials in z order -
+   * deterministic - and runs the epilogue.  split <= 1: off.  mds_pw_fwd_split() gives the factor for a shape.   */
+  int split;
+  float* split_part;    /* fp32 [split][M][N] scratch */
+  int* split_ticket;    /* [tiles * MDS_PW_SPLIT_TICKET_STRIDE], tiles = ceil(M / MDS_PW_SPLIT_TILE_ROWS) * ceil(N / 128); zero before the first launch */
 } mds_pw_fwd_args;
 int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream);
+int mds_pw_fwd_split(long M, int K, int N, int dtype);   /* recommended split-K factor (1 = none); <= MDS_PW_MAX_SPLIT */
+#define MDS_PW_MAX_SPLIT 16
+#define MDS_PW_SPLIT_TILE_ROWS 64   /* tiles of a launch = ceil(M / 64) * ceil(N / 128) */
+#define MDS_PW_SPLIT_TICKET_STRIDE 32   /* ints between two tiles' tickets: one 128-byte line each (atomics on one line serialise, ~0.13 us apiece) */
 
 /* The linear form of BatchNorm backward (replaces mds_bn_bwd_apply for the BatchNorm behind a 1x1 expansion y = x W^T,
  * W fp32 [Cmid][Cin], multidim_stacker.py:106 / timm conv_pw).  With dy = A*g + B*y + D (mds_bn_bwd_finalize `lin`):
@@ -312,6 +325,11 @@ typedef struct {
   mds_pro_t pro;
   double* stats;
   mds_epi_t epi;       /* eval-mode output transform (sliding-window kernels: kt == 1, or kt == 3 with T == 5) */
+  /* squeeze-excite pooling in the same pass (inference plans: the output IS the activation, so its per-image channel
+   * means are the SE input - no mds_se_pool launch): pool[n][c] += pool_inv * sum over the image's stored outputs.
+   * Needs an output transform, a sliding-window kernel, and kt == 3 or T == 1 (group = batch element n).        */
+  double* pool;        /* optional fp64 [N][C], caller-zeroed */
+  float pool_inv;      /* 1 / (T*OH*OW) */
 } mds_dw_fwd_args;
 int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream);
 

@@ -249,9 +249,11 @@ template <typename T> inline T __shfl_xor(T v, int mask, int width = 64) { (void
 template <typename T> inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; return hipemu::shfl_src(v, hipemu::lane_id() + (int)d); }
 template <typename T> inline T __shfl(T v, int src, int width = 64) { (void)width; return hipemu::shfl_src(v, src); }
 
+inline void __threadfence() {}
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 
 inline const char* hipGetErrorString(int) { return "hipemu"; }

@@ -9,6 +9,8 @@ MDS_DEV bf16_t f2bf(float f) {  // round-to-nearest-even
 }
 MDS_DEV uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
+MDS_DEV void st_coherent4(float* p, const f32x4& v) { for (int j = 0; j < 4; ++j) p[j] = v[j]; }
+MDS_DEV f32x4 ld_coherent4(const float* p) { f32x4 v; for (int j = 0; j < 4; ++j) v[j] = p[j]; return v; }
 MDS_DEV float fast_exp(float x) { return expf(x); }
 MDS_DEV float fast_exp2(float x) { return exp2f(x); }
 MDS_DEV float fast_rcp(float x) { return 1.0f / x; }

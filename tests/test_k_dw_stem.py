@@ -57,6 +57,18 @@ def test_dw_strip_lengths(be, length, N, T, H, W, C, stride, kt):
         be.lib.fn["dev_set"](knob, 0)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,T,H,W,C,stride,kt", [c for c in DW_CASES if c[5] == 1 and c[6] == 1])
+def test_dw_fwd_six_row_bands(be, dt, N, T, H, W, C, stride, kt):
+    """small launches take two-row bands (dw2_fwd_kernel<T, 2>); the six-row form that every training layer uses is forced here"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_DW2_R, 1), "dev_set")
+    try:
+        _dw_fwd_bwd(be, dt, N, T, H, W, C, stride, kt)
+        test_dw_fwd_output_transform(be, dt, N, T, H, W, C, stride, kt)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_DW2_R, 0)
+
+
 def _dw_fwd_bwd(be, dt, N, T, H, W, C, stride, kt):
     code, tdt = DT[dt]
     g = gen(H * W + C + kt)
@@ -125,11 +137,16 @@ def test_dw_fwd_output_transform(be, dt, N, T, H, W, C, stride, kt):
     pads = (geo.same_pad(H, stride), geo.same_pad(W, stride)) if stride == 2 else ((1, 1), (1, 1))
     ref = F.silu(dw_ref(x.float(), w, stride, kt, pads) * esc.view(1, -1, 1, 1, 1) + esh.view(1, -1, 1, 1, 1))
     y = torch.full((N, T, OH, OW, C), float("nan")).to(tdt).to(be.device)
+    # (kt == 1: T == 1 in every case; the pooled means of the STORED output come out of the same pass - mds_dw_fwd_args.pool)
+    pool = torch.zeros(N, C, dtype=torch.float64, device=be.device)
     be.call("dw_fwd", cabi.make("mds_dw_fwd_args", dtype=code, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=stride, pad_t=pt,
                                 pad_l=pl, kt=kt, x=be.t(to_rows(x)), w=be.t(w.view(C, kt * 9)), y=y, pro=cabi.pro(0), stats=None,
-                                epi=cabi.make("mds_epi_t", mode=2, scale=be.t(esc), shift=be.t(esh))))
+                                epi=cabi.make("mds_epi_t", mode=2, scale=be.t(esc), shift=be.t(esh)),
+                                pool=pool, pool_inv=1.0 / (T * OH * OW)))
     be.sync()
     assert_close(y, to_rows(ref), dt, msg="y")
+    want = y.float().cpu().double().mean((1, 2, 3))
+    assert (pool.cpu() - want).abs().max() <= 2e-6 * max(1.0, float(want.abs().max())), "pooled means of the stored output"
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

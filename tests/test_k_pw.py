@@ -106,6 +106,57 @@ def test_pw_fwd_output_transform(be, dt, M, K, N, pmode, emode, res):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,N,pmode,emode,res,split", [(300, 448, 144, 0, 2, False, 3), (200, 672, 112, 4, 1, True, 5), (130, 1152, 192, 4, 1, True, 16),
+                                                      (77, 200, 48, 0, 0, False, 2), (920, 360, 192, 4, 1, False, 4)])
+def test_pw_fwd_split_k(be, dt, M, K, N, pmode, emode, res, split):
+    """split-K of the small-M inference GEMMs (mds_pw_fwd_args.split): partial tiles + ticket, the last block of a tile adds the
+    partials in z order and runs the epilogue.  Same result as the unsplit launch to rounding, bit-identical between two split
+    launches (the order of the sum is fixed), tickets back at zero afterwards, K ranges with a ragged / empty last split."""
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(M + N + split)
+    rpg = 97
+    groups = (M + rpg - 1) // rpg
+    x = torch.randn(M, K, generator=g).to(tdt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(tdt)
+    scale, shift, gate = _mk_pro(be, pmode, K, groups, g)
+    esc = 1.0 + 0.3 * torch.randn(N, generator=g); esh = 0.5 * torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g).to(tdt) if res else None
+    part = torch.full((split * M * N,), float("nan"), device=be.device)
+    tiles = -(-M // cabi.MDS_PW_SPLIT_TILE_ROWS) * -(-N // 128)
+    ticket = torch.zeros(tiles * cabi.MDS_PW_SPLIT_TICKET_STRIDE, dtype=torch.int32, device=be.device)
+    outs = []
+    for sp in (split, split, 0):
+        y = torch.full((M, N), float("nan")).to(tdt).to(be.device)
+        epi = cabi.make("mds_epi_t", mode=emode, scale=be.t(esc), shift=be.t(esh)) if emode else cabi.make("mds_epi_t", mode=0)
+        be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=be.t(x), w=be.t(w), y=y,
+                                    pro=cabi.pro(pmode, scale, shift, gate, rpg), residual=be.t(r) if res else None, stats=None, epi=epi,
+                                    split=sp, split_part=part if sp else None, split_ticket=ticket if sp else None))
+        be.sync()
+        outs.append(y.float().cpu())
+        assert int(ticket.abs().sum()) == 0, "tickets must reset themselves"
+    a = _apply_pro(x.float(), pmode, scale, shift, gate, rpg)
+    if dt == "bf16":
+        a = a.to(tdt).float()
+    ref = a @ w.float().t()
+    if emode:
+        ref = ref * esc + esh
+    if emode == 2:
+        ref = F.silu(ref)
+    if res:
+        ref = ref + r.float()
+    assert_close(outs[0], ref, dt, msg="y (split)")
+    assert torch.equal(outs[0], outs[1]), "two split launches must agree bit for bit"
+    assert_close(outs[0], outs[2], dt, msg="split vs unsplit")
+
+
+def test_pw_fwd_split_rule(be):
+    f = be.lib.fn["pw_fwd_split"]
+    assert f(920, 1152, 192, cabi.MDS_F32) >= 2 and f(3680, 672, 112, cabi.MDS_F32) >= 2       # the gated projections of one 736x1280 frame
+    assert f(18400, 1152, 192, cabi.MDS_BF16) == 1 and f(920, 192, 1152, cabi.MDS_F32) == 1     # training shapes / short K: never
+    assert all(1 <= f(m, k, n, d) <= cabi.MDS_PW_MAX_SPLIT for m in (1, 64, 920, 7360) for k in (8, 192, 1152) for n in (16, 192, 1280) for d in (0, 1))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,K,N,mode", [
     (500, 32, 64, 0),
     (333, 48, 144, 2),
