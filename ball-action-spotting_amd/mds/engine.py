@@ -989,19 +989,34 @@ class Plan:
     def bind_dlogits(self, dlogits):
         self.dlogits.tensor.copy_(dlogits.reshape(-1).float())
 
-    def begin_forward(self, mask_override=None):
-        self.zf_arena.tensor.zero_()
-        self.zf64_arena.tensor.zero_()
+    def weight_tensors(self):
+        """every tensor whose CONTENT the weight-dependent prefix of a forward reads (packed weights, eval BatchNorm table)"""
+        ts = [p for p, *_ in self.pack_jobs]
+        for m, _, _ in self.eval_bn:
+            ts += [m.weight, m.bias, m.running_mean, m.running_var]
+        return ts
+
+    def refresh_weights(self):
+        """the weight-dependent prefix of a forward: packed filter copies + the eval-mode BatchNorm table"""
+        self.pack_weights()
+        if self.eval_bn:
+            self.lib.check(self.lib.fn["bn_eval_table"](self.eval_bn_table.data_ptr(), len(self.eval_bn), self.eval_bn_maxc,
+                                                        self._stream()), "bn_eval_table")
+
+    def begin_forward(self, mask_override=None, refresh=True):
+        """refresh=False (the stream predictor): the caller runs refresh_weights() itself, and only when a parameter changed"""
+        if self.zf_arena.numel:
+            self.zf_arena.tensor.zero_()
+        if self.zf64_arena.numel:
+            self.zf64_arena.tensor.zero_()
         if self.masks:
             if mask_override is not None:
                 self.mask_arena.tensor.copy_(mask_override.to(self.device, torch.float32).view(-1))
             else:
                 r = torch.rand(self._mask_total, device=self.device)
                 self.mask_arena.tensor.copy_((r < self.mask_keep).float() / self.mask_keep)
-        self.pack_weights()
-        if self.eval_bn:
-            self.lib.check(self.lib.fn["bn_eval_table"](self.eval_bn_table.data_ptr(), len(self.eval_bn), self.eval_bn_maxc,
-                                                        self._stream()), "bn_eval_table")
+        if refresh:
+            self.refresh_weights()
 
     def begin_backward(self):
         self.zb_arena.tensor.zero_()

@@ -113,14 +113,23 @@ class StreamPredictor:
             self.f, self.tdt = f, p2d.tdt
             self.store = torch.zeros(self.nfeat, b, f, dtype=p2d.tdt, device=dev)      # [slot][orig | flipped][h*w*c]
         c = self.plans[n] = dict(p2d=p2d, ptail=ptail, g2d=None, gtail=None, warm=0, cache={})
+        c["2d_w"], c["tail_w"] = p2d.weight_tensors(), ptail.weight_tensors()
         return c
 
     def _replay(self, c, which):
         """eager for the first calls (kernel attribute opt-ins, allocator warm-up), then one hipGraph replay"""
         plan = c["p2d"] if which == "2d" else c["ptail"]
 
+        # packed weights / eval BatchNorm table: rebuilt only when a parameter or buffer was written since the last pass
+        # (tensor version counters - the module's weights are still read in place, a load_state_dict / optimizer step between
+        # two frames is picked up by the next one); kept OUT of the replayed graph
+        ver = sum(t._version for t in c[which + "_w"])
+        if c.get(which + "_ver") != ver:
+            plan.refresh_weights()
+            c[which + "_ver"] = ver
+
         def fn():
-            plan.begin_forward(None)
+            plan.begin_forward(None, refresh=False)
             if which == "2d":
                 plan.run("f2d")
             else:
@@ -176,7 +185,10 @@ class StreamPredictor:
                 results.append((None, index - self._predict_offset))
             # ring update (n <= ring length; the frames of one chunk land in distinct slots)
             assert n <= self.max_chunk, "chunk longer than the frame ring allows"
-            self.frames[torch.arange(first_index, first_index + n, device=dev) % self.nframes] = frames
+            if n == 1:
+                self.frames[first_index % self.nframes].copy_(frames[0])
+            else:
+                self.frames[torch.arange(first_index, first_index + n, device=dev) % self.nframes] = frames
             for j in range(n):
                 if self._window_ready(first_index + j):
                     ready.append(j)
@@ -217,15 +229,22 @@ class StreamPredictor:
             self.encoder_passes += 1
             fslots = [st[-1] % self.nfeat for st in todo]
             si = self._idx(c, ("fs", tuple(fslots)), fslots, dev)
-            self.store[si] = p2d.feat.tensor.view(b, n, self.f).transpose(0, 1)      # images: n originals, then their n mirrored copies
+            if n == 1:
+                self.store[fslots[0]].copy_(p2d.feat.tensor.view(b, self.f))
+            else:
+                self.store[si] = p2d.feat.tensor.view(b, n, self.f).transpose(0, 1)      # images: n originals, then their n mirrored copies
             for st, fs in zip(todo, fslots):
                 self.feat_tag[fs] = st
         slots = [[st[-1] % self.nfeat for st in sts] for sts in stacks]
         gi = self._idx(c, ("g", tuple(s_[-1] for s_ in slots)), slots, dev)              # [n][S]
-        gathered = self.store[gi]                                                          # [n][S][b][f]
-        ptail.feat.tensor.view(n, b, self.S, self.f).copy_(gathered.permute(0, 2, 1, 3))
+        if b == 1:      # no TTA: [n][S][1][f] is already the tail's [n][1][S][f] - one gather straight into its input
+            torch.index_select(self.store.view(self.nfeat, self.f), 0, gi.view(-1), out=ptail.feat.tensor.view(n * self.S, self.f))
+        else:
+            gathered = self.store[gi]                                                          # [n][S][b][f]
+            ptail.feat.tensor.view(n, b, self.S, self.f).copy_(gathered.permute(0, 2, 1, 3))
         self._replay(c, "tail")
-        probs = torch.sigmoid(ptail.logits.tensor.view(n, b, -1)).mean(dim=1)              # nn.Sigmoid, then the TTA mean
+        probs = torch.sigmoid(ptail.logits.tensor.view(n, b, -1))                          # nn.Sigmoid, then the TTA mean
+        probs = probs[:, 0] if b == 1 else probs.mean(dim=1)
         return [(probs[j], indexes[j] - self._predict_offset) for j in range(n)]
 
 

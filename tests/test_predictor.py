@@ -117,6 +117,37 @@ def test_stream_predictor_matches_reference_logic(be, tta):
     assert out is None
 
 
+def test_weights_written_between_two_frames_are_picked_up(be):
+    """the packed filter copies and the eval BatchNorm table are rebuilt only when a parameter / buffer version changed: a
+    load_state_dict (or any in-place write) between two frames must show in the very next prediction, exactly as if a fresh
+    predictor had been built on the new weights"""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    src = fill_deterministic(orc.MultiDimStacker(**kw), 7, scale=0.02)
+    other = fill_deterministic(orc.MultiDimStacker(**kw), 8, scale=0.02)
+    prod = mds.MultiDimStacker(**kw)
+    prod.load_state_dict(src.state_dict())
+    prod = prod.to(be.device)
+    if be.name == "emu":
+        prod._lib = be.lib
+    g = torch.Generator().manual_seed(3)
+    frames = [torch.randint(0, 256, (32, 64), generator=g).to(torch.uint8) for _ in range(31)]
+    stale = StreamPredictor(prod, frame_size=(64, 32), use_graphs=False)      # A: the old weights for all 31 frames
+    for i in range(31):
+        p_stale, _ = stale.predict(frames[i], i)
+    stale.close()
+    sp = StreamPredictor(prod, frame_size=(64, 32), use_graphs=False)         # B: new weights loaded before the last frame
+    for i in range(30):
+        p_old, _ = sp.predict(frames[i], i)
+    assert p_old is not None
+    prod.load_state_dict(other.state_dict())          # in-place copy_ into the same tensors: data pointers unchanged, versions bumped
+    p_new, _ = sp.predict(frames[30], 30)
+    assert not torch.equal(p_new.cpu(), p_stale.cpu()), "the new weights were not picked up"
+    # and what B returns is what the NEW tail + NEW encoder give on the stored (old-weight) features of the four older stacks:
+    # re-running the last frame changes nothing (the refresh is complete after one call, not spread over several)
+    p_again, _ = sp.predict(frames[30], 30)
+    assert torch.equal(p_new.cpu(), p_again.cpu())
+
+
 def test_chunked_prediction_encodes_every_stack_once(be):
     """windows sit 6 frames apart, so inside a chunk of 8 the newest stack of frame j is the second newest of
     frame j + 6 - the 2D encoder must run ONE pass of n stacks per chunk in steady state (it ran 2 at n = 8, 5 at n = 32)."""
