@@ -304,7 +304,8 @@ MDS_DEV DwBlock dw_block(const DwStrips& g) {
   return b;
 }
 
-template <typename T, int R>
+// POOL: the squeeze-excite pooling of inference plans (mds_dw_fwd_args.pool) - a template flag, so that the training kernels do not carry its sums
+template <typename T, int R, bool POOL = false>
 __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
   constexpr int NR = R + 2;
   typedef Pair<T> P;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
           if (oy0 + r < a.OH) {
             const raw_t pk = P::pk(epi2(acc, emode, esc, esh));
             P::str(yim + ((long)r * a.OW + ox0 + o) * C, pk);
-            s1 += acc; s2 += acc * acc; sp += P::up(pk);
+            s1 += acc; s2 += acc * acc; if (POOL) sp += P::up(pk);
           }
         }
       }
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwSt
       if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
     }
   }
-  if (a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
+  if (POOL && a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
 }
 
 // backward, same decomposition over INPUT pixels: window = dy rows iy-1..iy+R, cols ix-1..ix+1.
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwSt
 // row that needs it), the 27 taps of the channel pair are read from LDS once per column.  The LDS-tiled
 // kernel above had 216-324 blocks of five barrier-separated slices each for the whole launch.
 #define DW3_T 5
-template <typename T>
+template <typename T, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
   constexpr int TT = DW3_T;
   typedef Pair<T> P;
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
       for (int ot = 0; ot < TT; ++ot) {
         const raw_t pk = P::pk(epi2(acc[ot], emode, esc, esh));
         P::str(yim + (long)ot * tstr + (long)(ox0 + o) * C, pk);
-        s1 += acc[ot]; s2 += acc[ot] * acc[ot]; sp += P::up(pk);
+        s1 += acc[ot]; s2 += acc[ot] * acc[ot]; if (POOL) sp += P::up(pk);
       }
     }
   }
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
       if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
     }
   }
-  if (a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
+  if (POOL && a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
 }
 
 // backward: window of dy [5 slices][3 rows][3 cols] around the thread's input row; per input pixel
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void dw3_bwd_kernel(mds_dw_bwd_args a, DwSt
 // ------------------------------------------------------------------------------------ 3x3 stride 2 (TF-SAME)
 // Sliding window for the two stride-2 layers.  Forward: R = 3 output rows need 7 input rows; an output
 // column consumes two new input columns (window col 0 <- old col 2).
-template <typename T>
+template <typename T, bool POOL = false>
 __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
   constexpr int R = 3, NR = 2 * R + 1;
   typedef Pair<T> P;
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
         if (oy0 + r < a.OH) {
           const raw_t pk = P::pk(epi2(acc, emode, esc, esh));
           P::str(yim + ((long)r * a.OW + ox0 + o) * C, pk);
-          s1 += acc; s2 += acc * acc; sp += P::up(pk);
+          s1 += acc; s2 += acc * acc; if (POOL) sp += P::up(pk);
         }
       }
     }
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
       if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
     }
   }
-  if (a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
+  if (POOL && a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
 }
 
 // Backward over INPUT pixels: a thread owns 4 input rows x pairs of input columns; the dy values that
@@ -1143,20 +1144,27 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
     const int R = small ? 2 : 6;
     DwStrips g = dw_strips(images, a->OH, a->OW, a->C, R, dw2_len(images, a->OH, a->OW, a->C, R));
     dim3 grid = dw_grid(g), block(256);
-    if (small) MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 2>), grid, block, 0, stream, *a, g));
-    else MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
+    if (a->pool) {
+      if (small) MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 2, true>), grid, block, 0, stream, *a, g));
+      else MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6, true>), grid, block, 0, stream, *a, g));
+    } else {
+      if (small) MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 2>), grid, block, 0, stream, *a, g));
+      else MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_fwd_kernel<T, 6>), grid, block, 0, stream, *a, g));
+    }
     return mds_check_launch("dw_fwd");
   }
   if (a->kt == 1 && a->stride == 2 && !mds_switch(MDS_SW_DW_OLD)) {
     DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 3);
     dim3 grid = dw_grid(g), block(256);
-    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw2s_fwd_kernel<T>, grid, block, 0, stream, *a, g));
+    if (a->pool) MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2s_fwd_kernel<T, true>), grid, block, 0, stream, *a, g));
+    else MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2s_fwd_kernel<T, false>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
   if (a->kt == 3 && a->T == DW3_T && !mds_switch(MDS_SW_DW_OLD)) {
     DwStrips g = dw_strips(a->N, a->OH, a->OW, a->C, 1, dw3_len(a->N, a->OH, a->OW, a->C, 20));
     dim3 grid = dw_grid(g), block(256);
-    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_fwd_kernel<T>, grid, block, 0, stream, *a, g));
+    if (a->pool) MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw3_fwd_kernel<T, true>), grid, block, 0, stream, *a, g));
+    else MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw3_fwd_kernel<T, false>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
   MDS_DISPATCH_DTYPE(a->dtype, T, {
