@@ -149,6 +149,36 @@ def test_pw_fwd_split_k(be, dt, M, K, N, pmode, emode, res, split):
     assert_close(outs[0], outs[2], dt, msg="split vs unsplit")
 
 
+@pytest.mark.gpu
+def test_pw_fwd_split_k_handoff_under_load():
+    """the in-launch hand-off of the partial tiles (device-scope stores, barrier, ticket, device-scope loads - no fence) on the
+    hardware it was designed on: every launch reproduces the first bit for bit while a second stream streams copies through
+    HBM and the partial buffer is NaN-poisoned between launches (a stale or early read would be a NaN)"""
+    from backends import be_gpu
+    b = be_gpu()
+    dev = b.device
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device=dev); big2 = torch.empty_like(big)
+    for (M, K, N, S, code, tdt) in [(920, 1152, 192, 12, cabi.MDS_F32, torch.float32), (3680, 672, 112, 4, cabi.MDS_BF16, torch.bfloat16)]:
+        x = torch.randn(M, K, device=dev).to(tdt); w = (torch.randn(N, K, device=dev) / K ** 0.5).to(tdt)
+        y = torch.empty(M, N, device=dev, dtype=tdt)
+        part = torch.empty(S * M * N, device=dev)
+        tk = torch.zeros(-(-M // cabi.MDS_PW_SPLIT_TILE_ROWS) * -(-N // 128) * cabi.MDS_PW_SPLIT_TICKET_STRIDE, dtype=torch.int32, device=dev)
+        a = cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=x, w=w, y=y, pro=cabi.pro(0), residual=None, stats=None,
+                      split=S, split_part=part, split_ticket=tk)
+        b.call("pw_fwd", a); b.sync()
+        ref = y.clone()
+        assert torch.isfinite(ref.float()).all()
+        for it in range(300):
+            if it % 25 == 0:
+                with torch.cuda.stream(side):
+                    big2.copy_(big)
+            part.fill_(float("nan"))
+            b.call("pw_fwd", a)
+            assert torch.equal(y, ref), it
+        assert int(tk.abs().sum()) == 0
+
+
 def test_pw_fwd_split_rule(be):
     f = be.lib.fn["pw_fwd_split"]
     assert f(920, 1152, 192, cabi.MDS_F32) >= 2 and f(3680, 672, 112, cabi.MDS_F32) >= 2       # the gated projections of one 736x1280 frame
