@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backends import be, DT, assert_close  # noqa: F401
+from backends import be, be_gpu, DT, assert_close  # noqa: F401
 from mds import cabi
 
 
@@ -150,12 +150,11 @@ def test_pw_fwd_split_k(be, dt, M, K, N, pmode, emode, res, split):
 
 
 @pytest.mark.gpu
-def test_pw_fwd_split_k_handoff_under_load():
+def test_pw_fwd_split_k_handoff_under_load(be_gpu):
     """the in-launch hand-off of the partial tiles (device-scope stores, barrier, ticket, device-scope loads - no fence) on the
     hardware it was designed on: every launch reproduces the first bit for bit while a second stream streams copies through
     HBM and the partial buffer is NaN-poisoned between launches (a stale or early read would be a NaN)"""
-    from backends import be_gpu
-    b = be_gpu()
+    b = be_gpu
     dev = b.device
     side = torch.cuda.Stream()
     big = torch.empty(64 << 20, dtype=torch.float32, device=dev); big2 = torch.empty_like(big)
