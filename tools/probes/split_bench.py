@@ -1,3 +1,4 @@
+"""Developer tool (GPU box): split-K factor sweep of mds_pw_fwd on the inference shapes of one 736x1280 frame."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ball-action-spotting_amd")]
@@ -20,12 +21,8 @@ for (M, K, N, gated) in [(920, 1152, 192, 1), (3680, 672, 112, 1), (920, 192, 11
     pro = cabi.pro(4, None, None, gate, (M + 7) // 8) if gated else cabi.pro(0)
     out = []
     for S in (0, 2, 3, 4, 6, 8, 12):
-        row = []
-        for dbg in (0, 1, 2, 3, 7):
-            a = cabi.make("mds_pw_fwd_args", dtype=0, M=M, K=K, N=N, x=x, w=w, y=y, pro=pro, residual=r, stats=None,
-                          epi=cabi.make("mds_epi_t", mode=1, scale=sc, shift=sh), split=S, split_part=part if S else None, split_ticket=tk if S else None, K1=dbg if S else 0)
-            row.append(t_us(lambda: lib.call("pw_fwd", a, st())))
-            tk.zero_()
-            if not S: break
-        out.append(f"S={S}: " + " ".join(f"{v:6.1f}" for v in row))
-    print(f"M={M} K={K} N={N} gated={gated}  [full | no stores | no reduce loads | neither | neither+no ticket]\n  " + "\n  ".join(out), flush=True)
+        a = cabi.make("mds_pw_fwd_args", dtype=0, M=M, K=K, N=N, x=x, w=w, y=y, pro=pro, residual=r, stats=None,
+                      epi=cabi.make("mds_epi_t", mode=1, scale=sc, shift=sh), split=S, split_part=part if S else None, split_ticket=tk if S else None)
+        out.append(f"S={S}: {t_us(lambda: lib.call('pw_fwd', a, st())):6.1f}")
+    # (the ablation columns quoted in k_pw.hip - no partial stores / no reduce loads / no ticket - came from temporary hooks in the kernel)
+    print(f"M={M} K={K} N={N} gated={gated}  us per launch\n  " + "\n  ".join(out), flush=True)
