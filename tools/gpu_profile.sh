@@ -12,21 +12,21 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 PY=python
 BENCH="$ROOT/bench.py"
-SHORT="--steps 3 --warmup 2 --profile-steps 0 --no-cpu-baseline $EXTRA"
+SHORT="--steps 3 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-other-configs $EXTRA"   # (the child configs under --pmc took 40 GPU-minutes once)
 
 echo "== bench" ; $PY $BENCH $EXTRA > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err ; tail -c 600 $OUT/${TAG}_bench.err
 
 if [ "${SKIP_TRACE:-0}" != "1" ]; then
   echo "== kernel trace"
   rm -rf /tmp/prof_kt && mkdir -p /tmp/prof_kt
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt --output-format csv -- $PY $BENCH --steps 10 --warmup 3 --profile-steps 0 --no-cpu-baseline $EXTRA > $OUT/${TAG}_kt_bench.json 2> $OUT/${TAG}_kt.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt --output-format csv -- $PY $BENCH --steps 10 --warmup 3 --profile-steps 0 --no-cpu-baseline --no-pmc --no-other-configs $EXTRA > $OUT/${TAG}_kt_bench.json 2> $OUT/${TAG}_kt.err)
   f=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_kernel_stats.csv
 fi
 
 pmc_pass() {  # name, counters...
   local name=$1; shift
   rm -rf /tmp/prof_$name && mkdir -p /tmp/prof_$name
-  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" -d /tmp/prof_$name -o pmc --output-format csv -- $PY $BENCH $SHORT > /dev/null 2> $OUT/${TAG}_pmc_$name.err)
+  (cd /tmp && timeout 240 rocprofv3 --pmc "$@" -d /tmp/prof_$name -o pmc --output-format csv -- $PY $BENCH $SHORT > /dev/null 2> $OUT/${TAG}_pmc_$name.err)
   f=$(find /tmp/prof_$name -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_pmc_$name.csv && echo "   $name: $(wc -l < $f) rows"
 }
