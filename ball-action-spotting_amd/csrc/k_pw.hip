@@ -520,7 +520,7 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(!split || bm == 64, "pw_fwd: split-K is for small M (64-row tiles)");
   const int mt = cdiv(a->M, bm), nt = cdiv(a->N, BN);
   int gy = 1;
-  if (nt > 1) { gy = cdiv(1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
+  if (nt > 1) { gy = cdiv(mds_knob(MDS_KNOB_PW_GY) > 0 ? mds_knob(MDS_KNOB_PW_GY) : 1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
   dim3 grid(mt, gy, split ? a->split : 1), block(256);
 #define PW_GOSPLIT(T, PRO, TAIL_) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
@@ -1032,7 +1032,7 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
     const int g = kg % 10;
     if (tr && !dyp && a->pro.mode != MDS_PRO_BN_SILU_GATE && (g == 2 || g == 4) && (kg < 10 || a->M <= 20000)) G = g;
   }
-  long want_blocks = (mds_knob(MDS_KNOB_WG_BLOCKS) > 0 ? mds_knob(MDS_KNOB_WG_BLOCKS) : (G > 1 ? 256 : 128)) / tiles;
+  long want_blocks = (mds_knob(MDS_KNOB_WG_BLOCKS) > 0 ? mds_knob(MDS_KNOB_WG_BLOCKS) : (G > 1 ? 256 : 192)) / tiles;   // budget re-swept with the XCD-aligned splits: 128 / 192 / 224 / 288 -> 13.88 / 13.77 / 13.78 / 13.78 ms per step (was 128)
   if (G == 1 && want_blocks < a->M / 2048) want_blocks = a->M / 2048;
   if (G > 1 && want_blocks < a->M / 16384) want_blocks = a->M / 16384;
   if (tr && !(mds_knob(MDS_KNOB_WG_DBG) & 32)) {   // row splits in multiples of 8: split s and all its output tiles run on XCD s % 8 (see the kernel)

@@ -59,7 +59,8 @@ const char* mds_last_error(void);
 #define MDS_KNOB_DW2_L 9         /* strip length of the 3x3 stride-1 sliding-window kernels (0 = default rule) */
 #define MDS_KNOB_PW_SPLIT 10       /* split-K of the small-M inference GEMMs: 0 = rule (mds_pw_fwd_split), 1 = never, n >= 2 = at most n */
 #define MDS_KNOB_DW2_R 11          /* 1: the 3x3 stride-1 forward keeps six-row bands for small launches too (A/B) */
-#define MDS_KNOB_COUNT 12
+#define MDS_KNOB_PW_GY 12          /* block target of mds_pw_fwd when it spreads n-tiles over grid.y (0 = default 1536) */
+#define MDS_KNOB_COUNT 13
 int mds_dev_set(int knob, int value);
 
 /* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
