@@ -516,7 +516,8 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   // 64-row tiles below 400 k rows: twice the blocks for the stage-3..5 / 3D layers (isolated: -10...25 %;
   // inside the step, where the weight-gradient stream fills the idle CUs anyway, +1 %)
   // (the dy-prologue variant keeps two operand tiles in flight: its 128-row form would spill)
-  const int bm = (wn == 2 && (a->M <= 400000 || dy)) ? 64 : PW_BM;
+  const long bar64 = mds_knob(MDS_KNOB_PW_BM64) > 0 ? 1000L * mds_knob(MDS_KNOB_PW_BM64) : 400000;
+  const int bm = (wn == 2 && (a->M <= bar64 || dy)) ? 64 : PW_BM;
   MDS_REQUIRE(!split || bm == 64, "pw_fwd: split-K is for small M (64-row tiles)");
   const int mt = cdiv(a->M, bm), nt = cdiv(a->N, BN);
   int gy = 1;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 119
+#define MDS_VERSION 120
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -60,7 +60,8 @@ const char* mds_last_error(void);
 #define MDS_KNOB_PW_SPLIT 10       /* split-K of the small-M inference GEMMs: 0 = rule (mds_pw_fwd_split), 1 = never, n >= 2 = at most n */
 #define MDS_KNOB_DW2_R 11          /* 1: the 3x3 stride-1 forward keeps six-row bands for small launches too (A/B) */
 #define MDS_KNOB_PW_GY 12          /* block target of mds_pw_fwd when it spreads n-tiles over grid.y (0 = default 1536) */
-#define MDS_KNOB_COUNT 13
+#define MDS_KNOB_PW_BM64 13        /* row bar (in thousands) below which mds_pw_fwd takes 64-row tiles (0 = default 400) */
+#define MDS_KNOB_COUNT 14
 int mds_dev_set(int knob, int value);
 
 /* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
