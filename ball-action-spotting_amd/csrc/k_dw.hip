@@ -1095,7 +1095,7 @@ static int dw2_len(int images, int H, int W, int C, int R) {
   if (mds_knob(MDS_KNOB_DW2_L)) return mds_knob(MDS_KNOB_DW2_L) == 1 ? 0 : mds_knob(MDS_KNOB_DW2_L);   // 1: the former rule (dw_strips)
   const long chunks = cdiv(C, 64), bands = cdiv(H, R);
   int nseg = cdiv(W, 32);      // (never longer than 32 columns: with 132 images - the 33-frame configuration - whole 80-column rows measured 0.6 % slower per step)
-  while (cdiv(W, nseg + 1) >= 8 && cdiv((long)images * bands * nseg, 8) * chunks < 640) ++nseg;
+  while (cdiv(W, nseg + 1) >= 8 && cdiv((long)images * bands * nseg, 8) * chunks < (mds_knob(MDS_KNOB_DW2_BLOCKS) > 0 ? mds_knob(MDS_KNOB_DW2_BLOCKS) : 640)) ++nseg;
   return cdiv(W, nseg);
 }
 

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
 }
 // blocks per group of a reduce kernel: every block ends with O(C) atomics / partial stores, so it
 // must own enough rows to amortise them (8 passes made the C = 1152 layers tail-bound: 1.2 TB/s)
-static int reduce_passes() { return 32; }   // measured 8 / 16 / 32 / 64 / 128 at the four layer shapes
+static int reduce_passes() { return mds_knob(MDS_KNOB_REDUCE_PASSES) > 0 ? mds_knob(MDS_KNOB_REDUCE_PASSES) : 32; }   // measured 8 / 16 / 32 / 64 / 128 at the four layer shapes
 static inline int group_blocks(long rows, int C) {
   const long per = (long)rows_per_pass(C, row_slices(C)) * reduce_passes();
   const long b = (rows + per - 1) / per;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 120
+#define MDS_VERSION 121
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -61,7 +61,9 @@ const char* mds_last_error(void);
 #define MDS_KNOB_DW2_R 11          /* 1: the 3x3 stride-1 forward keeps six-row bands for small launches too (A/B) */
 #define MDS_KNOB_PW_GY 12          /* block target of mds_pw_fwd when it spreads n-tiles over grid.y (0 = default 1536) */
 #define MDS_KNOB_PW_BM64 13        /* row bar (in thousands) below which mds_pw_fwd takes 64-row tiles (0 = default 400) */
-#define MDS_KNOB_COUNT 14
+#define MDS_KNOB_REDUCE_PASSES 14  /* rows passes per block of the grouped reduce kernels (0 = default 32) */
+#define MDS_KNOB_DW2_BLOCKS 15     /* block target of the 3x3 stride-1 strip rule (0 = default 640) */
+#define MDS_KNOB_COUNT 16
 int mds_dev_set(int knob, int value);
 
 /* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
