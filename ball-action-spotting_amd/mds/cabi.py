@@ -71,6 +71,16 @@ DEFINES, STRUCTS, FUNCS = _parse_header(HEADER)
 globals().update(DEFINES)
 
 
+def _ctype_of(param: str):
+    """ctypes type of one parameter of a prototype in include/mds.h ("const mds_x_args* a", "mds_stream_t stream", "long M", ...)"""
+    words = param.replace("*", " * ").split()
+    words = [w for w in words[:-1] if w != "const"]          # drop the parameter name and qualifiers
+    if "*" in words:
+        return C.POINTER(STRUCTS[words[0]]) if words[0] in STRUCTS and words[0].endswith("_args") else C.c_void_p
+    scalar = {"int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double, "mds_stream_t": C.c_void_p}
+    return scalar[words[0]]
+
+
 class MdsError(RuntimeError):
     pass
 
@@ -101,20 +111,11 @@ class Lib:
                 continue
             f.restype = C.c_int
             self.fn[name[4:]] = f
-        for op in list(self.fn):
-            st = STRUCTS.get(f"mds_{op}_args") or STRUCTS.get(f"mds_{op.rsplit('_', 1)[0]}_args")   # se_fc_bwd_data -> mds_se_fc_bwd_args
-            if st is not None:
-                self.fn[op].argtypes = [C.POINTER(st), C.c_void_p]
-        if "se_bwd_reduce_blocks" in self.fn:
-            self.fn["se_bwd_reduce_blocks"].argtypes = [C.c_long, C.c_int]
-        if "pw_fwd_split" in self.fn:
-            self.fn["pw_fwd_split"].argtypes = [C.c_long, C.c_int, C.c_int, C.c_int]
-        if "pack_weights" in self.fn:
-            self.fn["pack_weights"].argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        if "dev_set" in self.fn:
-            self.fn["dev_set"].argtypes = [C.c_int, C.c_int]
-        if "bn_eval_table" in self.fn:
-            self.fn["bn_eval_table"].argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        # argument types of EVERY entry point come from the header's own prototypes: an untyped ctypes call passes a Python int as a
+        # 32-bit C int, which truncates a hipStream_t (any stream but the null stream) and crashes inside the launch
+        for name, params in FUNCS:
+            if name[4:] in self.fn:
+                self.fn[name[4:]].argtypes = [_ctype_of(p) for p in params.split(",")] if params.strip() != "void" else []
 
     def check(self, rc: int, op: str):
         if rc != 0:

@@ -190,6 +190,54 @@ def gsrc(mode, u, gate=None, dpooled=None, mask=None, rpg=0):
     return dict(_struct="mds_gsrc_t", mode=mode, u=u, gate=gate, dpooled=dpooled, mask=mask, rows_per_group=rpg)
 
 
+_MASKED = {}
+
+
+def _hip_path():
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                return line.split()[-1]
+    raise RuntimeError("libamdhip64 is not mapped in this process")
+
+
+def _masked_stream(device):
+    """MDS_SIDE_CUS=n[:stride[:first]]: the weight-gradient stream is created with a compute-unit mask (hipExtStreamCreateWithCUMask) of
+    n CUs - mask bit first + j * stride for j < n - so that its launches cannot take CU slots from the dependent chain on the
+    other CUs.  Unset / 0: an ordinary stream.  One masked stream per device (HIP has no cheap destroy for them inside a step)."""
+    spec = os.environ.get("MDS_SIDE_CUS", "0")
+    prio = os.environ.get("MDS_SIDE_PRIO", "")
+    if spec in ("", "0") and prio == "":
+        return None
+    key = (device.index, spec, prio)
+    if key not in _MASKED and spec in ("", "0"):
+        # MDS_SIDE_PRIO=<int>: an unmasked stream of that HIP priority (hipDeviceGetStreamPriorityRange: larger = lower priority)
+        import ctypes
+        hip = ctypes.CDLL(_hip_path())
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, int(prio))   # 1 = hipStreamNonBlocking
+        if rc != 0 or not h.value:
+            raise RuntimeError(f"hipStreamCreateWithPriority failed: {rc}")
+        _MASKED[key] = torch.cuda.ExternalStream(h.value, device=device)
+    if key not in _MASKED:
+        import ctypes
+        parts = [int(v) for v in spec.split(":")]
+        n, stride, first = parts[0], (parts[1] if len(parts) > 1 else 1), (parts[2] if len(parts) > 2 else 0)
+        hip = ctypes.CDLL(_hip_path())
+        words = (ctypes.c_uint32 * 8)()
+        for j in range(n):
+            b = first + j * stride
+            words[b >> 5] |= 1 << (b & 31)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+        if rc != 0 or not h.value:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+        _MASKED[key] = torch.cuda.ExternalStream(h.value, device=device)
+    return _MASKED[key]
+
+
 class Plan:
     """The recorded schedules + buffers for one configuration."""
 
@@ -946,7 +994,7 @@ class Plan:
         if self.device.type != "cuda" or os.environ.get("MDS_SIDE_STREAM", "1") == "0":
             return None
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = _masked_stream(self.device) or torch.cuda.Stream(device=self.device)
             self._side_events = []
         return self._side
 

@@ -28,6 +28,7 @@ import argparse
 import csv
 import glob
 import json
+import contextlib
 import os
 import re
 import shutil
@@ -459,14 +460,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # MDS_BENCH_STREAM=1 (developer A/B): the steps run on a non-default HIP stream, as a trainer that owns its stream would
+    own = torch.cuda.stream(torch.cuda.Stream(dev)) if os.environ.get("MDS_BENCH_STREAM", "0") == "1" else contextlib.nullcontext()
+    with own:
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

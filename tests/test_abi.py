@@ -21,6 +21,20 @@ def test_hip_library_exports_every_declared_symbol():
     assert lib.dll.mds_version() == cabi.MDS_VERSION
 
 
+def test_every_entry_point_is_typed_from_the_header():
+    """an untyped ctypes call passes Python ints as 32-bit C ints: a hipStream_t other than the null stream would be truncated
+    (round 3: mds_focal_fwd_bwd / mds_multi_* / mds_aug_pass / mds_frame_luma crashed on a non-default stream)"""
+    lib = cabi.Lib(cabi.HIP_LIB)
+    for name, params in cabi.FUNCS:
+        if name == "mds_version":
+            continue
+        f = lib.fn[name[4:]]
+        assert f.argtypes is not None, name
+        assert len(f.argtypes) == (0 if params.strip() == "void" else len(params.split(","))), name
+        if "mds_stream_t" in params:
+            assert f.argtypes[-1] is ctypes.c_void_p, name
+
+
 def test_struct_sizes_match_the_c_compiler():
     names = [n for n in cabi.STRUCTS]
     src = '#include <stdio.h>\n#include "mds.h"\nint main(void){\n' + "".join(

@@ -195,3 +195,43 @@ def test_model_ema_without_float_entries_is_a_no_op(lib):
     m.n += 4
     ema.update(m)
     assert int(ema.ema.n) == int(0.5 * 5 + 0.5 * 9)
+
+
+@pytest.mark.gpu
+def test_train_ops_run_on_a_non_default_stream():
+    """a trainer that owns its HIP stream: loss, both optimizers and the EMA are launched on torch's CURRENT stream (64-bit handle)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 2, generator=g); t = (torch.rand(64, 2, generator=g) < 0.5).float()
+    xr = x.clone().requires_grad_(True)
+    lr = orc.sigmoid_focal_loss(xr, t, alpha=-1.0, gamma=1.2, reduction="mean"); lr.backward()
+    own = torch.cuda.Stream(dev)
+    for which in ("adamw", "sgd"):
+        ps = [torch.nn.Parameter(torch.randn(33, 7, generator=g).to(dev)), torch.nn.Parameter(torch.randn(129, generator=g).to(dev))]
+        rs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+        opt = train.FusedAdamW(ps, lr=1e-2) if which == "adamw" else train.FusedSGD(ps, lr=1e-2, momentum=0.9, nesterov=True)
+        ropt = torch.optim.AdamW(rs, lr=1e-2) if which == "adamw" else torch.optim.SGD(rs, lr=1e-2, momentum=0.9, nesterov=True)
+        net = torch.nn.Linear(7, 3).to(dev)
+        ema_ref = copy.deepcopy(net).cpu()
+        with torch.cuda.stream(own):
+            xd = x.to(dev).requires_grad_(True)
+            lp = train.FocalLoss(-1.0, 1.2, "mean")(xd, t.to(dev)); lp.backward()
+            for _ in range(3):
+                for p, r in zip(ps, rs):
+                    gr = torch.randn(p.shape, generator=g)
+                    p.grad = gr.to(dev); r.grad = gr.clone()
+                opt.step(); ropt.step()
+            ema = train.ModelEma(net, decay=0.9)
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(1.0)
+            ema.update(net)
+        own.synchronize()
+        torch.testing.assert_close(lp.detach().cpu(), lr.detach(), rtol=2e-5, atol=1e-6)
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=2e-5, atol=1e-7)
+        for p, r in zip(ps, rs):
+            torch.testing.assert_close(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
+        for (k, e), (_, m0) in zip(ema.ema.state_dict().items(), ema_ref.state_dict().items()):
+            torch.testing.assert_close(e.cpu(), 0.9 * m0 + 0.1 * (m0 + 1.0), rtol=1e-5, atol=1e-6)
