@@ -286,3 +286,33 @@ def test_run_to_run_reproducibility(amp):
         assert not bad, bad[:8]
         for n in g1:      # the atomically accumulated weight gradients: same values up to fp32 summation order
             assert relerr(g2[n], g1[n], 1e-12) < (1e-2 if amp else 1e-4), n
+
+
+def test_train_step_and_predictor_on_a_non_default_stream():
+    """a caller that owns its HIP stream: every launch of the plan (both of its streams), the fused loss and the predictor follow
+    torch's CURRENT stream; same results as on the null stream (weight gradients to atomic-order noise, the rest exactly)"""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    _, prod = build_pair(kw)
+    prod.train()
+    x = torch.rand(2, 15, 128, 160, generator=torch.Generator().manual_seed(1)).to(DEV)
+    tgt = torch.tensor([[1.0, 0.0], [0.0, 1.0]]).to(DEV)
+    buffers0 = {n: b.detach().clone() for n, b in prod.named_buffers()}
+    l0, g0 = step(prod, x, tgt)
+    torch.cuda.synchronize()
+    for n, b in prod.named_buffers():       # same BatchNorm running statistics at the start of the second run
+        b.data.copy_(buffers0[n])
+    own = torch.cuda.Stream(DEV)
+    own.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(own):
+        l1, g1 = step(prod, x, tgt)
+        prod.eval()
+        with torch.no_grad():
+            e1 = prod(x).clone()
+    own.synchronize()
+    with torch.no_grad():
+        e0 = prod(x)
+    torch.cuda.synchronize()
+    assert torch.equal(l0, l1)
+    assert torch.equal(e0, e1)
+    errs = grad_errors(g1, g0)
+    assert errs[0][0] < 1e-4, errs[:3]
