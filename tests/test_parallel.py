@@ -17,7 +17,7 @@ def test_shard_windows_partitions_everything():
         assert max(map(len, parts)) - min(map(len, parts)) <= 1
 
 
-def _worker(rank, world, port, tmp, frozen=False):
+def _worker(rank, world, port, tmp, frozen=False, gpu=False):
     for p in sys.path_extra:
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -28,21 +28,25 @@ def _worker(rank, world, port, tmp, frozen=False):
     from mds import parallel as par
     from oracle import multidim_stacker_ref as orc
     from det_init import fill_deterministic
-    from hipemu.loader import load_emulator
+    dev = torch.device("cuda:0" if gpu else "cpu")       # gpu: both ranks share the box's one MI355X (gloo moves the slices)
 
     # 1. flat-buffer mean all-reduce
-    flat = torch.full((1000,), float(rank + 1))
+    flat = torch.full((1000,), float(rank + 1), device=dev)
     par.allreduce_mean_(flat)
-    assert torch.allclose(flat, torch.full((1000,), (1 + world) / 2 * 1.0))
+    assert torch.allclose(flat.cpu(), torch.full((1000,), (1 + world) / 2 * 1.0))
 
     # 2. whole module: rank-local windows + local BN, averaged gradients == mean of the oracle's
     kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
     prod = mds.MultiDimStacker(**kw)
     fill_deterministic(prod, 3 + rank, scale=0.05)          # ranks start different on purpose
-    prod._lib = load_emulator()
+    if gpu:
+        prod = prod.to(dev)                                  # the product library (libmds_hip.so), both plan streams + the comm stream
+    else:
+        from hipemu.loader import load_emulator
+        prod._lib = load_emulator()
     par.data_parallel(prod)                                  # broadcasts rank 0's state, installs the sync
     ref = orc.MultiDimStacker(**kw)
-    ref.load_state_dict(prod.state_dict())
+    ref.load_state_dict({k: v.cpu() for k, v in prod.state_dict().items()})
     ref0 = fill_deterministic(orc.MultiDimStacker(**kw), 3, scale=0.05)
     for a, b in zip(ref.state_dict().values(), ref0.state_dict().values()):
         assert torch.equal(a, b)                             # the packed broadcast made every rank equal to rank 0
@@ -54,7 +58,7 @@ def _worker(rank, world, port, tmp, frozen=False):
     xs = [torch.rand(1, 15, 64, 32, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
     tgt = torch.tensor([[1.0, 0.0]])
     prod.train()
-    orc.sigmoid_focal_loss(prod(xs[rank]), tgt, alpha=-1.0, gamma=1.2).backward()
+    orc.sigmoid_focal_loss(prod(xs[rank].to(dev)), tgt.to(dev), alpha=-1.0, gamma=1.2).backward()
     want = None
     for r in range(world):                                   # oracle on every shard, fresh copy each
         m = orc.MultiDimStacker(**kw); m.load_state_dict(ref0.state_dict()); m.train()
@@ -65,7 +69,7 @@ def _worker(rank, world, port, tmp, frozen=False):
         g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
         want = g if want is None else want + g
     want /= world
-    got = torch.cat([p.grad.flatten() for p in prod.parameters() if p.grad is not None])
+    got = torch.cat([p.grad.flatten() for p in prod.parameters() if p.grad is not None]).cpu()
     assert got.numel() == want.numel() and (not frozen or all(p.grad is None for p in prod.conv2d_encoder.parameters()))
     err = (got - want).abs().max().item() / want.abs().max().item()
     assert err < 1e-3, err
@@ -102,6 +106,27 @@ def test_gloo_gradients_match_mean_of_oracle(tmp_path, world, frozen):
         assert p.exitcode == 0
 
 
-def _spawn_entry(rank, world, port, tmp, paths, frozen=False):
+def _spawn_entry(rank, world, port, tmp, paths, frozen=False, gpu=False):
     sys.path_extra = paths
-    _worker(rank, world, port, tmp, frozen)
+    _worker(rank, world, port, tmp, frozen, gpu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frozen", [False, True])
+def test_world2_sharing_one_gpu_gradients_match_mean_of_oracle(tmp_path, frozen):
+    """world size 2 on the HIP path itself: two processes, each with its own window shard, both on the box's single MI355X
+    (RCCL refuses two ranks on one device, so the slices travel over gloo): the plan's two streams, the communication stream's
+    waits and the in-place sliced all-reduce run for real; averaged gradients == mean of the oracle's per-shard gradients"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    sys.path_extra = [p for p in sys.path if "repo" in p]
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = []
+    for r in range(2):
+        p = ctx.Process(target=_spawn_entry, args=(r, 2, port, str(tmp_path), sys.path_extra, frozen, True))
+        p.start(); procs.append(p)
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
