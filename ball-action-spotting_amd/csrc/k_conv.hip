@@ -267,9 +267,10 @@ struct CvqGeom {
 
 template <typename T, int MF, int NFR> struct CvqOcc { static const int v = (sizeof(T) == 4 || MF * NFR >= 8 || NFR == 4) ? 2 : 3; };
 
-template <typename T, bool HASPRO, int IS, int MF, int NFR>
+// X3 (fp32 inference plans, a.epi.mode != NONE): split-bf16 products, see Mma<float, true> in platform.h
+template <typename T, bool HASPRO, int IS, int MF, int NFR, bool X3 = false>
 __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kernel(mds_conv_fwd_args a, CvqGeom gq) {
-  typedef typename Frag<T>::type frag_t;
+  typedef Mma<T, X3> MM;
   constexpr int TA = 4 * MF, BNQ = 16 * NFR, MAXX = CVQ_MAXX;
   MDS_DYN_SMEM(smem);
   const int Cin = a.Cin, Cout = a.Cout, K = a.ntaps * Cin, KS = gq.KS, TW = gq.TW;
@@ -399,15 +400,15 @@ __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kerne
       for (int s = s0; s < s1; ++s) {
         const int xo = xo_next;   // the tap-offset lookup of step s+1 is issued a step ahead
         xo_next = ktab[4 * (s + 1 < s1 ? s + 1 : s) + q];
-        frag_t xf[MF], wf[NFR];
+        typename MM::frag xf[MF], wf[NFR];
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) xf[mf] = ld_frag(xs + xbase[mf] + xo);
+        for (int mf = 0; mf < MF; ++mf) xf[mf] = MM::prep(ld_frag(xs + xbase[mf] + xo));
 #pragma unroll
-        for (int nf = 0; nf < NFR; ++nf) wf[nf] = ld_frag(ws + wbase + 16 * nf * LDW + 32 * s);   // rows past Cout are zeros
+        for (int nf = 0; nf < NFR; ++nf) wf[nf] = MM::prep(ld_frag(ws + wbase + 16 * nf * LDW + 32 * s));   // rows past Cout are zeros
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) mma16(wf[nf], xf[mf], acc[mf][nf]);
+          for (int mf = 0; mf < MF; ++mf) MM::mma(wf[nf], xf[mf], acc[mf][nf]);
       }
       const int gA = gq.gA[g], gB = gq.gB[g], goy = gq.goy[g], gox = gq.gox[g];
 #pragma unroll
@@ -555,7 +556,12 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
       if (want < 1) want = 1;
       gq.tpb = (int)cdiv(total, want < total ? want : total);
       dim3 pgrid(cdiv(total, gq.tpb), nt);
-#define CVQ_GO3(T, HP, IS_, MF_, NF_) MDS_LAUNCH((conv_fwd_q_kernel<T, HP, IS_, MF_, NF_>), pgrid, block, smem, stream, *a, gq)
+      const bool x3 = MDS_EVAL_X3 && a->dtype == MDS_F32 && a->epi.mode != MDS_EPI_NONE;
+#define CVQ_GO3(T, HP, IS_, MF_, NF_)                                                                                           \
+  do {                                                                                                                          \
+    if (x3) MDS_LAUNCH((conv_fwd_q_kernel<T, HP, IS_, MF_, NF_, (sizeof(T) == 4)>), pgrid, block, smem, stream, *a, gq);       \
+    else MDS_LAUNCH((conv_fwd_q_kernel<T, HP, IS_, MF_, NF_, false>), pgrid, block, smem, stream, *a, gq);                     \
+  } while (0)
 #define CVQ_GO2(T, HP, IS_, MF_) do { if (NFRs == 4) CVQ_GO3(T, HP, IS_, MF_, 4); else if (NFRs == 2) CVQ_GO3(T, HP, IS_, MF_, 2); else CVQ_GO3(T, HP, IS_, MF_, 1); } while (0)
 #define CVQ_GO(T, HP)                                                                   \
   do {                                                                                  \

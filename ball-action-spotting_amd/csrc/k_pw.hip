@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
   static_assert(!TWO || (PRO == MDS_PRO_NONE && !DEEP && TAIL != 2), "two operand pairs: plain prologue, no output transform");
   constexpr bool POST = TAIL == 1, EPI = TAIL == 2;
   typedef typename Frag<T>::type frag_t;
+  typedef Mma<T, EPI && sizeof(T) == 4 && MDS_EVAL_X3> MM;   // inference plans in fp32: split-bf16 products (platform.h)
   constexpr int KC = PwCfg<T>::KC, LD = PwCfg<T>::LD, VPR = KC / 8, RPP = 256 / VPR, NL = BM / RPP;
   constexpr int BN = 64 * WN, MFW = (WN == 2 ? BM / 32 : BM / 64), NLW = BN / RPP;   // tile columns, m-fragments per wave, filter rows per thread
   MDS_DYN_SMEM(smem);
@@ -262,14 +263,14 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
 #pragma unroll
       for (int ks = 0; ks < KC / 32; ++ks) {
         if (DEEP || ks < ksteps) {   // DEEP: no branch between a refill and its wait (channels past K are staged as zeros)
-          frag_t xf[MFW];
+          typename MM::frag xf[MFW];
 #pragma unroll
-          for (int mf = 0; mf < MFW; ++mf) xf[mf] = ld_frag(xs + (16 * MFW * wm + 16 * mf + i) * LD + 32 * ks + 8 * q);
+          for (int mf = 0; mf < MFW; ++mf) xf[mf] = MM::prep(ld_frag(xs + (16 * MFW * wm + 16 * mf + i) * LD + 32 * ks + 8 * q));
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) {   // no "nf < nfr" test here: filter rows past N are staged as zeros,
-            frag_t wf = ld_frag(ws + (64 * wn + 16 * nf + i) * LD + 32 * ks + 8 * q);   // and a branch-free k-loop schedules better
+            const typename MM::frag wf = MM::prep(ld_frag(ws + (64 * wn + 16 * nf + i) * LD + 32 * ks + 8 * q));   // and a branch-free k-loop schedules better
 #pragma unroll
-            for (int mf = 0; mf < MFW; ++mf) mma16(wf, xf[mf], acc[mf][nf]);  // acc[r] = y[m = i][n = 4q + r]
+            for (int mf = 0; mf < MFW; ++mf) MM::mma(wf, xf[mf], acc[mf][nf]);  // acc[r] = y[m = i][n = 4q + r]
           }
         }
       }

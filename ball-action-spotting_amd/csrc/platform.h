@@ -100,6 +100,46 @@ template <> struct Frag<float> { typedef f32x8 type; };
 // Orders one wave's own LDS traffic (lane A's write, lane B's read) without a block barrier: the LDS unit runs a wave's
 // DS instructions in order, so only the compiler (and the simulator's lane interleaving) must be held back.
 
+// Split-precision product for the fp32 INFERENCE plans (X3): every fp32 operand is split in registers into two bf16 values,
+// a = hi + lo with hi = bf16(a), lo = bf16(a - hi) (16 significant bits together), and a fragment product is three bf16 MFMAs
+// lo*hi + hi*lo + hi*hi accumulated in fp32 - the dropped lo*lo term and the residual of the split are <= 2^-16 of a product
+// (the exact-fp32 path issues eight v_mfma_f32_16x16x4_f32 per fragment pair at 1/16 of the bf16 rate: 2048 against 3 x 16 clocks;
+// the split costs 3 VALU ops per element).  The fragment layout does not change: lane (i, q) holds k = 8q .. 8q+7 of row i in
+// both forms.  Training plans (TAIL != EPI) and every bf16 kernel use Mma<T, false> = the plain mma16.
+#ifndef MDS_EVAL_X3
+#define MDS_EVAL_X3 1     /* 0: inference plans keep the exact fp32 MFMA (library A/B) */
+#endif
+struct FragX3 { u16x8 hi, lo; };
+MDS_DEV FragX3 split_x3(const f32x8& v) {
+  u32x4 h, l;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = v[2 * p], b = v[2 * p + 1];
+    const uint32_t hh = pack2(a, b);
+    const float ha = __builtin_bit_cast(float, hh << 16), hb = __builtin_bit_cast(float, hh & 0xffff0000u);
+    h[p] = hh;
+    l[p] = pack2(a - ha, b - hb);
+  }
+  FragX3 r;
+  r.hi = __builtin_bit_cast(u16x8, h);
+  r.lo = __builtin_bit_cast(u16x8, l);
+  return r;
+}
+template <typename T, bool X3> struct Mma {
+  typedef typename Frag<T>::type frag;
+  static MDS_DEV frag prep(const typename Frag<T>::type& f) { return f; }
+  static MDS_DEV void mma(const frag& a, const frag& b, f32x4& c) { mma16(a, b, c); }
+};
+template <> struct Mma<float, true> {
+  typedef FragX3 frag;
+  static MDS_DEV frag prep(const f32x8& f) { return split_x3(f); }
+  static MDS_DEV void mma(const frag& a, const frag& b, f32x4& c) {
+    mma16(a.lo, b.hi, c);
+    mma16(a.hi, b.lo, c);
+    mma16(a.hi, b.hi, c);
+  }
+};
+
 MDS_DEV void frag_from8(u16x8& f, const float (&v)[8]) { f = pack8(v); }
 MDS_DEV void frag_from8(f32x8& f, const float (&v)[8]) { f = (f32x8){v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}; }
 MDS_DEV void frag_zero(u16x8& f) { f = (u16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
