@@ -228,8 +228,8 @@ def pmc_for(dom, extra_args):
     """HBM traffic per launch of kernel family `dom` (FETCH_SIZE and WRITE_SIZE in separate passes, KiB units,
     FETCH_SIZE x2 on gfx950 — MI355X_MICROARCH.md §HBM) and its MFMA-busy / wave-cycle split."""
     res = {"traffic": None}
-    f = pmc_child(["FETCH_SIZE"], extra_args)
-    w = pmc_child(["WRITE_SIZE"], extra_args)
+    f = pmc_child(["FETCH_SIZE"], extra_args) or pmc_child(["FETCH_SIZE"], extra_args)      # (one retry: a counter pass on a fresh box
+    w = pmc_child(["WRITE_SIZE"], extra_args) or pmc_child(["WRITE_SIZE"], extra_args)      #  occasionally comes back without its csv)
     if f and w and dom in f and dom in w:
         res["traffic"] = int(f[dom]["FETCH_SIZE"] * 1024 * 2 + w[dom]["WRITE_SIZE"] * 1024)
         nsteps = 3.0      # the child runs 1 warm-up + 2 timed steps
