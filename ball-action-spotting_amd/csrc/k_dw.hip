@@ -304,9 +304,13 @@ MDS_DEV DwBlock dw_block(const DwStrips& g) {
   return b;
 }
 
+#ifndef MDS_DW2F_OCC
+#define MDS_DW2F_OCC 3   /* blocks per CU the bf16 / two-row variants of dw2_fwd are compiled for (library A/B) */
+#endif
 // POOL: the squeeze-excite pooling of inference plans (mds_dw_fwd_args.pool) - a template flag, so that the training kernels do not carry its sums
 template <typename T, int R, bool POOL = false>
-__global__ __launch_bounds__(256, 3) void dw2_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
+// (fp32 six-row bands at 168 VGPRs spilled 56-63 registers: 1.3-1.5 TB/s in the fp32 inference plans; two blocks per CU for that variant)
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && R == 6) ? 2 : MDS_DW2F_OCC) void dw2_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
   constexpr int NR = R + 2;
   typedef Pair<T> P;
   typedef typename P::raw_t raw_t;
