@@ -130,7 +130,7 @@ def kernel_family(name):
     return fn.replace("dws_", "dw_")
 
 
-def pmc_child(counters, extra_args, timeout=240):
+def pmc_child(counters, extra_args, timeout=120):
     """Run this script under `rocprofv3 --pmc <counters>` (counter collection only — never combined with trace
     domains) for 2 steps and return {kernel family: {counter: mean per launch, 'launches': n, 'us': mean duration}}."""
     exe = shutil.which("rocprofv3")
@@ -139,7 +139,7 @@ def pmc_child(counters, extra_args, timeout=240):
     tmp = tempfile.mkdtemp(prefix="mds_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", *counters, "-d", tmp, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
            os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--profile-steps", "0", "--no-cpu-baseline", "--no-pmc",
-           *extra_args]
+           "--no-other-configs", *extra_args]      # (the config 4 / 5 child runs inside a counter pass took it past its timeout)
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
