@@ -219,8 +219,10 @@ def test_fp32_and_bf16_batch4_bench_shape_vs_oracle():
     orc.sigmoid_focal_loss(l32, tgt, alpha=-1.0, gamma=1.2).backward()
     errs32 = sorted(((_rel(p.grad, gr[n], floor), n) for n, p in ref32.named_parameters()), reverse=True)
     print("batch-4 bench shape, worst gradient errors vs float64: HIP fp32", errs[:4], "torch fp32", errs32[:4])
-    # bar: 1e-3 (north_star), or - for the cancellation-dominated BatchNorm-bias sums - 1.5x torch's own fp32 deviation
-    assert errs[0][0] < max(1e-3, 1.5 * errs32[0][0]), (errs[:6], errs32[:6])
+    # bar: 1e-3 (north_star) for every parameter but at most two cancellation-dominated BatchNorm-bias sums, which stay below
+    # 1.5e-3 (measured 1.18e-3 on every run - the sums are fp64 and ordered; torch's own fp32 run of this step: 1.80e-3 on the
+    # same parameter with 32 host threads, printed above, not asserted: it depends on the host's thread count)
+    assert errs[0][0] < 1.5e-3, (errs[:6], errs32[:6])
     assert sum(e > 1e-3 for e, _ in errs) <= 2, errs[:6]
     for (n, b), (_, b2) in zip(ref.named_buffers(), prod.named_buffers()):
         assert _rel(b2, b, 1e-6) < 1e-3, n
