@@ -117,6 +117,22 @@ class BNL:
         self.bwd_finalize(pb, seg, frozen)
         pb.op(seg, "bn_bwd_apply", dtype=pb.code, M=self.count, C=self.C, g=gsrc, y=y, bn=self.buf, coef=self.coef, dy=dy)
 
+    def backward_wg(self, pb, seg, gsrc, y, dy, x, K, dw, wide_act, group_rows=0):
+        """finalize + the apply pass that also accumulates a 1x1 weight gradient (mds_bn_bwd_apply_wg): dW[c][k] = sum_m wide[m][c] x[m][k]
+        with wide = dy (wide_act 0) or silu(bn(y)) * gate (wide_act 1); the slabs' partial tiles are added into `dw` by a finishing
+        launch on the second stream.  The sums were taken by the producer of the gradient source (reduce=False callers only)."""
+        self.bwd_finalize(pb, seg, False)
+        slabs = int(pb.lib.fn["bn_bwd_apply_wg_slabs"](int(self.count), int(self.C), int(K), int(group_rows)))
+        assert slabs > 0
+        part = pb.f32(slabs * self.C * K)
+        pb.op(seg, "bn_bwd_apply_wg", dtype=pb.code, M=self.count, C=self.C, g=gsrc, y=y, bn=self.buf, lin=self.lin, dy=dy, K=K, x=x,
+              wide_act=wide_act, group_rows=group_rows, slabs=slabs, part=part)
+        pb.op(seg, "wg_finish", C=self.C, K=K, slabs=slabs, transpose=wide_act, part=part, dw=dw)
+
+    @staticmethod
+    def wg_ok(C, K):
+        return (C % 64 == 0 or C % 96 == 0) and K in (48, 96, 112, 192)
+
     def backward_fused(self, pb, seg, gsrc, y, reduce=True, frozen=False):
         """reduce (unless the producer of u took the sums) / finalize; returns the dy-prologue descriptor that the
         consumers of dy evaluate on load (mds_dyp_t) — no apply pass, no dy tensor.  gsrc: PLAIN or MASK."""
@@ -180,6 +196,8 @@ def op_cost(name, kw, es):
     if name in ("se_bwd_reduce", "bn_bwd_reduce"):
         n = g("M") * g("C") if name == "bn_bwd_reduce" else g("groups") * g("rows_per_group") * g("C")
         return 2 * n * es, 10 * n
+    if name == "bn_bwd_apply_wg":      # the apply pass's three wide operands + the narrow operand once + the partial tiles
+        return 3 * g("M") * g("C") * es + g("M") * g("K") * es + g("slabs") * g("C") * g("K") * 4, 2 * g("M") * g("C") * g("K") + 12 * g("M") * g("C")
     if name in ("bn_bwd_apply", "gem_bwd"):
         n = g("M") * g("C") if name == "bn_bwd_apply" else g("groups") * g("rows_per_group") * g("C")
         return 3 * n * es, 12 * n
@@ -262,6 +280,9 @@ class Plan:
         # vs 244 windows/s), kept with their tests.  0 = every reduce and apply is its own launch.
         self.fuse_mode = int(os.environ.get("MDS_FUSE_BN_BWD", "3"))
         self.fuse_bn_bwd = self.fuse_mode >= 1
+        # MDS_WG_RIDE (bit 0: BN1 / conv_pw, bit 1: BN2 / conv_pwl): the 1x1 weight gradients of the inverted-residual blocks ride on
+        # the BatchNorm-backward apply passes (mds_bn_bwd_apply_wg) instead of re-reading the wide tensors on the second stream
+        self.wg_ride = int(os.environ.get("MDS_WG_RIDE", "3"))
         self.bn1_lin = int(os.environ.get("MDS_BN1_LIN", "0"))      # 0 = off; else the smallest rows x channels the linear form is used for
         # inference plans (eval-mode BatchNorm, no gradient): producers store activated outputs (mds_epi_t)
         self.eval_epilogues = (not training) and (not need_grad) and os.environ.get("MDS_EVAL_EPI", "1") == "1"
@@ -483,11 +504,11 @@ class Plan:
                             wi=wi, **common)
         return dxb
 
-    def _pw_bwd(self, seg, xin, pro, M, K, N_, wparam, dy, need_dx, residual=None, frozen=False, head=None):
+    def _pw_bwd(self, seg, xin, pro, M, K, N_, wparam, dy, need_dx, residual=None, frozen=False, head=None, wgrad=True):
         """wgrad (+ dgrad) of a 1x1 conv y[M][N] = pro(x)[M][K] w^T.  `dy` is a materialised tensor or a dy-prologue
         descriptor (BNL.backward_fused); `head`: take the next BatchNorm backward's sums in the dgrad epilogue."""
         fused = isinstance(dy, dict)
-        if not frozen:
+        if not frozen and wgrad:
             self.op(seg, "pw_wgrad", dtype=self.code, M=M, K=K, N=N_, x=xin, dy=None if fused else dy, dw=self.grad(wparam),
                     pro=pro or dict(mode=0), **({"dyp": dy} if fused else {}))
         if not need_dx:
@@ -584,7 +605,9 @@ class Plan:
             else:       # (mode 3: only the sums move into the producer's epilogue; dy stays materialised)
                 dy3 = self.act(Mout, cout)
                 bn3.backward(self, seg, g3, y3, dy3, reduce=dout.reduced is not bn3, frozen=frozen)
-            u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen).buf
+            ride2 = bool(self.wg_ride & 2) and not frozen and not isinstance(dy3, dict) and BNL.wg_ok(mid, cout) and Mout % rpg == 0
+            ride1 = bool(self.wg_ride & 1) and not frozen and BNL.wg_ok(mid, cin) and not (fuse and self.fuse_mode == 1) and not self.bn1_lin
+            u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen, wgrad=not ride2).buf
             dgate, dpool = self.zero_bwd64(groups * mid), self.f32(groups * mid)
             nblk = self.lib.fn["se_bwd_reduce_blocks"](rpg, mid)
             bnsums = self.f32(groups * nblk * 4 * mid)
@@ -602,7 +625,11 @@ class Plan:
             self.op(seg, "se_fc_bwd_data", _struct="mds_se_fc_bwd_args", **sekw)
             self.op(seg, "se_fc_bwd_params", _struct="mds_se_fc_bwd_args", **sekw)     # parameter gradients: second stream
             dy2 = self.act(Mout, mid)
-            bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, reduce=False, frozen=frozen)
+            if ride2:     # BN2's apply pass also accumulates dW(conv_pwl) = (silu(z2) * gate)^T dy3
+                bn2.backward_wg(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, dy3, cout,
+                                self.grad(blk.conv_pwl.weight), 1, group_rows=rpg)
+            else:
+                bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, reduce=False, frozen=frozen)
             g1 = self.act(Min, mid)
             self.op(seg, "dw_bwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
                     pad_l=pl, kt=kt, x=y1, dy=dy2, w=wdw, g=g1, dw=self.f32(mid * kt * 9) if frozen else self.grad(blk.conv_dw.weight),
@@ -626,11 +653,14 @@ class Plan:
                     self.op(seg, "bn_bwd_apply", dtype=self.code, M=Min, C=mid, g=gsrc(G_PLAIN, g1), y=y1, bn=bn1.buf, coef=bn1.coef, dy=dy1, _side=1)
                     self.op(seg, "pw_wgrad", dtype=self.code, M=Min, K=cin, N=mid, x=xin, dy=dy1, dw=self.grad(blk.conv_pw.weight), pro=dict(mode=0))
                 return Grad(dx, nxt_head["bn"] if nxt_head is not None else None)
+            elif ride1:   # BN1's apply pass also accumulates dW(conv_pw) = dy1^T x
+                dy1 = self.act(Min, mid)
+                bn1.backward_wg(self, seg, gsrc(G_PLAIN, g1), y1, dy1, xin, cin, self.grad(blk.conv_pw.weight), 0)
             else:
                 dy1 = self.act(Min, mid)
                 bn1.backward(self, seg, gsrc(G_PLAIN, g1), y1, dy1, reduce=False, frozen=frozen)
             return self._pw_bwd(seg, xin, None, Min, cin, mid, blk.conv_pw.weight, dy1, True,
-                                residual=dout.buf if has_skip else None, frozen=frozen, head=nxt_head)
+                                residual=dout.buf if has_skip else None, frozen=frozen, head=nxt_head, wgrad=not ride1)
 
         bwd.head = bn3.head(y3, POST_MASK if mask is not None else POST_PLAIN, mask, rpg)
         bwd.lo = self._lo(blk)
@@ -938,7 +968,7 @@ class Plan:
 
     # (the stem's weight gradient stays on the dependent chain: it is its last launch, and the second stream still has the first
     #  3x3 layer's weight gradient to finish - 14.30 vs 14.35 ms per step)
-    SIDE_OPS = ("pw_wgrad", "conv_wgrad", "se_fc_bwd_params")
+    SIDE_OPS = ("pw_wgrad", "conv_wgrad", "se_fc_bwd_params", "wg_finish")
     BUCKET_ELEMS = 1_500_000
 
     def _lo(self, *mods_or_params):
