@@ -13,8 +13,8 @@
 // per wave (~0.2 us); the accumulator tile leaves once per block as a plain store into part[slab] (no atomics), and
 // mds_wg_finish adds the slabs in order on the second stream.
 //
-// Pipeline: two register sets, so that the loads of step s+1 are in flight while step s is formed / staged / multiplied;
-// the steady-state loop is branch-free (full 64-row steps only, refills from clamped step indices) so that the compiler can
+// Pipeline: a ring of register sets for the wide pair (3-4 steps requested ahead) + one set for the narrow operand; the
+// steady-state loop is branch-free (full 64-row steps only, refills from clamped step indices) so that the compiler can
 // count its vmcnt waits ("a register ring only exists if the compiler can count it"); the ragged last step of a
 // slab runs once, guarded, after the loop.
 #include "gemm.h"
@@ -58,19 +58,27 @@ template <> MDS_DEV void bwg_st8<float>(float* gp, float* lp, const float (&dv)[
   store8(lp, same ? dv : wv);
 }
 
+// Wave roles.  vmcnt retires in order, so a wave that waits for ANY load has waited for every older one: a wave that both
+// streams the wide pair (HBM: the bytes that must stay in flight) and fetches the narrow rows (L2 hits, consumed one step
+// later) can never hold more than one step of wide rows outstanding (first version: 3.3 TB/s; a six-deep wide ring in the
+// same waves: no better - every wait for the narrow rows drained it).  So the block is two groups of four waves with their
+// own counters: the WIDE waves keep a ring of NS steps of (g, y) rows requested ahead, form dy, store it and stage the wide
+// operand; the NARROW waves fetch and stage the narrow operand's rows one step ahead; after the barrier all eight waves
+// multiply (wave = (half of the wide fragments, every fourth narrow fragment)).  Both groups execute the same barrier sequence.
 template <typename T, int CW, int K, bool SE>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 || (CW == 96 && K == 192 && SE)) ? 1 : 2) void bn_bwd_apply_wg_kernel(mds_bn_bwd_apply_wg_args a, int nchunks, int splits, int rows_per_slab, long gr) {
+__global__ __launch_bounds__(512, (sizeof(T) == 4 || SE) ? 1 : 2) void bn_bwd_apply_wg_kernel(mds_bn_bwd_apply_wg_args a, int nchunks, int splits, int rows_per_slab, long gr) {
   constexpr int ES = sizeof(T);
   constexpr int LW = bwg_pitch(CW, ES), LX = bwg_pitch(K, ES);
   constexpr int WCH = CW / 8, WR = (256 / WCH) >= 32 ? 32 : 16, WP = BWG_ROWS / WR;   // 8-channel chunks per row, rows per pass, passes
   constexpr bool ALLW = WCH * WR == 256;
-  constexpr int XV = K / 8, NX = BWG_ROWS * XV, XI = (NX + 255) / 256;
-  constexpr int NFW = CW / 16, KF = K / 16, KFW = (KF + 3) / 4;
+  constexpr int XV = K / 8, XP = (XV + 3) / 4;
+  constexpr int NFW = CW / 16, NFH = NFW / 2, KF = K / 16, KFW = (KF + 3) / 4;
+  constexpr int NS = ES == 2 ? (CW == 64 ? 4 : 2) : (CW == 64 ? 2 : 1);      // wide ring depth (registers: NS * WP * 2 vectors)
   typedef typename Frag<T>::type frag_t;
   MDS_DYN_SMEM(smem);
   T* ws = (T*)smem;                 // [64][LW]  the wide operand of the weight gradient (dy, or silu(z)*gate)
   T* xs = ws + BWG_ROWS * LW;       // [64][LX]  the narrow operand's rows
-  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6), role = MDS_UNIFORM(tid >> 8), t = tid & 255;
   const int i = lane & 15, q = lane >> 4;
   // block -> (slab, chunk): the chunk blocks of one slab are consecutive on ONE XCD (they share the narrow operand's rows)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -81,176 +89,199 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 || (CW == 96 && K == 192 && SE
   long mend = mbeg + rows_per_slab;
   if (mend > (long)(grp + 1) * gr) mend = (long)(grp + 1) * gr;
   const int C = a.C;
-  const int wc = tid % WCH, wr = tid / WCH;
-  const bool wact = ALLW || wr < WR;
-  const int c0 = chunk * CW + 8 * (wact ? wc : 0);
+  const long nrows = mend - mbeg;
+  const int nfull = (int)(nrows / BWG_ROWS), nrem = (int)(nrows - (long)nfull * BWG_ROWS);
 
-  float cA[8], cB[8], cD[8], sc[8], sh[8], ga[8], dp[8];
-  load8f(a.lin + c0, cA); load8f(a.lin + C + c0, cB); load8f(a.lin + 2 * C + c0, cD);
-  if (SE) {
-    load8f(a.bn + c0, sc); load8f(a.bn + C + c0, sh);
-    load8f(a.g.gate + (long)grp * C + c0, ga); load8f(a.g.dpooled + (long)grp * C + c0, dp);
-  }
-  // one row of the wide pair -> dy (stored) and the weight gradient's wide operand
-  auto form = [&](const float (&u)[8], const float (&yv)[8], float (&dv)[8], float (&wv)[8]) {
+  const int wh = (wave >> 2) & 1, wx = wave & 3;   // this wave's MFMA share: wide fragments [wh * NFH, wh * NFH + NFH), narrow fragments wx + 4 jv
+  f32x4 acc[NFH][KFW];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (SE) {
-        const float z = yv[j] * sc[j] + sh[j], s = sigmoidf_(z);
-        const float gg = (u[j] * ga[j] + dp[j]) * (s * (1.0f + z * (1.0f - s)));
-        dv[j] = cA[j] * gg + cB[j] * yv[j] + cD[j];
-        wv[j] = z * s * ga[j];
-      } else {
-        dv[j] = cA[j] * u[j] + cB[j] * yv[j] + cD[j];
-      }
-    }
-  };
-
-  // per-thread staging constants of the narrow operand (items past the tile alias earlier ones: same data to the same LDS
-  // address - harmless, and the loop stays branch-free)
-  int xoff[XI], xlds[XI], xrow[XI];
-#pragma unroll
-  for (int p = 0; p < XI; ++p) {
-    int it = tid + 256 * p;
-    if (it >= NX) it -= NX;
-    xrow[p] = it / XV;
-    xoff[p] = xrow[p] * K + 8 * (it % XV);
-    xlds[p] = xrow[p] * LX + 8 * (it % XV);
-  }
-  const int wstride = WR * C;
-  const int wlds = (wact ? wr : 0) * LW + 8 * wc;
-
-  f32x4 acc[NFW][KFW];
-#pragma unroll
-  for (int u = 0; u < NFW; ++u)
+  for (int u = 0; u < NFH; ++u)
 #pragma unroll
     for (int v = 0; v < KFW; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   auto mfma_step = [&]() {
 #pragma unroll
     for (int ks = 0; ks < BWG_ROWS / 32; ++ks) {
-      frag_t wf[NFW];
+      // every fragment of the k-step is requested before the first MFMA (one LDS latency per k-step, not one per operand)
+      frag_t wf[NFH], xf[KFW];
 #pragma unroll
-      for (int u = 0; u < NFW; ++u) wf[u] = BwgFrag<T>::ld(ws, LW, ks, 16 * u, i, q);
+      for (int u = 0; u < NFH; ++u) wf[u] = BwgFrag<T>::ld(ws, LW, ks, 16 * (wh * NFH + u), i, q);
 #pragma unroll
       for (int jv = 0; jv < KFW; ++jv) {
-        const int v = wave + 4 * jv;
-        if (v < KF) {       // wave-uniform
-          const frag_t xf = BwgFrag<T>::ld(xs, LX, ks, 16 * v, i, q);
+        const int v = wx + 4 * jv;
+        xf[jv] = BwgFrag<T>::ld(xs, LX, ks, 16 * ((KF % 4 == 0 || v < KF) ? v : 0), i, q);
+      }
 #pragma unroll
-          for (int u = 0; u < NFW; ++u) mma16(wf[u], xf, acc[u][jv]);   // acc[r] = P[c = 16u + 4q + r][k = 16v + i]
+      for (int jv = 0; jv < KFW; ++jv) {
+        if (KF % 4 == 0 || wx + 4 * jv < KF) {       // wave-uniform
+#pragma unroll
+          for (int u = 0; u < NFH; ++u) mma16(wf[u], xf[jv], acc[u][jv]);   // acc[r] = P[c = 16(wh NFH + u) + 4q + r][k = 16v + i]
         }
       }
     }
   };
 
-  struct Regs { RawV8<T> g[WP], y[WP], x[XI]; };
-  const T* gsrc_ = (const T*)a.g.u;
-  const T* ysrc_ = (const T*)a.y;
-  const T* xsrc_ = (const T*)a.x;
-  T* dydst_ = (T*)a.dy;
-  const long nrows = mend - mbeg;
-  const int nfull = (int)(nrows / BWG_ROWS), nrem = (int)(nrows - (long)nfull * BWG_ROWS);
-  const long wbase = (mbeg + (wact ? wr : 0)) * C + c0;
-  const T* pg = gsrc_ + wbase;        // running pointers of the NEXT step to request
-  const T* py = ysrc_ + wbase;
-  const T* px = xsrc_ + mbeg * K;
-  T* pd = dydst_ + wbase;             // running pointer of the NEXT step to store
-  auto issue = [&](Regs& R) {
-    if (wact) {
-#pragma unroll
-      for (int p = 0; p < WP; ++p) { R.g[p].ld(pg + p * wstride); R.y[p].ld(py + p * wstride); }
+  if (role == 0) {
+    // ------------------------------------------------------------ WIDE waves
+    const int wc = t % WCH, wr = t / WCH;
+    const bool wact = ALLW || wr < WR;
+    const int c0 = chunk * CW + 8 * (wact ? wc : 0);
+    float cA[8], cB[8], cD[8], sc[8], sh[8], ga[8], dp[8];
+    load8f(a.lin + c0, cA); load8f(a.lin + C + c0, cB); load8f(a.lin + 2 * C + c0, cD);
+    if (SE) {
+      load8f(a.bn + c0, sc); load8f(a.bn + C + c0, sh);
+      load8f(a.g.gate + (long)grp * C + c0, ga); load8f(a.g.dpooled + (long)grp * C + c0, dp);
     }
+    // one row of the wide pair -> dy (stored) and the weight gradient's wide operand
+    auto form = [&](const float (&u)[8], const float (&yv)[8], float (&dv)[8], float (&wv)[8]) {
 #pragma unroll
-    for (int p = 0; p < XI; ++p) R.x[p].ld(px + xoff[p]);
-  };
-  auto advance = [&](int next_step) {   // clamped: past the last full step the same rows are requested again (never consumed)
-    const long d = next_step < nfull ? BWG_ROWS : 0;
-    pg += d * C; py += d * C; px += d * K;
-  };
-  auto process = [&](Regs& R) {
-    __syncthreads();     // the previous step's fragment reads are done
-    if (wact) {
-#pragma unroll
-      for (int p = 0; p < WP; ++p) {
-        float u[8], yv[8], dv[8], wv[8];
-        R.g[p].get(u); R.y[p].get(yv);
-        form(u, yv, dv, wv);
-        bwg_st8<T>(pd + p * wstride, ws + wlds + p * WR * LW, dv, wv, !SE);
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < XI; ++p) R.x[p].st(xs + xlds[p]);
-    pd += (long)BWG_ROWS * C;
-    __syncthreads();
-    mfma_step();
-  };
-
-  if (nfull > 0) {
-    Regs RA, RB;
-    issue(RA); advance(1);
-    int s = 0;
-    for (; s + 2 <= nfull; s += 2) {
-      issue(RB); advance(s + 2);
-      process(RA);
-      issue(RA); advance(s + 3);
-      process(RB);
-    }
-    if (s < nfull) process(RA);
-  }
-  if (nrem > 0) {   // the ragged last step of the slab: guarded, not pipelined
-    const long mb = mbeg + (long)nfull * BWG_ROWS;
-    __syncthreads();
-    if (wact) {
-#pragma unroll
-      for (int p = 0; p < WP; ++p) {
-        const int lr = wr + WR * p;
-        const bool ok = lr < nrem;
-        const long off = (mb + (ok ? lr : 0)) * C + c0;
-        float u[8], yv[8], dv[8], wv[8];
-        load8(gsrc_ + off, u); load8(ysrc_ + off, yv);
-        form(u, yv, dv, wv);
-        if (!ok) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { dv[j] = 0.f; wv[j] = 0.f; }
+      for (int j = 0; j < 8; ++j) {
+        if (SE) {
+          const float z = yv[j] * sc[j] + sh[j], s = sigmoidf_(z);
+          const float gg = (u[j] * ga[j] + dp[j]) * (s * (1.0f + z * (1.0f - s)));
+          dv[j] = cA[j] * gg + cB[j] * yv[j] + cD[j];
+          wv[j] = z * s * ga[j];
+        } else {
+          dv[j] = cA[j] * u[j] + cB[j] * yv[j] + cD[j];
         }
-        bwg_st8<T>(ok ? dydst_ + off : (T*)nullptr, ws + wlds + p * WR * LW, dv, wv, !SE);
       }
-    }
+    };
+    const int wstride = WR * C;
+    const int wlds = (wact ? wr : 0) * LW + 8 * wc;
+    struct Wide { RawV8<T> g[WP], y[WP]; };
+    const long wbase = (mbeg + (wact ? wr : 0)) * C + c0;
+    const T* pg = (const T*)a.g.u + wbase;
+    const T* py = (const T*)a.y + wbase;
+    T* pd = (T*)a.dy + wbase;           // running pointer of the NEXT step to store
+    int wreq = 0;                       // next step to request (clamped to the last full step: re-requested rows are never consumed)
+    auto issue_w = [&](Wide& R) {
+      const long o = (long)(wreq < nfull ? wreq : nfull - 1) * BWG_ROWS * C;
+      ++wreq;
+      if (wact) {
 #pragma unroll
-    for (int p = 0; p < XI; ++p) {
-      const bool ok = xrow[p] < nrem;
-      RawV8<T> r;
-      r.ld(xsrc_ + mb * K + (ok ? xoff[p] : xoff[p] - xrow[p] * K));
-      if (!ok) r.zero();
-      r.st(xs + xlds[p]);
+        for (int p = 0; p < WP; ++p) { R.g[p].ld(pg + o + p * wstride); R.y[p].ld(py + o + p * wstride); }
+      }
+    };
+    auto step = [&](Wide& R) {
+      __syncthreads();     // the previous step's fragment reads are done
+      if (wact) {
+#pragma unroll
+        for (int p = 0; p < WP; ++p) {
+          float u[8], yv[8], dv[8], wv[8];
+          R.g[p].get(u); R.y[p].get(yv);
+          form(u, yv, dv, wv);
+          bwg_st8<T>(pd + p * wstride, ws + wlds + p * WR * LW, dv, wv, !SE);
+        }
+      }
+      issue_w(R);          // this set's registers are free again: request step s + NS
+      pd += (long)BWG_ROWS * C;
+      __syncthreads();
+      mfma_step();
+    };
+    if (nfull > 0) {
+      Wide W[NS];
+#pragma unroll
+      for (int r = 0; r < NS; ++r) issue_w(W[r]);
+      int s = 0;
+      for (; s + NS <= nfull; s += NS) {
+#pragma unroll
+        for (int r = 0; r < NS; ++r) step(W[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < NS - 1; ++r)
+        if (s + r < nfull) step(W[r]);
     }
-    __syncthreads();
-    mfma_step();
+    if (nrem > 0) {   // the ragged last step of the slab: guarded, not pipelined
+      const long mb = mbeg + (long)nfull * BWG_ROWS;
+      __syncthreads();
+      if (wact) {
+#pragma unroll
+        for (int p = 0; p < WP; ++p) {
+          const int lr = wr + WR * p;
+          const bool ok = lr < nrem;
+          const long off = (mb + (ok ? lr : 0)) * C + c0;
+          float u[8], yv[8], dv[8], wv[8];
+          load8((const T*)a.g.u + off, u); load8((const T*)a.y + off, yv);
+          form(u, yv, dv, wv);
+          if (!ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dv[j] = 0.f; wv[j] = 0.f; }
+          }
+          bwg_st8<T>(ok ? (T*)a.dy + off : (T*)nullptr, ws + wlds + p * WR * LW, dv, wv, !SE);
+        }
+      }
+      __syncthreads();
+      mfma_step();
+    }
+  } else {
+    // ------------------------------------------------------------ NARROW waves: four threads per row, thread j takes the
+    // 16-byte vectors j, j + 4, ... of its row (one base address + immediate offsets); vectors past the row alias the previous
+    // one of the same thread (same data to the same LDS address: harmless, and the loop stays branch-free)
+    const int xr_ = t >> 2, xj = t & 3;
+    const int xlast = (xj + 4 * (XP - 1) < XV) ? 32 * (XP - 1) : 32 * (XP - 2);    // element offset of the last vector (XV % 4 != 0: an alias)
+    const int xoff0 = xr_ * K + 8 * xj, xlds0 = xr_ * LX + 8 * xj;
+    const T* px = (const T*)a.x + mbeg * K;
+    int xreq = 0;
+    struct Nar { RawV8<T> v[XP]; };
+    auto issue_x = [&](Nar& R) {
+      const long o = (long)(xreq < nfull ? xreq : nfull - 1) * BWG_ROWS * K + xoff0;
+      ++xreq;
+#pragma unroll
+      for (int p = 0; p < XP; ++p) R.v[p].ld(px + o + (p == XP - 1 ? xlast : 32 * p));
+    };
+    auto step = [&](Nar& R) {
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < XP; ++p) R.v[p].st(xs + xlds0 + (p == XP - 1 ? xlast : 32 * p));
+      issue_x(R);          // two steps ahead
+      __syncthreads();
+      mfma_step();
+    };
+    if (nfull > 0) {
+      Nar X[2];
+      issue_x(X[0]); issue_x(X[1]);
+      int s = 0;
+      for (; s + 2 <= nfull; s += 2) { step(X[0]); step(X[1]); }
+      if (s < nfull) step(X[0]);
+    }
+    if (nrem > 0) {
+      const long mb = mbeg + (long)nfull * BWG_ROWS;
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < XP; ++p) {
+        const bool ok = xr_ < nrem;
+        const int e = (p == XP - 1 ? xlast : 32 * p);
+        RawV8<T> r;
+        r.ld((const T*)a.x + mb * K + (ok ? xoff0 : 8 * xj) + e);
+        if (!ok) r.zero();
+        r.st(xs + xlds0 + e);
+      }
+      __syncthreads();
+      mfma_step();
+    }
   }
 
   float* part = a.part + ((long)slab * C + (long)chunk * CW) * K;
 #pragma unroll
-  for (int u = 0; u < NFW; ++u)
+  for (int u = 0; u < NFH; ++u)
 #pragma unroll
     for (int jv = 0; jv < KFW; ++jv) {
-      const int v = wave + 4 * jv;
-      if (v < KF) {
+      const int v = wx + 4 * jv;
+      if (KF % 4 == 0 || v < KF) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part[(long)(16 * u + 4 * q + r) * K + 16 * v + i] = acc[u][jv][r];
+        for (int r = 0; r < 4; ++r) part[(long)(16 * (wh * NFH + u) + 4 * q + r) * K + 16 * v + i] = acc[u][jv][r];
       }
     }
 }
 
 // slab geometry shared by the launcher and mds_bn_bwd_apply_wg_slabs
 struct BwgGeo { int cw, nchunks, groups, splits, rows_per_slab, slabs; long gr; };
-static BwgGeo bwg_geo(long M, int C, long group_rows) {
+static BwgGeo bwg_geo(long M, int C, long group_rows, bool se, int dtype) {
   BwgGeo g;
   g.cw = (C % 64 == 0) ? 64 : 96;
   g.nchunks = C / g.cw;
   g.gr = group_rows > 0 ? group_rows : M;
   g.groups = (int)(M / g.gr);
-  const int target = mds_knob(MDS_KNOB_BWG_BLOCKS) > 0 ? mds_knob(MDS_KNOB_BWG_BLOCKS) : 512;
+  const int target = mds_knob(MDS_KNOB_BWG_BLOCKS) > 0 ? mds_knob(MDS_KNOB_BWG_BLOCKS)   : ((se || dtype == MDS_F32) ? 256 : 512);   // one resident round: 1 (SE / fp32) or 2 blocks per CU
   int want = target / g.nchunks;                       // slabs in all
   if (want < 1) want = 1;
   int splits = (want + g.groups / 2) / g.groups;       // per group
@@ -266,9 +297,9 @@ static bool bwg_dims_ok(long M, int C, int K, long group_rows) {
   return M > 0 && C > 0 && (C % 64 == 0 || C % 96 == 0) && (K == 48 || K == 96 || K == 112 || K == 192) && group_rows >= 0 &&
          (group_rows == 0 || M % group_rows == 0) && M < 2147483647L;
 }
-extern "C" int mds_bn_bwd_apply_wg_slabs(long M, int C, int K, long group_rows) {
+extern "C" int mds_bn_bwd_apply_wg_slabs(long M, int C, int K, long group_rows, int wide_act, int dtype) {
   if (!bwg_dims_ok(M, C, K, group_rows)) return 0;
-  return bwg_geo(M, C, group_rows).slabs;
+  return bwg_geo(M, C, group_rows, wide_act == 1, dtype).slabs;
 }
 
 extern "C" int mds_bn_bwd_apply_wg(const mds_bn_bwd_apply_wg_args* a, mds_stream_t stream) {
@@ -279,9 +310,9 @@ extern "C" int mds_bn_bwd_apply_wg(const mds_bn_bwd_apply_wg_args* a, mds_stream
   MDS_REQUIRE(se == (a->wide_act == 1) && (a->wide_act == 0 || a->wide_act == 1), "bn_bwd_apply_wg: wide_act 1 goes with SE_SILU (its gate), 0 with PLAIN");
   MDS_REQUIRE(!se || (a->g.gate && a->g.dpooled && a->g.rows_per_group > 0 && a->group_rows == a->g.rows_per_group),
               "bn_bwd_apply_wg: SE_SILU needs gate, dpooled and group_rows == rows_per_group");
-  const BwgGeo g = bwg_geo(a->M, a->C, a->group_rows);
+  const BwgGeo g = bwg_geo(a->M, a->C, a->group_rows, se, a->dtype);
   MDS_REQUIRE(a->slabs == g.slabs, "bn_bwd_apply_wg: slabs must come from mds_bn_bwd_apply_wg_slabs");
-  const dim3 grid((unsigned)((g.slabs + 7) / 8 * 8 * g.nchunks)), block(256);
+  const dim3 grid((unsigned)((g.slabs + 7) / 8 * 8 * g.nchunks)), block(512);
 #define BWG_GO(T, CW, K_, SE_)                                                                                     \
   MDS_LAUNCH((bn_bwd_apply_wg_kernel<T, CW, K_, SE_>), grid, block, (size_t)BWG_ROWS * (bwg_pitch(CW, sizeof(T)) + bwg_pitch(K_, sizeof(T))) * sizeof(T), \
              stream, *a, g.nchunks, g.splits, g.rows_per_slab, g.gr)

@@ -28,6 +28,8 @@ bool mds_switch(int id) {   // thread-safe one-time read (C++11 static initialis
 #include <atomic>
 static std::atomic<int> g_knob[MDS_KNOB_COUNT];
 int mds_knob(int id) { return id >= 0 && id < MDS_KNOB_COUNT ? g_knob[id].load(std::memory_order_relaxed) : 0; }
+thread_local void* mds_tl_stop_event = nullptr;   // read by MDS_LAUNCH (mds_platform_hw.h)
+extern "C" int mds_launch_event(void* event) { mds_tl_stop_event = event; return 0; }
 extern "C" int mds_dev_set(int knob, int value) {
   MDS_REQUIRE(knob >= 0 && knob < MDS_KNOB_COUNT, "mds_dev_set: unknown knob %d", knob);
   g_knob[knob].store(value, std::memory_order_relaxed);

@@ -45,6 +45,7 @@ MDS_DEV f32x4 ld_coherent4(const float* p) {
   return (f32x4){__builtin_bit_cast(float, (uint32_t)a), __builtin_bit_cast(float, (uint32_t)(a >> 32)),
                  __builtin_bit_cast(float, (uint32_t)b), __builtin_bit_cast(float, (uint32_t)(b >> 32))};
 }
+extern thread_local void* mds_tl_stop_event;   // k_misc.hip (mds_launch_event)
 #define MDS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MDS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  /* wave-uniform value -> scalar register */
 #define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
@@ -59,7 +60,10 @@ MDS_DEV f32x4 ld_coherent4(const float* p) {
         mds_cur_.store(mds_smem_, std::memory_order_relaxed);                                       \
       }                                                                                             \
     }                                                                                               \
-    hipLaunchKernelGGL(kernel, grid, block, mds_smem_, (hipStream_t)(stream), __VA_ARGS__);        \
+    if (mds_tl_stop_event) /* armed by mds_launch_event: the kernel's own completion signal is the event */ \
+      hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)mds_smem_, (hipStream_t)(stream), nullptr, (hipEvent_t)mds_tl_stop_event, 0, __VA_ARGS__); \
+    else                                                                                            \
+      hipLaunchKernelGGL(kernel, grid, block, mds_smem_, (hipStream_t)(stream), __VA_ARGS__);      \
   } while (0)
 
 MDS_DEV u16x4 lds_tr4(const bf16_t* p) {

@@ -122,7 +122,7 @@ class BNL:
         with wide = dy (wide_act 0) or silu(bn(y)) * gate (wide_act 1); the slabs' partial tiles are added into `dw` by a finishing
         launch on the second stream.  The sums were taken by the producer of the gradient source (reduce=False callers only)."""
         self.bwd_finalize(pb, seg, False)
-        slabs = int(pb.lib.fn["bn_bwd_apply_wg_slabs"](int(self.count), int(self.C), int(K), int(group_rows)))
+        slabs = int(pb.lib.fn["bn_bwd_apply_wg_slabs"](int(self.count), int(self.C), int(K), int(group_rows), int(wide_act), int(pb.code)))
         assert slabs > 0
         part = pb.f32(slabs * self.C * K)
         pb.op(seg, "bn_bwd_apply_wg", dtype=pb.code, M=self.count, C=self.C, g=gsrc, y=y, bn=self.buf, lin=self.lin, dy=dy, K=K, x=x,
@@ -196,6 +196,10 @@ def op_cost(name, kw, es):
     if name in ("se_bwd_reduce", "bn_bwd_reduce"):
         n = g("M") * g("C") if name == "bn_bwd_reduce" else g("groups") * g("rows_per_group") * g("C")
         return 2 * n * es, 10 * n
+    if name == "pw_dgrad":             # the apply pass's wide operands (g, y in; dy out when stored) + the narrow output (+ residual) + the filter
+        M, K, N = g("M"), g("K"), g("N")
+        wide = (2 if g("dyp") is not None else 1) + (1 if g("dy_out") is not None else 0)
+        return (wide * M * K + M * N * (2 if g("residual") is not None else 1) + N * K) * es, 2 * M * K * N + 4 * M * K
     if name == "bn_bwd_apply_wg":      # the apply pass's three wide operands + the narrow operand once + the partial tiles
         return 3 * g("M") * g("C") * es + g("M") * g("K") * es + g("slabs") * g("C") * g("K") * 4, 2 * g("M") * g("C") * g("K") + 12 * g("M") * g("C")
     if name in ("bn_bwd_apply", "gem_bwd"):
@@ -282,7 +286,10 @@ class Plan:
         self.fuse_bn_bwd = self.fuse_mode >= 1
         # MDS_WG_RIDE (bit 0: BN1 / conv_pw, bit 1: BN2 / conv_pwl): the 1x1 weight gradients of the inverted-residual blocks ride on
         # the BatchNorm-backward apply passes (mds_bn_bwd_apply_wg) instead of re-reading the wide tensors on the second stream
-        self.wg_ride = int(os.environ.get("MDS_WG_RIDE", "3"))
+        self.wg_ride = int(os.environ.get("MDS_WG_RIDE", "0"))
+        # MDS_PW_DGRAD=1 (default): the expansions' data gradient forms dy on load and stores it for the weight gradient
+        # (mds_pw_dgrad, k_pwd.hip) - BN1's apply launch and the second read of dy leave the dependent chain
+        self.pw_dgrad = os.environ.get("MDS_PW_DGRAD", "1") == "1"
         self.bn1_lin = int(os.environ.get("MDS_BN1_LIN", "0"))      # 0 = off; else the smallest rows x channels the linear form is used for
         # inference plans (eval-mode BatchNorm, no gradient): producers store activated outputs (mds_epi_t)
         self.eval_epilogues = (not training) and (not need_grad) and os.environ.get("MDS_EVAL_EPI", "1") == "1"
@@ -653,6 +660,21 @@ class Plan:
                     self.op(seg, "bn_bwd_apply", dtype=self.code, M=Min, C=mid, g=gsrc(G_PLAIN, g1), y=y1, bn=bn1.buf, coef=bn1.coef, dy=dy1, _side=1)
                     self.op(seg, "pw_wgrad", dtype=self.code, M=Min, K=cin, N=mid, x=xin, dy=dy1, dw=self.grad(blk.conv_pw.weight), pro=dict(mode=0))
                 return Grad(dx, nxt_head["bn"] if nxt_head is not None else None)
+            elif (self.pw_dgrad and not ride1 and self.fuse_mode in (0, 3) and self.lib.fn["pw_dgrad_ok"](int(Min), int(mid), int(cin)) == 1
+                  and (nxt_head is None or nxt_head["mode"] in (POST_PLAIN, POST_MASK))):
+                # BN1's apply pass folded into the data gradient (dy formed on load, stored once for the weight gradient)
+                bn1.bwd_finalize(self, seg, frozen)
+                dy1 = None if frozen else self.act(Min, mid)
+                dx = self.act(Min, cin)
+                extra = {"post": nxt_head["bn"].post(nxt_head)} if nxt_head is not None else {}
+                self.op(seg, "pw_dgrad", dtype=self.code, M=Min, K=mid, N=cin, x=None,
+                        dyp=dict(_struct="mds_dyp_t", mode=1, g=gsrc(G_PLAIN, g1), y=y1, bn=bn1.buf, lin=bn1.lin), dy_out=dy1,
+                        w=self.pack(blk.conv_pw.weight, cabi.MDS_PACK_IO_FLIP, mid, cin, 1), y=dx,
+                        residual=dout.buf if has_skip else None, **extra)
+                if not frozen:
+                    self.op(seg, "pw_wgrad", dtype=self.code, M=Min, K=cin, N=mid, x=xin, dy=dy1, dw=self.grad(blk.conv_pw.weight),
+                            pro=dict(mode=0))
+                return Grad(dx, nxt_head["bn"] if nxt_head is not None else None)
             elif ride1:   # BN1's apply pass also accumulates dW(conv_pw) = dy1^T x
                 dy1 = self.act(Min, mid)
                 bn1.backward_wg(self, seg, gsrc(G_PLAIN, g1), y1, dy1, xin, cin, self.grad(blk.conv_pw.weight), 0)
@@ -997,23 +1019,74 @@ class Plan:
         # Backward: the weight-gradient GEMMs are leaves of the dependency graph (they only add
         # into the gradient arena), so they go to a second HIP stream and fill the CUs that the
         # short dgrad / BN-backward launches of the critical path leave idle.
+        # Hand-off (round 4): the second stream waits for the STOP event of the dependent chain's last kernel before the side
+        # launch (mds_launch_event: the kernel's own completion signal) - an event RECORDED on the chain is a marker packet that
+        # costs it 4.4 us (tools/probes/event_cost.py), 71 times per step.  MDS_SIDE_EVENTS=record restores the recorded events.
         main = torch.cuda.current_stream(self.device)
         side_h = side.cuda_stream
+        ops = self.bound[seg]
+        is_side = self._side_flags.get(seg)
+        if is_side is None:
+            is_side = self._side_flags[seg] = [name in self.SIDE_OPS or name.endswith("@side") for name, *_ in ops]
+        ext = self._ext_events()
         evs, n = self._side_events, 0
-        for k, (name, fn, st, ref) in enumerate(self.bound[seg]):
-            if name in self.SIDE_OPS or name.endswith("@side"):
-                if n == len(evs):
-                    evs.append(torch.cuda.Event())
-                ev = evs[n]; n += 1
-                ev.record(main)
-                side.wait_event(ev)
+        armed = None          # stop event bound to the chain's most recent kernel (None: nothing to wait for yet in this segment)
+        for k, (name, fn, st, ref) in enumerate(ops):
+            if is_side[k]:
+                if ext is not None and armed is not None:
+                    ext.wait(side_h, armed)
+                else:
+                    if n == len(evs):
+                        evs.append(torch.cuda.Event())
+                    ev = evs[n]; n += 1
+                    ev.record(main)
+                    side.wait_event(ev)
                 rc = fn(ref, side_h)
+            elif ext is not None and k + 1 < len(ops) and is_side[k + 1]:
+                armed = ext.get(seg, k)
+                self.lib.fn["launch_event"](armed)
+                rc = fn(ref, stream)
+                self.lib.fn["launch_event"](None)
             else:
                 rc = fn(ref, stream)
             if rc:
                 self.lib.check(rc, name)
             if hook is not None and (seg, k + 1) in self.cuts:
                 hook(self, *self.cuts[(seg, k + 1)])
+
+    class _ExtEvents:
+        """hipEvent_t handles used as kernel STOP events (hipExtLaunchKernelGGL through mds_launch_event) + hipStreamWaitEvent"""
+
+        def __init__(self, device):
+            import ctypes
+            self.ct = ctypes
+            self.hip = ctypes.CDLL(_hip_path())
+            self.hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+            self.hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+            self.device, self.ev = device, {}
+
+        def get(self, seg, k):
+            h = self.ev.get((seg, k))
+            if h is None:
+                v = self.ct.c_void_p()
+                with torch.cuda.device(self.device):
+                    rc = self.hip.hipEventCreateWithFlags(self.ct.byref(v), 0)
+                if rc != 0 or not v.value:
+                    raise RuntimeError(f"hipEventCreateWithFlags failed: {rc}")
+                h = self.ev[(seg, k)] = v.value
+            return h
+
+        def wait(self, stream_handle, event):
+            rc = self.hip.hipStreamWaitEvent(stream_handle, event, 0)
+            if rc != 0:
+                raise RuntimeError(f"hipStreamWaitEvent failed: {rc}")
+
+    def _ext_events(self):
+        if os.environ.get("MDS_SIDE_EVENTS", "stop") != "stop":
+            return None
+        if getattr(self, "_ext", None) is None:
+            self._ext = Plan._ExtEvents(self.device)
+        return self._ext
 
     def join_backward(self):
         """the gradient arena is complete once the side stream has drained"""
@@ -1026,6 +1099,7 @@ class Plan:
         if getattr(self, "_side", None) is None:
             self._side = _masked_stream(self.device) or torch.cuda.Stream(device=self.device)
             self._side_events = []
+            self._side_flags = {}
         return self._side
 
     def _run_profiled(self, seg):

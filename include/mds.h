@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 122
+#define MDS_VERSION 124
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -63,9 +63,15 @@ const char* mds_last_error(void);
 #define MDS_KNOB_PW_BM64 13        /* row bar (in thousands) below which mds_pw_fwd takes 64-row tiles (0 = default 400) */
 #define MDS_KNOB_REDUCE_PASSES 14  /* rows passes per block of the grouped reduce kernels (0 = default 32) */
 #define MDS_KNOB_DW2_BLOCKS 15     /* block target of the 3x3 stride-1 strip rule (0 = default 640) */
-#define MDS_KNOB_BWG_BLOCKS 16     /* block target of mds_bn_bwd_apply_wg (0 = default 512) */
+#define MDS_KNOB_BWG_BLOCKS 16     /* block target of mds_bn_bwd_apply_wg (0 = default: one resident round) */
 #define MDS_KNOB_COUNT 17
 int mds_dev_set(int knob, int value);
+/* Completion event of the NEXT launches of the calling thread (a hipEvent_t as void*; NULL disarms).  While armed, every kernel
+ * this thread launches through the library is issued with the event as its STOP event (hipExtLaunchKernelGGL), i.e. the event is
+ * bound to the last such kernel's own completion signal - no marker packet on the stream.  The planner uses it to let the
+ * weight-gradient stream wait for a kernel of the dependent chain: an event RECORDED on that chain costs it 4.4 us (measured,
+ * tools/probes/event_cost.py; 71 of them per training step), a stop event nothing.                                            */
+int mds_launch_event(void* event);
 
 /* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
  * the predictor): the producer stores act(acc*scale[c] + shift[c]) instead of the raw convolution output, so no consumer
@@ -225,6 +231,27 @@ typedef struct {
   const float* nscale;  /* optional [N]: row n of the accumulated tile is multiplied by nscale[n] before it is added to dw */
 } mds_pw_wgrad_args;
 int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream);
+
+/* ---- data gradient of a 1x1 EXPANSION convolution (K = mid wide, N = cin <= 192) with the BatchNorm-backward apply pass
+ * folded in (round 4, k_pwd.hip): dx[M][N] = dy[M][K] w[N][K]^T (+ residual), dy = A*g + B*y + D formed on load (dyp) and, if
+ * dy_out is given, stored for the weight gradient; optionally the next BatchNorm backward's sums over dx (post: PLAIN / MASK).
+ * A block owns 64 rows and all N columns and streams K: every wide element is read once.  Replaces mds_bn_bwd_apply +
+ * mds_pw_fwd on the dependent chain (native_batch_norm_backward + the input half of convolution_backward behind
+ * multidim_stacker.py:124-134 / timm InvertedResidual).                                                                 */
+typedef struct {
+  int dtype;
+  long M;
+  int K, N;             /* K: a multiple of 32 in 64 .. 2048; N: 48, 96, 112 or 192 */
+  const void* x;        /* [M][K] dy, when dyp.mode == 0 */
+  mds_dyp_t dyp;        /* mode 1: dy formed on load from g (PLAIN) and y */
+  void* dy_out;         /* optional [M][K]: the formed dy is also stored */
+  const void* w;        /* [N][K] (MDS_PACK_IO_FLIP of the conv weight) */
+  void* y;              /* [M][N] out */
+  const void* residual; /* optional [M][N], added */
+  mds_poststat_t post;  /* NONE, PLAIN or MASK */
+} mds_pw_dgrad_args;
+int mds_pw_dgrad(const mds_pw_dgrad_args* a, mds_stream_t stream);
+int mds_pw_dgrad_ok(long M, int K, int N);   /* 1 if mds_pw_dgrad takes the shape */
 
 /* ---- K2/K3: dense 3x3 convolution as an MFMA implicit GEMM over a tap list.
  * For output sub-grid point (a,b), a<A, b<B of image n:
@@ -561,11 +588,11 @@ typedef struct {
   const void* x;        /* [M][K] narrow operand */
   int wide_act;
   long group_rows;      /* > 0: slabs never straddle a multiple of group_rows (required with MDS_G_SE_SILU: = g.rows_per_group) */
-  int slabs;            /* mds_bn_bwd_apply_wg_slabs(M, C, K, group_rows) */
+  int slabs;            /* mds_bn_bwd_apply_wg_slabs(M, C, K, group_rows, wide_act, dtype) */
   float* part;          /* fp32 [slabs][C][K] scratch, fully overwritten */
 } mds_bn_bwd_apply_wg_args;
 int mds_bn_bwd_apply_wg(const mds_bn_bwd_apply_wg_args* a, mds_stream_t stream);
-int mds_bn_bwd_apply_wg_slabs(long M, int C, int K, long group_rows);   /* number of row slabs (rows of part) the launch will use */
+int mds_bn_bwd_apply_wg_slabs(long M, int C, int K, long group_rows, int wide_act, int dtype);   /* number of row slabs (rows of part) the launch will use */
 
 /* dw (+)= sum over slabs of part[s][C][K] in slab order; transpose: dw is [K][C] (the gated projection's [cout][mid]) */
 typedef struct {

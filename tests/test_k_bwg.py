@@ -34,7 +34,7 @@ def _run(be, dt, M, C, K, se, group_rows, seed=0, knob_blocks=0):
     if knob_blocks:
         be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_BWG_BLOCKS, knob_blocks), "dev_set")
     try:
-        slabs = be.lib.fn["bn_bwd_apply_wg_slabs"](M, C, K, group_rows)
+        slabs = be.lib.fn["bn_bwd_apply_wg_slabs"](M, C, K, group_rows, 1 if se else 0, code)
         assert slabs > 0
         dy = torch.full((M, C), float("nan")).to(tdt).to(be.device)
         part = torch.full((slabs, C, K), float("nan"), device=be.device)
@@ -110,4 +110,4 @@ def test_real_layer_shapes(be_gpu, M, C, K, se, group_rows):
 def test_bad_arguments_are_errors(be):
     with pytest.raises(cabi.MdsError):
         be.call("bn_bwd_apply_wg", cabi.make("mds_bn_bwd_apply_wg_args", dtype=1, M=64, C=80, K=48))
-    assert be.lib.fn["bn_bwd_apply_wg_slabs"](64, 64, 50, 0) == 0
+    assert be.lib.fn["bn_bwd_apply_wg_slabs"](64, 64, 50, 0, 0, 1) == 0
