@@ -29,7 +29,7 @@ MDS_DEV void pwd_raw8(RawV8<bf16_t>& o, const float (&v)[8]) { o.v = pack8(v); }
 MDS_DEV void pwd_raw8(RawV8<float>& o, const float (&v)[8]) { o.a = (f32x4){v[0], v[1], v[2], v[3]}; o.b = (f32x4){v[4], v[5], v[6], v[7]}; }
 
 template <typename T, int N, bool DYP, bool POST>
-__global__ __launch_bounds__(512, sizeof(T) == 2 ? 2 : 1) void pw_dgrad_kernel(mds_pw_dgrad_args a) {
+__global__ __launch_bounds__(512, sizeof(T) == 2 ? 2 : 1) void pw_dgrad_kernel(mds_pw_dgrad_args a, int dbg) {
   constexpr int LD = PwdCfg<T>::LD, NB = (N + 31) / 32 * 32, NP = NB / 32, NFR = N / 16, KFW = (NFR + 3) / 4;
   constexpr int NS = sizeof(T) == 2 ? 3 : 2;         // wide ring depth
   constexpr int OP = N + 4;                          // fp32 output staging pitch
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 2 : 1) void pw_dgrad_kernel(m
 #pragma unroll
     for (int v = 0; v < KFW; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto mfma_chunk = [&]() {
+    if (dbg & 1) return;
 #pragma unroll
     for (int ks = 0; ks < PWD_KC / 32; ++ks) {
       frag_t wf[KFW], df[2];
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 2 : 1) void pw_dgrad_kernel(m
       const int kc = req < nkc ? req : nkc - 1;
       ++req;
       const int c = PWD_KC * kc + 8 * vec, cl = c < K ? c : K - 8;
+      if (dbg & 4) return;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         R.g[p].ld(src + rowoff[p] + cl);
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 2 : 1) void pw_dgrad_kernel(m
           for (int j = 0; j < 8; ++j) dv[j] = ok ? cA[j] * u[j] + cB[j] * yv[j] + cD[j] : 0.f;
           RawV8<T> o;
           pwd_raw8(o, dv);
-          if (dyo && ok) o.st(dyo + rowoff[p] + c);
+          if (dyo && ok && !(dbg & 2)) o.st(dyo + rowoff[p] + c);
           o.st(lp);
         } else {
           if (!(cok && rok[p])) R.g[p].zero();
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 2 : 1) void pw_dgrad_kernel(m
       const int kc = req < nkc ? req : nkc - 1;
       ++req;
       const int c = PWD_KC * kc + 8 * vec, cl = c < K ? c : K - 8;
+      if (dbg & 8) return;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int n = r0 + 32 * p;
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 2 ? 2 : 1) void pw_dgrad_kernel(m
   }
 
   // ---------------------------------------------------------------- epilogue: fp32 tile through LDS, then row-major
+  if (dbg & 16) return;
   __syncthreads();       // the last chunk's fragment reads are done: the staging buffers are free
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -273,7 +277,7 @@ extern "C" int mds_pw_dgrad(const mds_pw_dgrad_args* a, mds_stream_t stream) {
   do {                                                                                                                     \
     const size_t loop_ = (size_t)(PWD_BM + (N_ + 31) / 32 * 32) * PwdCfg<T>::LD * sizeof(T) + (DYP_ ? (size_t)3 * Kp * 4 : 0); \
     const size_t out_ = (size_t)PWD_BM * (N_ + 4) * 4;                                                                     \
-    MDS_LAUNCH((pw_dgrad_kernel<T, N_, DYP_, POST_>), grid, block, (loop_ > out_ ? loop_ : out_) + 2 * N_ * 4, stream, *a); \
+    MDS_LAUNCH((pw_dgrad_kernel<T, N_, DYP_, POST_>), grid, block, (loop_ > out_ ? loop_ : out_) + 2 * N_ * 4, stream, *a, mds_knob(MDS_KNOB_WG_DBG)); \
   } while (0)
 #define PWD_FLAGS(T, N_)                                                                  \
   do {                                                                                    \

@@ -289,7 +289,7 @@ class Plan:
         self.wg_ride = int(os.environ.get("MDS_WG_RIDE", "0"))
         # MDS_PW_DGRAD=1 (default): the expansions' data gradient forms dy on load and stores it for the weight gradient
         # (mds_pw_dgrad, k_pwd.hip) - BN1's apply launch and the second read of dy leave the dependent chain
-        self.pw_dgrad = os.environ.get("MDS_PW_DGRAD", "1") == "1"
+        self.pw_dgrad = os.environ.get("MDS_PW_DGRAD", "0") == "1"
         self.bn1_lin = int(os.environ.get("MDS_BN1_LIN", "0"))      # 0 = off; else the smallest rows x channels the linear form is used for
         # inference plans (eval-mode BatchNorm, no gradient): producers store activated outputs (mds_epi_t)
         self.eval_epilogues = (not training) and (not need_grad) and os.environ.get("MDS_EVAL_EPI", "1") == "1"

@@ -234,8 +234,13 @@ def bench_bwg():
 
 def bench_pwd():
     """mds_pw_dgrad (apply pass folded into the expansion's data gradient) against the apply + pw_fwd pair it replaces"""
-    for (M, K, N, tag) in [(18400, 1152, 192, "s5"), (73600, 672, 112, "s4"), (73600, 576, 96, "s4.0"), (73600, 384, 96, "s3"), (18400, 576, 192, "3d"),
-                           (294400, 192, 48, "s3.0"), (18400, 672, 112, "s5.0")]:
+    if os.environ.get("KB_DBG"):
+        lib.check(lib.fn["dev_set"](cabi.MDS_KNOB_WG_DBG, int(os.environ["KB_DBG"])), "dev_set")
+    shapes = [(18400, 1152, 192, "s5"), (73600, 672, 112, "s4"), (73600, 576, 96, "s4.0"), (73600, 384, 96, "s3"), (18400, 576, 192, "3d"),
+              (294400, 192, 48, "s3.0"), (18400, 672, 112, "s5.0")]
+    if os.environ.get("KB_DBG"):
+        shapes = shapes[:2]
+    for (M, K, N, tag) in shapes:
         u = rnd(M, K); y = rnd(M, K); w = rnd(N, K); res = rnd(M, N); out = torch.empty(M, N, device=dev, dtype=BF); dyo = torch.empty_like(y)
         lin = torch.rand(3, K, device=dev); coef = torch.rand(3, K, device=dev); bn = torch.rand(4, K, device=dev)
         py = rnd(M, N); pbn = torch.rand(4, N, device=dev); st = torch.zeros(SLOTS, 2, N, device=dev, dtype=torch.float64)
