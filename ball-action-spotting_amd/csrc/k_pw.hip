@@ -300,7 +300,9 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
         }
       }
       int* lastp = (int*)smem;    // (the operand tiles are dead: every wave passed the K loop's last barrier)
-      __syncthreads();            // every lane has waited for the acknowledgements of its device-scope stores (vmcnt(0) is part of the barrier)
+      mds_wait_stores();          // every lane waits for the acknowledgements of its device-scope stores: EXPLICIT vmcnt(0) - the
+                                  // memory model does not oblige the compiler to put one in front of a workgroup barrier
+      __syncthreads();
       if (tid == 0) {
         int* tk = a.split_ticket + ((long)blockIdx.x * ((N + BN - 1) / BN) + n0 / BN) * MDS_PW_SPLIT_TICKET_STRIDE;
         const int t = atomicAdd(tk, 1);

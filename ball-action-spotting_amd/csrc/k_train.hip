@@ -51,7 +51,14 @@ extern "C" int mds_focal_fwd_bwd(const mds_focal_args* a, mds_stream_t stream) {
 // accesses when the four streams are 16-byte aligned at the chunk start (always for the flat buffers; parameters
 // are separate torch allocations, 256-byte aligned), scalar tail otherwise.
 __global__ __launch_bounds__(256) void adamw_kernel(mds_adamw_args a) {
-  if (a.found_inf && *a.found_inf != 0.f) return;           // GradScaler: skip the step
+  const bool skip = a.found_inf && *a.found_inf != 0.f;     // GradScaler: skip the step
+  float bias1 = a.bias1, bias2 = a.bias2;
+  if (a.step_in) {                                          // device step counter: a skipped step does not count
+    const float t = *a.step_in + (skip ? 0.f : 1.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.step_out = t;
+    bias1 = 1.0f - powf(a.beta1, t); bias2 = 1.0f - powf(a.beta2, t);
+  }
+  if (skip) return;
   const int ti = a.chunks[2 * blockIdx.x], c0 = a.chunks[2 * blockIdx.x + 1];
   const mds_opt_tensor T = a.table[ti];
   const long beg = (long)c0 * MDS_OPT_CHUNK;
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(mds_adamw_args a) {
   const float* g = a.gbase + T.goff;
   float* m = a.exp_avg + T.soff;
   float* v = a.exp_avg_sq + T.soff;
-  const float decay = 1.0f - a.lr * a.weight_decay, step = a.lr / a.bias1, rb2 = 1.0f / sqrtf(a.bias2);
+  const float decay = 1.0f - a.lr * a.weight_decay, step = a.lr / bias1, rb2 = 1.0f / sqrtf(bias2);
   const float inv_scale = a.grad_scale ? 1.0f / *a.grad_scale : 1.0f;    // GradScaler: unscale on load (torch multiplies by 1/scale too)
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {
     gg *= inv_scale;
@@ -92,7 +99,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(mds_adamw_args a) {
 }
 extern "C" int mds_multi_adamw(const mds_adamw_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->table && a->chunks && a->nchunks > 0 && a->exp_avg && a->exp_avg_sq, "multi_adamw: bad args");
-  MDS_REQUIRE(a->bias1 > 0.f && a->bias2 > 0.f, "multi_adamw: bias corrections must be positive (step >= 1)");
+  MDS_REQUIRE(a->step_in || (a->bias1 > 0.f && a->bias2 > 0.f), "multi_adamw: bias corrections must be positive (step >= 1)");
+  MDS_REQUIRE(!a->step_in || (a->step_out && a->step_out != a->step_in), "multi_adamw: the device step counter needs two distinct scalars");
   MDS_LAUNCH(adamw_kernel, dim3(a->nchunks), dim3(256), 0, stream, *a);
   return mds_check_launch("multi_adamw");
 }
@@ -100,7 +108,14 @@ extern "C" int mds_multi_adamw(const mds_adamw_args* a, mds_stream_t stream) {
 // SGD with momentum / Nesterov over the same tables (torch.optim.SGD: weight decay added to the gradient, buffer
 // initialised WITH the first gradient, dampening applied from the second step on)
 __global__ __launch_bounds__(256) void sgd_kernel(mds_sgd_args a) {
-  if (a.found_inf && *a.found_inf != 0.f) return;
+  const bool skip = a.found_inf && *a.found_inf != 0.f;
+  bool first = a.first != 0;
+  if (a.step_in) {
+    const float t0 = *a.step_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.step_out = t0 + (skip ? 0.f : 1.f);
+    first = t0 == 0.f;
+  }
+  if (skip) return;
   const int ti = a.chunks[2 * blockIdx.x], c0 = a.chunks[2 * blockIdx.x + 1];
   const mds_opt_tensor T = a.table[ti];
   const long beg = (long)c0 * MDS_OPT_CHUNK;
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(mds_sgd_args a) {
   auto upd = [&](float& pp, float gg, float& bb) {
     gg = gg * inv_scale + a.weight_decay * pp;
     if (mom) {
-      bb = a.first ? gg : a.momentum * bb + keep * gg;
+      bb = first ? gg : a.momentum * bb + keep * gg;
       gg = a.nesterov ? gg + a.momentum * bb : bb;
     }
     pp -= a.lr * gg;

@@ -46,6 +46,8 @@ MDS_DEV f32x4 ld_coherent4(const float* p) {
                  __builtin_bit_cast(float, (uint32_t)b), __builtin_bit_cast(float, (uint32_t)(b >> 32))};
 }
 extern thread_local void* mds_tl_stop_event;   // k_misc.hip (mds_launch_event)
+// all of this lane's outstanding vector-memory operations (loads returned, stores acknowledged): s_waitcnt vmcnt(0)
+MDS_DEV void mds_wait_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // gfx9 encoding: vmcnt = 0, expcnt / lgkmcnt = max (no wait)
 #define MDS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MDS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  /* wave-uniform value -> scalar register */
 #define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]

@@ -97,6 +97,7 @@ class BNL:
         if not pb.batch_stats:      # eval: running statistics only — every layer of the plan in one table-driven launch
             pb.eval_bn.append((m, self.C, self.buf))
             return
+        pb._bn_buffers += [m.running_mean, m.running_var, m.num_batches_tracked]
         pb.op(seg, "bn_finalize", C=self.C, count=self.count, stats=self.stats, gamma=P(m.weight), beta=P(m.bias),
               eps=float(m.eps), momentum=float(m.momentum if m.momentum is not None else 0.1),
               training=int(pb.batch_stats), running_mean=P(m.running_mean), running_var=P(m.running_var),
@@ -301,6 +302,7 @@ class Plan:
         self.segs: Dict[str, list] = {"pack": [], "f2d": [], "f3d": [], "fhead": [], "bhead": [], "b3d": [], "b2d": []}
         self._recs: Dict[str, list] = {"2d": [], "3d": [], "head": []}
         self.pack_jobs = []
+        self._bn_buffers = []    # running_mean / running_var / num_batches_tracked of every BatchNorm this plan updates
         self.taps = []           # block outputs in forward order: dict(tag, buf, bn (raw tensor read through BN+SiLU) or None, rows, C)
         self.masks = []          # (Lazy view, keep_prob)
         self._mask_total = 0
@@ -1002,6 +1004,14 @@ class Plan:
 
     cut_hook = None     # data parallelism: called as cut_hook(plan, lo, hi) when arena[lo:hi] is final (all its launches issued)
 
+    def _failed(self, rc, name):
+        """a launch was refused: split-K tickets reset themselves only when a launch completes - zero them so that the plan's
+        later launches do not start from a stale count - then raise"""
+        tk = getattr(self, "_split_ticket", None)
+        if tk is not None and tk.tensor is not None:
+            tk.tensor.zero_()
+        self.lib.check(rc, name.split("@")[0])
+
     def run(self, seg):
         if self.profile is not None:
             return self._run_profiled(seg)
@@ -1012,7 +1022,7 @@ class Plan:
             for k, (name, fn, st, ref) in enumerate(self.bound[seg]):
                 rc = fn(ref, stream)
                 if rc:
-                    self.lib.check(rc, name.split("@")[0])
+                    self._failed(rc, name)
                 if hook is not None and (seg, k + 1) in self.cuts:
                     hook(self, *self.cuts[(seg, k + 1)])
             return
@@ -1050,7 +1060,7 @@ class Plan:
             else:
                 rc = fn(ref, stream)
             if rc:
-                self.lib.check(rc, name)
+                self._failed(rc, name)
             if hook is not None and (seg, k + 1) in self.cuts:
                 hook(self, *self.cuts[(seg, k + 1)])
 
@@ -1169,6 +1179,10 @@ class Plan:
                 self.mask_arena.tensor.copy_((r < self.mask_keep).float() / self.mask_keep)
         if refresh:
             self.refresh_weights()
+        if self.update_running and self._bn_buffers:
+            # the kernels update the running statistics through raw pointers: bump the tensors' version counters so that
+            # autograd's saved-tensor checks and version-keyed caches (mds.predict) see the write
+            torch.autograd.graph.increment_version(self._bn_buffers)
 
     def begin_backward(self):
         self.zb_arena.tensor.zero_()

@@ -80,6 +80,19 @@ class _Release:
             plan.in_flight = False
 
 
+class _Release2:
+    """the same for the registered operator's path: lives on the autograd context, releases the plan named by the token"""
+
+    def __init__(self, handle, token):
+        self.handle, self.token = handle, token
+
+    def __del__(self):
+        try:
+            _release_token(self.handle, self.token)
+        except Exception:       # interpreter shutdown
+            pass
+
+
 class _MDSFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, plan, *params):
@@ -217,7 +230,12 @@ def _module_of(handle: int):
     return m
 
 
-@torch.library.custom_op("mds::forward", mutates_args=())
+# A training forward also updates the BatchNorm running statistics and draws DropPath / dropout masks.  torch refuses an autograd
+# formula on an operator that declares mutated arguments, so the operator stays functional in its schema and carries the
+# `nondeterministic_seeded` tag instead (it IS seeded-random with drop rates > 0): graph passes that merge or reorder pure nodes
+# leave tagged operators alone.  tests/test_module_emu.py runs two identical calls in one compiled graph and checks that the
+# statistics advance twice.
+@torch.library.custom_op("mds::forward", mutates_args=(), tags=(torch.Tag.nondeterministic_seeded,))
 def _op_forward(x: torch.Tensor, params: List[torch.Tensor], handle: int, need_grad: bool, code: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """logits of MultiDimStacker.forward + a CPU token naming the launch plan that holds the activations for backward.
     `params` only tells autograd what the result depends on - the kernels read the module's parameters in place."""
@@ -263,10 +281,23 @@ def _(dlogits, x, token, handle):
     return dlogits.new_empty((sum(p.numel() for p in _module_of(handle).parameters()),), dtype=torch.float32)
 
 
+def _release_token(handle, token):
+    """the autograd node of a grad-enabled forward died without running backward (loss only evaluated, an exception): its plan
+    - a full activation arena - becomes reusable at once instead of after four later forwards"""
+    m = _MODULES.get(handle)
+    if m is not None:
+        plan = m._live.pop(token, None)
+        if plan is not None:
+            plan.in_flight = False
+
+
 def _op_setup_context(ctx, inputs, output):
     x, params, handle, need_grad, code = inputs
     ctx.save_for_backward(x, output[1])     # x is version-checked: an in-place edit before backward raises
     ctx.handle = handle
+    tok = output[1]
+    if need_grad and type(tok) is torch.Tensor and not torch.compiler.is_compiling():     # (not while tracing: fake tensors have no value)
+        ctx._mds_release = _Release2(handle, int(tok))
     ctx.meta = [(p.numel(), p.shape, p.requires_grad) for p in params]
 
 
@@ -383,6 +414,11 @@ class MultiDimStacker(nn.Module):
             new.__dict__[k] = {} if k == "_live" else (v if k == "_lib" else copy.deepcopy(v, memo))     # (a loaded library is shared)
         new._register()
         return new
+
+    def __getstate__(self):                   # plans of forwards in flight are not part of the module's state
+        state = dict(self.__dict__)
+        state["_live"] = {}
+        return state
 
     def __setstate__(self, state):            # torch.save(module) / pickle
         super().__setstate__(state)

@@ -136,12 +136,17 @@ class _FusedOptimizer(torch.optim.Optimizer):
             for p in ps:
                 soff[id(p)] = off
                 off += (p.numel() + 3) // 4 * 4          # keep every tensor's state 16-byte aligned
-            gs = dict(soff=soff, step=old["step"] if old else 0, cache=None, device=dev)
+            # the step counter lives on the DEVICE (two scalars used alternately: a launch reads one and writes the other), because
+            # a step GradScaler skips on found_inf must not count (torch's fused optimizers rewind it on the device as well)
+            gs = dict(soff=soff, cache=None, device=dev, k=0,
+                      step_dev=(old["step_dev"].to(dev) if old else torch.zeros(2, device=dev)))
+            if old:
+                gs["k"] = old["k"]
             for name in self.STATE_NAMES:
                 gs[name] = old[name].to(dev) if old else torch.zeros(off, device=dev)
             for p in ps:
                 o = soff[id(p)]
-                self.state[p] = {"step": torch.tensor(float(gs["step"])),
+                self.state[p] = {"step": torch.tensor(0.0),
                                  **{name: gs[name][o:o + p.numel()].view_as(p) for name in self.STATE_NAMES}}
             self._g[gi] = gs
         return gs
@@ -187,18 +192,21 @@ class _FusedOptimizer(torch.optim.Optimizer):
             cache, base = self._tables(gs, active, grads)
             dev = active[0].device
             found_inf, grad_scale = self._amp(dev)
-            gs["step"] += 1      # (a step GradScaler skips on the device still counts here; torch's fused optimizers rewind it on the device)
             with torch.cuda.device(dev) if dev.type == "cuda" else _null():
                 self._launch(gs, group, active, cache, base, found_inf, grad_scale)
+            gs["k"] ^= 1
             cache["amp"] = (found_inf, grad_scale)
+            # the kernel wrote through raw pointers: tell autograd / version-based caches (mds.predict) that the parameters changed
+            torch.autograd.graph.increment_version(active)
         return loss
 
     def state_dict(self):
         for gi, group in enumerate(self.param_groups):
             gs = self._g.get(gi)
             if gs is not None:
+                step = float(gs["step_dev"][gs["k"]].item())
                 for p in group["params"]:
-                    self.state[p]["step"] = torch.tensor(float(gs["step"]))
+                    self.state[p]["step"] = torch.tensor(step)
         return super().state_dict()
 
     def load_state_dict(self, sd):
@@ -217,7 +225,7 @@ class _FusedOptimizer(torch.optim.Optimizer):
                         if st.get(name) is not None:
                             self.state[p][name].copy_(st[name])
                     if "step" in st:
-                        gs["step"] = int(float(st["step"]))
+                        gs["step_dev"][gs["k"]] = float(st["step"])
 
 
 class FusedAdamW(_FusedOptimizer):
@@ -233,13 +241,13 @@ class FusedAdamW(_FusedOptimizer):
         self._g = {}          # group index -> dict(exp_avg, exp_avg_sq, soff, step, cache, device)
 
     def _launch(self, gs, group, active, cache, base, found_inf, grad_scale):
-        t = gs["step"]
         b1, b2 = group["betas"]
+        k = gs["k"]
         lib = _lib(active[0])
         args = cabi.make("mds_adamw_args", table=cache["table"], chunks=cache["chunks"], nchunks=cache["nchunks"], gbase=base,
                          exp_avg=gs["exp_avg"], exp_avg_sq=gs["exp_avg_sq"], lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
-                         eps=float(group["eps"]), weight_decay=float(group["weight_decay"]), bias1=1.0 - b1 ** t,
-                         bias2=1.0 - b2 ** t, found_inf=found_inf, grad_scale=grad_scale)
+                         eps=float(group["eps"]), weight_decay=float(group["weight_decay"]), bias1=0.0, bias2=0.0,
+                         found_inf=found_inf, grad_scale=grad_scale, step_in=gs["step_dev"][k:k + 1], step_out=gs["step_dev"][1 - k:2 - k])
         lib.check(lib.fn["multi_adamw"](C.byref(args), _stream(active[0])), "multi_adamw")
 
 
@@ -262,7 +270,8 @@ class FusedSGD(_FusedOptimizer):
         args = cabi.make("mds_sgd_args", table=cache["table"], chunks=cache["chunks"], nchunks=cache["nchunks"], gbase=base,
                          momentum_buf=gs["momentum_buffer"], lr=float(group["lr"]), momentum=float(group["momentum"]),
                          dampening=float(group["dampening"]), weight_decay=float(group["weight_decay"]),
-                         nesterov=int(bool(group["nesterov"])), first=int(gs["step"] == 1), found_inf=found_inf, grad_scale=grad_scale)
+                         nesterov=int(bool(group["nesterov"])), first=0, found_inf=found_inf, grad_scale=grad_scale,
+                         step_in=gs["step_dev"][gs["k"]:gs["k"] + 1], step_out=gs["step_dev"][1 - gs["k"]:2 - gs["k"]])
         lib.check(lib.fn["multi_sgd"](C.byref(args), _stream(active[0])), "multi_sgd")
 
 
@@ -309,6 +318,7 @@ class ModelEma(nn.Module):
             args = cabi.make("mds_ema_args", table=c["table"], chunks=c["chunks"], nchunks=c["nchunks"], gbase=None, decay=float(self.decay))
             with torch.cuda.device(dev) if dev.type == "cuda" else _null():
                 lib.check(lib.fn["multi_ema"](C.byref(args), _stream(evs[0])), "multi_ema")
+            torch.autograd.graph.increment_version([e for e, _ in fl])      # written through raw pointers (see _FusedOptimizer.step)
         ints = [(e, m) for e, m in rest if e.numel() == 1 and not e.is_floating_point()]
         if ints:
             es = torch.stack([e.reshape(()) for e, _ in ints])

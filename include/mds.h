@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 124
+#define MDS_VERSION 125
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -702,6 +702,11 @@ typedef struct {
   float bias1, bias2;            /* 1 - beta1^t, 1 - beta2^t for this step */
   const float* found_inf;        /* optional [1] (GradScaler): the whole update is skipped when != 0 */
   const float* grad_scale;       /* optional [1] (GradScaler): gradients are divided by it on load (no unscale pass) */
+  /* optional device step counter (round 4): with step_in the bias corrections are 1 - beta^(t) for t = *step_in + 1 computed
+   * in the kernel (bias1 / bias2 are ignored), and *step_out = t - or *step_in when the step is skipped on found_inf, as
+   * torch's fused optimizers do not count a skipped step.  step_in != step_out (the host alternates two scalars).            */
+  const float* step_in;
+  float* step_out;
 } mds_adamw_args;
 #define MDS_OPT_CHUNK 4096
 int mds_multi_adamw(const mds_adamw_args* a, mds_stream_t stream);
@@ -722,6 +727,8 @@ typedef struct {
   int first;                     /* 1 on the first step of the group: buf = g (torch initialises the buffer with the gradient) */
   const float* found_inf;        /* optional [1]: skip the update when != 0 */
   const float* grad_scale;       /* optional [1]: gradients are divided by it on load */
+  const float* step_in;          /* optional device step counter as in mds_adamw_args: `first` is then *step_in == 0 */
+  float* step_out;
 } mds_sgd_args;
 int mds_multi_sgd(const mds_sgd_args* a, mds_stream_t stream);
 

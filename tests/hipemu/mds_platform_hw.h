@@ -44,6 +44,7 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
   for (int j = 0; j < 8; ++j) { fa[j] = a[j]; fb[j] = b[j]; }
   mma16_emu(fa, fb, c, false);
 }
+MDS_DEV void mds_wait_stores() {}
 #define MDS_SCHED_FENCE() ((void)0)
 #define MDS_UNIFORM(x) (x)
 #define MDS_DYN_SMEM(name) char* name = hipemu::dyn_smem()

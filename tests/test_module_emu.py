@@ -256,6 +256,72 @@ def test_forward_is_a_registered_operator_traceable_with_fullgraph():
         assert ema(x).shape == (1, 2)
 
 
+def test_two_identical_training_calls_in_one_compiled_graph_both_run():
+    """a training forward updates the BatchNorm running statistics: two identical calls in one compiled graph (the first one's
+    logits unused) must both run - the buffers advance exactly as in eager mode (two momentum updates, num_batches_tracked + 2).
+    The operator is tagged nondeterministic_seeded, so graph passes neither merge nor drop it."""
+    import torch._dynamo as dynamo
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    _, prod = _pair(kw)
+    prod.train()
+    x = torch.rand(1, 15, 32, 64, generator=torch.Generator().manual_seed(5))
+    state = copy.deepcopy(prod.state_dict())
+
+    def twice(m, inp):
+        m(inp)                    # logits unused
+        return m(inp)
+
+    with torch.no_grad():
+        ref = twice(prod, x)
+    want = copy.deepcopy(prod.state_dict())
+    assert int(want["conv2d_encoder.bn1.num_batches_tracked"]) == int(state["conv2d_encoder.bn1.num_batches_tracked"]) + 2
+    prod.load_state_dict(state)
+    dynamo.reset()
+    seen = []
+
+    def backend(gm, example_inputs):
+        seen.extend(str(n.target) for n in gm.graph.nodes if n.op == "call_function")
+        return gm.forward
+    with torch.no_grad():
+        got = torch.compile(twice, fullgraph=True, backend="aot_eager")(prod, x)
+        dynamo.reset()
+        prod.load_state_dict(state)
+        got = torch.compile(twice, fullgraph=True, backend=backend)(prod, x)
+    assert sum("mds.forward" in t for t in seen) == 2, seen
+    assert torch.equal(got, ref)
+    have = prod.state_dict()
+    for k in want:
+        assert torch.equal(have[k], want[k]), k
+    # and the writes are visible to version-keyed caches
+    v0 = prod.conv2d_encoder.bn1.running_mean._version
+    with torch.no_grad():
+        prod(x)
+    assert prod.conv2d_encoder.bn1.running_mean._version > v0
+
+
+def test_a_forward_whose_backward_never_runs_releases_its_plan():
+    """loss evaluated under grad mode and dropped (or an exception before backward): the plan - a whole activation arena - is
+    reusable as soon as the autograd graph dies, not after four later forwards; pickling a module never carries plans"""
+    import gc, pickle
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    _, prod = _pair(kw)
+    prod.train()
+    x = torch.rand(1, 15, 32, 64, generator=torch.Generator().manual_seed(9))
+    out = prod(x)
+    assert len(prod._live) == 1
+    plan = next(iter(prod._live.values()))
+    assert plan.in_flight
+    state = prod.__getstate__()
+    assert state["_live"] == {} and len(prod._live) == 1
+    del out
+    gc.collect()
+    assert len(prod._live) == 0 and not plan.in_flight
+    out = prod(x)                       # the same plan is handed out again
+    assert next(iter(prod._live.values())) is plan
+    out.sum().backward()
+    assert len(prod._live) == 0
+
+
 def test_plan_cache_is_bounded():
     from mds import module as mod
     kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)

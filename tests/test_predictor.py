@@ -146,6 +146,30 @@ def test_weights_written_between_two_frames_are_picked_up(be):
     # re-running the last frame changes nothing (the refresh is complete after one call, not spread over several)
     p_again, _ = sp.predict(frames[30], 30)
     assert torch.equal(p_new.cpu(), p_again.cpu())
+    # the framework's OWN writers go through raw pointers (multi-tensor optimizer, EMA, running statistics of a training forward):
+    # they bump the version counters too, so a predictor kept alive across them never serves stale weights
+    from mds import train
+    train.LIB = be.lib if be.name == "emu" else None
+    try:
+        opt = train.FusedAdamW(list(prod.parameters()), lr=0.05)
+        for p in prod.parameters():
+            p.grad = torch.full_like(p, 0.5)
+        opt.step()
+        p_opt, _ = sp.predict(frames[30], 30)
+        assert not torch.equal(p_opt.cpu(), p_new.cpu()), "an optimizer step between two frames was not picked up"
+        ema = train.ModelEma(prod, decay=0.5)
+        sp_e = StreamPredictor(ema.ema, frame_size=(64, 32), use_graphs=False)
+        for i in range(31):
+            e0, _ = sp_e.predict(frames[i], i)
+        with torch.no_grad():
+            for p in prod.parameters():
+                p.mul_(0.5)
+        ema.update(prod)
+        e1, _ = sp_e.predict(frames[30], 30)
+        assert not torch.equal(e0.cpu(), e1.cpu()), "an EMA update between two frames was not picked up"
+        sp_e.close()
+    finally:
+        train.LIB = None
 
 
 def test_chunked_prediction_encodes_every_stack_once(be):

@@ -164,12 +164,52 @@ def test_fused_optimizers_take_grad_scale_and_found_inf_on_the_device(lib, which
         if overflow:
             for b, q in zip(before, mine):
                 assert torch.equal(b, q.detach()), "a step with found_inf set must leave parameters untouched"
-            if which == "adamw":          # torch's fused AdamW rewinds its step count on overflow; ours counts on the host
-                mo._g[0]["step"] -= 1
-            continue
+            continue                      # (the device step counter did not advance: next step's bias corrections are torch's)
         ro.step()
     for p, q in zip(ref, mine):
         torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("which", ["adamw", "sgd"])
+def test_a_step_skipped_on_found_inf_does_not_count(lib, which):
+    """GradScaler skips the first fp16 steps (found_inf): torch's optimizers do not advance their step then, so the bias
+    corrections (AdamW) and the first-step momentum initialisation (SGD with dampening) of the NEXT step are those of step 1.
+    The counter lives on the device; state_dict() reports it."""
+    g = torch.Generator().manual_seed(11)
+    ref = [torch.randn(300, generator=g).requires_grad_(True), torch.randn(5000, generator=g).requires_grad_(True)]
+    mine = [lib.t(p.detach().clone()).requires_grad_(True) for p in ref]
+    if which == "adamw":
+        ro = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.99))
+        mo = train.FusedAdamW(mine, lr=1e-2, betas=(0.9, 0.99))
+    else:
+        ro = torch.optim.SGD(ref, lr=1e-2, momentum=0.9, dampening=0.3)
+        mo = train.FusedSGD(mine, lr=1e-2, momentum=0.9, dampening=0.3)
+    versions = [q._version for q in mine]
+    for step, inf in enumerate([1.0, 0.0, 1.0, 0.0, 0.0]):
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad = gr.clone(); q.grad = lib.t(gr)
+        mo.found_inf = lib.t(torch.tensor([inf])); mo.grad_scale = lib.t(torch.tensor([1.0]))
+        mo.step()
+        if not inf:
+            ro.step()
+    lib.sync()
+    for p, q in zip(ref, mine):
+        torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-5, atol=1e-6)
+    assert float(mo.state_dict()["state"][0]["step"]) == 3.0
+    assert all(q._version > v for q, v in zip(mine, versions)), "parameters written by the kernel must bump their version"
+
+
+def test_model_ema_update_bumps_versions(lib):
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+    m = m.to(lib.device)
+    ema = train.ModelEma(m, decay=0.5)
+    with torch.no_grad():
+        m[0].weight.add_(1.0)
+    v = ema.ema[0].weight._version
+    ema.update(m)
+    lib.sync()
+    assert ema.ema[0].weight._version > v
 
 
 def test_fused_optimizer_follows_parameter_reallocation(lib):
