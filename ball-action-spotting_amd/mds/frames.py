@@ -47,6 +47,11 @@ def open_rocdecode(video_path, gpu_id: int):
 
 
 class RocDecFrameFetcher:
+    """Frames are produced by ONE primitive, `_luma_into(surface, out)`: the decoder's pitched surface is copied (mds_frame_luma)
+    straight into the caller's destination - a fresh (H, W) tensor for `fetch_frame`, row k of a preallocated (n, H, W) clip for
+    `fetch_frames`, a slot of StreamPredictor's frame ring for `fetch_into`.  There are no per-frame temporaries and no stack /
+    concatenate pass: a clip costs n streaming copies into its final place."""
+
     def __init__(self, video_path: str | Path, gpu_id: int, decoder: Any = None):
         self.video_path = Path(video_path)
         self.gpu_id = gpu_id
@@ -54,65 +59,75 @@ class RocDecFrameFetcher:
         self.num_frames = int(self._dec.num_frames)
         self.width = int(self._dec.width)
         self.height = int(self._dec.height)
-        self._current_index = -1          # (VPF "skips the first frame at start": nvdec.py:21 starts at 0; a backend states its own origin)
+        self._cursor = -1                 # index of the last frame HANDED OUT (the reference's `_current_index`, nvdec.py:21 / abstract.py:22-24)
         self._lib = None                  # tests inject the kernel simulator here
+        self._pending = []                # surfaces whose asynchronous copy may still be running
 
-    # ------------------------------------------------------------------ src/frame_fetchers/abstract.py, restated
     @property
     def current_index(self) -> int:
-        return self._current_index
+        return self._cursor
 
     def _device(self):
         return torch.device("cpu") if self._lib is not None else torch.device("cuda", self.gpu_id)
 
-    def fetch_frame(self, index: Optional[int] = None) -> torch.Tensor:
-        try:
-            if index is None:
-                if self._current_index < self.num_frames - 1:
-                    frame = self._next_decode()
-                    self._current_index += 1
-                else:
-                    raise RuntimeError("End of frames")
-            else:
-                if index < 0 or index >= self.num_frames:
-                    raise RuntimeError(f"Frame index {index} out of range")
-                frame = self._seek_and_decode(index)
-                self._current_index = index
-            frame = self._convert(frame)
-        except BaseException as error:      # abstract.py:40-48: a broken frame becomes an empty one, the stream goes on
-            logger.error(f"Error while fetching frame {index} from '{str(self.video_path)}': {error}."
-                         f"Replace by empty frame.")
-            frame = torch.zeros(self.height, self.width, dtype=torch.uint8, device=self._device())
-        return frame
-
-    def fetch_frames(self, indexes: list[int]) -> torch.Tensor:
-        min_frame_index, max_frame_index = min(indexes), max(indexes)
-        index2frame = dict()
-        frame_indexes_set = set(indexes)
-        for index in range(min_frame_index, max_frame_index + 1):
-            if index not in frame_indexes_set:
-                self._next_decode()
-                continue
-            index2frame[index] = self.fetch_frame(index) if index == min_frame_index else self.fetch_frame()
-        return torch.stack([index2frame[index] for index in indexes], dim=0)
-
-    # ------------------------------------------------------------------ decoder backend + the device-side conversion
-    def _next_decode(self) -> Any:
-        return self._dec.decode_next()
-
-    def _seek_and_decode(self, index: int) -> Any:
-        return self._dec.seek_and_decode(index)
-
-    def _convert(self, surface: Any, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """pitched surface -> (H, W) uint8 tensor (or into `out`, e.g. a slot of StreamPredictor's frame ring)"""
+    # ------------------------------------------------------------------ the primitive
+    def _luma_into(self, surface: Any, out: torch.Tensor) -> None:
+        """luma plane of a pitched NV12 / Y surface -> `out` ((H, W) uint8, contiguous), asynchronously on the current stream"""
         ptr, pitch, keep = surface
-        dev = self._device()
-        if out is None:
-            out = torch.empty(self.height, self.width, dtype=torch.uint8, device=dev)
         lib = self._lib if self._lib is not None else cabi.load()
         args = cabi.make("mds_frame_luma_args", width=self.width, height=self.height, pitch=int(pitch), count=1, src=int(ptr),
                          surface_stride=0, dst=out)
-        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        stream = torch.cuda.current_stream(out.device).cuda_stream if out.is_cuda else 0
         lib.check(lib.fn["frame_luma"](C.byref(args), stream), "frame_luma")
-        self._keep = (keep, out)            # the copy is asynchronous: the surface must outlive it
+        self._pending.append((keep, out))       # the surface must outlive the copy
+        del self._pending[:-8]
+
+    def _produce(self, out: torch.Tensor, at: Optional[int]) -> None:
+        """fill `out` with frame `at` (seek + decode) or, for at=None, with the decoder's next frame.  Contract of the reference
+        (abstract.py:26-48): the position counter moves only when a frame was decoded, and ANY failure - end of stream, index out
+        of range, a corrupt packet, a conversion error - is logged and yields an all-zero frame instead of an exception."""
+        try:
+            if at is None:
+                if self._cursor + 1 >= self.num_frames:
+                    raise EOFError("End of frames")
+                surface = self._dec.decode_next()
+                self._cursor += 1
+            else:
+                if not 0 <= at < self.num_frames:
+                    raise IndexError(f"Frame index {at} out of range")
+                surface = self._dec.seek_and_decode(at)
+                self._cursor = at
+            self._luma_into(surface, out)
+        except BaseException as error:
+            logger.error(f"Error while fetching frame {at} from '{str(self.video_path)}': {error}."
+                         f"Replace by empty frame.")
+            out.zero_()
+
+    # ------------------------------------------------------------------ the reference's interface
+    def fetch_frame(self, index: Optional[int] = None) -> torch.Tensor:
+        out = torch.empty(self.height, self.width, dtype=torch.uint8, device=self._device())
+        self._produce(out, index)
         return out
+
+    def fetch_into(self, indexes, out: torch.Tensor) -> torch.Tensor:
+        """frames `indexes` (any order, repeats allowed) into out[k] - one forward sweep of the decoder from the smallest to the
+        largest index: a seek to the first wanted frame, then sequential decode; frames in between that nobody asked for are
+        decoded and dropped (abstract.py:50-68)."""
+        assert out.shape == (len(indexes), self.height, self.width) and out.dtype == torch.uint8 and out.is_contiguous()
+        rows = {}
+        for k, index in enumerate(indexes):
+            rows.setdefault(index, []).append(k)
+        first, last = min(rows), max(rows)
+        for index in range(first, last + 1):
+            ks = rows.get(index)
+            if ks is None:
+                self._dec.decode_next()                      # skipped frame: the decoder moves, nothing is copied
+                continue
+            self._produce(out[ks[0]], first if index == first else None)
+            for k in ks[1:]:
+                out[k].copy_(out[ks[0]])
+        return out
+
+    def fetch_frames(self, indexes: list[int]) -> torch.Tensor:
+        clip = torch.empty(len(indexes), self.height, self.width, dtype=torch.uint8, device=self._device())
+        return self.fetch_into(indexes, clip)

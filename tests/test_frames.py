@@ -73,6 +73,21 @@ def test_fetch_frames_sweeps_forward_once(be):
     assert dec.decoded == [2, 3, 4, 5, 6]                     # one seek, then sequential decode; skipped frames decoded and dropped
 
 
+def test_fetch_into_writes_in_place_any_order_with_repeats(be):
+    """the clip is written in its final place (no per-frame tensors, no stack): rows follow the ORDER of `indexes`, a repeated
+    index is decoded once, a corrupt frame is a zero row, and the destination may be a view of a larger ring"""
+    f, dec = _fetcher(be)
+    ring = torch.full((6, 20, 50), 7, dtype=torch.uint8, device=be.device)
+    idx = [8, 6, 7, 6]
+    out = f.fetch_into(idx, ring[1:5])
+    be.sync()
+    assert out.data_ptr() == ring[1:5].data_ptr()
+    assert torch.equal(ring[1].cpu(), dec.luma[8]) and torch.equal(ring[2].cpu(), dec.luma[6]) and torch.equal(ring[4].cpu(), dec.luma[6])
+    assert ring[3].abs().sum().item() == 0                      # frame 7 is corrupt
+    assert (ring[0] == 7).all() and (ring[5] == 7).all()        # nothing outside the destination was touched
+    assert dec.decoded == [6, 8]                                # one seek + sequential decode (7 raised inside the decoder)
+
+
 @pytest.mark.parametrize("w,h,pitch,count", [(50, 20, 64, 1), (1280, 720, 1280, 2), (720, 33, 768, 3), (17, 5, 32, 2)])
 def test_frame_luma_kernel(be, w, h, pitch, count):
     g = torch.Generator().manual_seed(w + h)
