@@ -510,7 +510,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
     }
     MDS_REQUIRE(nt_ == a->ntaps && a->is == 1 && !a->residual && !a->stats, "conv_fwd: tap groups partition the tap list (is = 1, no residual / statistics)");
   }
-  if (!a->residual && !mds_switch(MDS_SW_CONV_OLD)) {  // persistent variant when a filter slab + one whole-channel input patch fit in LDS
+  if (!a->residual) {  // persistent variant when a filter slab + one whole-channel input patch fit in LDS
     const int KS = cdiv(a->ntaps * a->Cin, 32);
     const int esz = a->dtype == MDS_BF16 ? 2 : 4;
     const int co16 = a->Cout / 16;

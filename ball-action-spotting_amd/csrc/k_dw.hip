@@ -1132,12 +1132,12 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "dw_fwd: prologue");
   MDS_REQUIRE(a->pro.mode != MDS_PRO_BN_SILU_GATE, "dw_fwd: gate prologue unsupported");
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_fwd: grid.z");
-  MDS_REQUIRE(a->epi.mode == MDS_EPI_NONE || (a->epi.scale && a->epi.shift && !a->stats && !mds_switch(MDS_SW_DW_OLD) && (a->kt == 1 || a->T == DW3_T)),
+  MDS_REQUIRE(a->epi.mode == MDS_EPI_NONE || (a->epi.scale && a->epi.shift && !a->stats && (a->kt == 1 || a->T == DW3_T)),
               "dw_fwd: an output transform needs scale/shift, no statistics, and a sliding-window kernel (kt == 1, or T == %d)", DW3_T);
-  MDS_REQUIRE(!a->pool || (a->epi.mode != MDS_EPI_NONE && !a->stats && a->pool_inv > 0.f && !mds_switch(MDS_SW_DW_OLD) &&
+  MDS_REQUIRE(!a->pool || (a->epi.mode != MDS_EPI_NONE && !a->stats && a->pool_inv > 0.f &&
                            ((a->kt == 1 && a->T == 1) || (a->kt == 3 && a->T == DW3_T))),
               "dw_fwd: pooling needs an output transform, no statistics, pool_inv, and a sliding-window kernel (kt == 1 with T == 1, or kt == 3 with T == %d)", DW3_T);
-  if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
+  if (a->kt == 1 && a->stride == 1) {
     MDS_REQUIRE(a->pad_t == 1 && a->pad_l == 1 && a->OH == a->IH && a->OW == a->IW, "dw_fwd: stride-1 geometry");
     // one or two images (the frame-by-frame predictor): 6-row bands with the shortest strips are 50-110 blocks - under one wave per
     // SIMD, every column a full memory round trip.  Two-row bands give three times the threads ((R + 2) / R = 2x the row reads,
@@ -1157,14 +1157,14 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
     }
     return mds_check_launch("dw_fwd");
   }
-  if (a->kt == 1 && a->stride == 2 && !mds_switch(MDS_SW_DW_OLD)) {
+  if (a->kt == 1 && a->stride == 2) {
     DwStrips g = dw_strips(a->N * a->T, a->OH, a->OW, a->C, 3);
     dim3 grid = dw_grid(g), block(256);
     if (a->pool) MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2s_fwd_kernel<T, true>), grid, block, 0, stream, *a, g));
     else MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2s_fwd_kernel<T, false>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_fwd");
   }
-  if (a->kt == 3 && a->T == DW3_T && !mds_switch(MDS_SW_DW_OLD)) {
+  if (a->kt == 3 && a->T == DW3_T) {
     DwStrips g = dw_strips(a->N, a->OH, a->OW, a->C, 1, dw3_len(a->N, a->OH, a->OW, a->C, 20));
     dim3 grid = dw_grid(g), block(256);
     if (a->pool) MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw3_fwd_kernel<T, true>), grid, block, 0, stream, *a, g));
@@ -1406,14 +1406,14 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_BN_SILU && a->pro.scale && a->pro.shift, "dw_bwd: needs the BN+SiLU prologue of the forward");
   MDS_REQUIRE(a->stride == 2 ? (a->pad_l == 0 || a->pad_l == 1) : (a->pad_l == 1 && a->pad_t == 1), "dw_bwd: pad=(%d,%d) unsupported for stride %d", a->pad_t, a->pad_l, a->stride);
   MDS_REQUIRE((long)a->N * 64 < 65536, "dw_bwd: grid.z");
-  if (a->kt == 1 && a->stride == 1 && !mds_switch(MDS_SW_DW_OLD)) {
+  if (a->kt == 1 && a->stride == 1) {
     MDS_REQUIRE(a->OH == a->IH && a->OW == a->IW, "dw_bwd: stride-1 geometry");
     DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4, dw2_len(a->N * a->T, a->IH, a->IW, a->C, 4));
     dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw2_bwd_kernel<T, 4>), grid, block, 0, stream, *a, g));
     return mds_check_launch("dw_bwd");
   }
-  if (a->kt == 1 && a->stride == 2 && !mds_switch(MDS_SW_DW_OLD)) {
+  if (a->kt == 1 && a->stride == 2) {
     MDS_REQUIRE((a->pad_t == 0 || a->pad_t == 1), "dw_bwd: pad_t");
     DwStrips g = dw_strips(a->N * a->T, a->IH, a->IW, a->C, 4, 16, true);
     dim3 grid = dw_grid(g), block(256);
@@ -1425,7 +1425,7 @@ extern "C" int mds_dw_bwd(const mds_dw_bwd_args* a, mds_stream_t stream) {
     });
     return mds_check_launch("dw_bwd");
   }
-  if (a->kt == 3 && a->T == DW3_T && !mds_switch(MDS_SW_DW_OLD)) {
+  if (a->kt == 3 && a->T == DW3_T) {
     DwStrips g = dw_strips(a->N, a->IH, a->IW, a->C, 1, dw3_len(a->N, a->IH, a->IW, a->C, 16));
     dim3 grid = dw_grid(g), block(256);
     MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(dw3_bwd_kernel<T>, grid, block, 0, stream, *a, g));

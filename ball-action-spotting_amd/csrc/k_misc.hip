@@ -20,11 +20,6 @@ int mds_check_launch(const char* what) {
   }
   return 0;
 }
-bool mds_switch(int id) {   // thread-safe one-time read (C++11 static initialisation)
-  static const bool v[MDS_SW_COUNT] = {getenv("MDS_DW_OLD") != 0, getenv("MDS_CONV_OLD") != 0, getenv("MDS_WG_OLD") != 0,
-                                       getenv("MDS_STEM_OLD") != 0};
-  return id >= 0 && id < MDS_SW_COUNT && v[id];
-}
 #include <atomic>
 static std::atomic<int> g_knob[MDS_KNOB_COUNT];
 int mds_knob(int id) { return id >= 0 && id < MDS_KNOB_COUNT ? g_knob[id].load(std::memory_order_relaxed) : 0; }
@@ -456,79 +451,3 @@ extern "C" int mds_head_bwd(const mds_head_bwd_args* a, mds_stream_t stream) {
   return mds_check_launch("head_bwd");
 }
 
-// ------------------------------------------------------------------ linear form of BatchNorm backward (include/mds.h)
-// prep: one block per input channel k (<= 192): its packed weight row { A[n] W[n][k] | Q[j][k] } and bias[k] = sum_n D[n] W[n][k].
-// mid * cin MACs per block (<= 221 k), W (<= 885 KB) read from L2 by every block: a ~10 us launch on the dependent chain.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_lin_prep_kernel(mds_bn_lin_prep_args a) {
-  __shared__ float wk[1152 + 8];      // B[n] * W[n][k] for this block's k  (Cmid <= 1152)
-  __shared__ float red[256];
-  const int k = blockIdx.x, tid = threadIdx.x, Cmid = a.Cmid, Cin = a.Cin;
-  const int Kp = (Cmid + 63) & ~63, K1p = (Cin + 63) & ~63, WL = Kp + K1p;
-  T* row = (T*)a.wcat + (long)k * WL;
-  const float* A = a.lin; const float* B = a.lin + Cmid; const float* D = a.lin + 2 * Cmid;
-  float bsum = 0.f;
-  for (int n = tid; n < Kp; n += 256) {
-    float wv = 0.f, av = 0.f;
-    if (n < Cmid) { wv = a.w[(long)n * Cin + k]; av = A[n] * wv; wk[n] = B[n] * wv; bsum += D[n] * wv; }
-    Elem<T>::st(row + n, av);
-  }
-  red[tid] = bsum;
-  __syncthreads();
-  for (int s_ = 128; s_ > 0; s_ >>= 1) { if (tid < s_) red[tid] += red[tid + s_]; __syncthreads(); }
-  if (tid == 0) a.bias[k] = red[0];
-  // Q[j][k] = sum_n W[n][j] * (B[n] W[n][k]): lane group tn (4 of them) takes the rows n = tn, tn + 4, ...; a thread holds up
-  // to four columns j = tj + 64 i (coalesced rows of W, four independent accumulators), then the four partial sums meet in LDS
-  __shared__ float part[4][256];
-  const int tj = tid & 63, tn = tid >> 6;
-  float q[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int n = tn; n < Cmid; n += 4) {
-    const float b = wk[n];
-    const float* wr = a.w + (long)n * Cin;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (tj + 64 * i < Cin) q[i] += wr[tj + 64 * i] * b;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) part[tn][tj + 64 * i] = q[i];
-  __syncthreads();
-  if (tid < K1p) Elem<T>::st(row + Kp + tid, tid < Cin ? (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]) : 0.f);
-}
-extern "C" int mds_bn_lin_prep(const mds_bn_lin_prep_args* a, mds_stream_t stream) {
-  MDS_REQUIRE(a && a->w && a->lin && a->wcat && a->bias, "bn_lin_prep: null pointer");
-  MDS_REQUIRE(a->Cmid > 0 && a->Cmid <= 1152 && a->Cin > 0 && a->Cin <= 256 && a->Cin % 8 == 0, "bn_lin_prep: Cmid <= 1152, Cin <= 256 (multiple of 8)");
-  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_lin_prep_kernel<T>, dim3(a->Cin), dim3(256), 0, stream, *a));
-  return mds_check_launch("bn_lin_prep");
-}
-
-// the last two terms of dW:  dw[n][k] += B[n] * sum_j W[n][j] gram[j][k] + D[n] * colsum[k];  block = 8 rows n, thread = k
-__global__ __launch_bounds__(256) void bn_lin_wgrad_kernel(mds_bn_lin_wgrad_args a) {
-  __shared__ float wrow[8][256];
-  const int tid = threadIdx.x, Cin = a.Cin, n0 = blockIdx.x * 8;
-  for (int e = tid; e < 8 * Cin; e += 256) {
-    const int r = e / Cin, j = e - r * Cin;
-    wrow[r][j] = n0 + r < a.Cmid ? a.w[(long)(n0 + r) * Cin + j] : 0.f;
-  }
-  double cs = 0.0;
-  if (tid < Cin)
-    for (int s_ = 0; s_ < MDS_STAT_SLOTS; ++s_) cs += a.colsum[(long)s_ * 2 * Cin + tid];
-  __syncthreads();
-  if (tid >= Cin) return;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int j = 0; j < Cin; ++j) {
-    const float g = a.gram[(long)j * Cin + tid];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] += wrow[r][j] * g;
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int n = n0 + r;
-    if (n < a.Cmid) a.dw[(long)n * Cin + tid] += a.lin[a.Cmid + n] * acc[r] + a.lin[2 * a.Cmid + n] * (float)cs;   // (this launch owns dw[n][:] after the weight-gradient GEMM on the same stream)
-  }
-}
-extern "C" int mds_bn_lin_wgrad(const mds_bn_lin_wgrad_args* a, mds_stream_t stream) {
-  MDS_REQUIRE(a && a->w && a->lin && a->gram && a->colsum && a->dw, "bn_lin_wgrad: null pointer");
-  MDS_REQUIRE(a->Cmid > 0 && a->Cin > 0 && a->Cin <= 256, "bn_lin_wgrad: Cin <= 256");
-  MDS_LAUNCH(bn_lin_wgrad_kernel, dim3(cdiv(a->Cmid, 8)), dim3(256), 0, stream, *a);
-  return mds_check_launch("bn_lin_wgrad");
-}

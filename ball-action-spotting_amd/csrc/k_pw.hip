@@ -28,27 +28,15 @@ template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 //                      1 -> 128x64 tile (4x1 waves of 32x64), ~160 VGPRs, three blocks per CU.
 // BM = rows per tile: 128, or 64 for the small-M layers (stage 5 / 3D: 18400 rows are only 144 tiles of 128 —
 //      fewer blocks than CUs); WN = 2 only.
-// PRO == PW_PRO_DY: the x operand is dy = A*g + B*y + D formed on load (mds_dyp_t); POST: BatchNorm-backward
-// sums of the NEXT layer over the output tile in the epilogue (mds_poststat_t).
-#define PW_PRO_DY 5
-// TAIL: 0 = plain epilogue, 1 = POST (BatchNorm-backward sums of the next layer, mds_poststat_t), 2 = EPI (mds_epi_t)
-// DEEP (opt-in through MDS_KNOB_PW_DEEP; K >= 4 chunks, 64-row tiles, NONE / GATE prologue): TWO K chunks in flight.  With 16 MFMAs per chunk and wave a chunk
-// is ~250 clocks of arithmetic against a ~2 us load, so the K-heavy projections (672 -> 112, 1152 -> 192 and their data
-// gradients) waited a full memory latency per chunk.  The ring follows k_pwr.hip's vmcnt discipline: every load is issued
-// unconditionally from a clamped address (zeroed in registers when staged), refills are never tested, and an odd chunk
-// count runs one all-zero phantom chunk instead of a branch.  Measured: the compiler still waits vmcnt(0) for the first set
-// (the second gets counted waits), the gated variant drops to two blocks per CU for registers, and the step is 1 % slower -
-// kept behind the knob with its tests as the starting point for a proper multi-stage K pipeline.
-// TWO: a second operand pair and a bias row (the LINEAR form of BatchNorm backward in a data gradient, mds_pw_fwd_args):
-//   y = x[M][K] w[:, 0:K]^T + x1[M][K1] w[:, Kp:Kp+K1]^T + bias,  Kp = K rounded up to 64 - the K loop simply runs over both
-// pairs, w rows hold both weight sets (zero padded), rows of x / x1 past their own K are staged as zeros.
+// TAIL: 0 = plain epilogue, 1 = POST (BatchNorm-backward sums of the NEXT layer over the output tile, mds_poststat_t),
+//       2 = EPI (mds_epi_t).
+// (Measured and removed, DESIGN 5: the x operand formed on load as dy = A*g + B*y + D, a second operand pair + bias row for the
+//  linear form of BatchNorm backward, two K chunks in flight for the K-heavy layers.)
 // SPLIT (inference plans, small M): grid.z blocks share an output tile, each over its own K range; partial tiles go to
 //   split_part[z][M][N] (fp32), the last block to finish the tile (ticket) adds them in z order and runs the epilogue.
-template <typename T, int PRO, int WN, int BM, int TAIL, int DEEP = 0, bool TWO = false, bool SPLIT = false>
-__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || TAIL == 1 || (DEEP && PRO == MDS_PRO_GATE) || SPLIT ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
-  static_assert(!SPLIT || (!DEEP && !TWO && TAIL != 1 && (PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && WN == 2 && BM == 64), "SPLIT variants");
-  static_assert(!DEEP || ((PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && BM == 64 && WN == 2 && TAIL != 2), "DEEP variants");
-  static_assert(!TWO || (PRO == MDS_PRO_NONE && !DEEP && TAIL != 2), "two operand pairs: plain prologue, no output transform");
+template <typename T, int PRO, int WN, int BM, int TAIL, bool SPLIT = false>
+__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+  static_assert(!SPLIT || (TAIL != 1 && (PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && WN == 2 && BM == 64), "SPLIT variants");
   constexpr bool POST = TAIL == 1, EPI = TAIL == 2;
   typedef typename Frag<T>::type frag_t;
   typedef Mma<T, EPI && sizeof(T) == 4 && MDS_EVAL_X3> MM;   // inference plans in fp32: split-bf16 products (platform.h)
@@ -68,22 +56,18 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const long m0 = (long)blockIdx.x * BM;
   const int N = a.N;
-  const int K0 = a.K, K0p = (K0 + 63) & ~63, K1 = TWO ? a.K1 : 0;
-  const int K = TWO ? K0p + ((K1 + 63) & ~63) : K0;       // length of the K loop = length of a packed weight row
+  const int K = a.K;
   // SPLIT: this block's K range [KB, KE) (whole chunks); K stays the row pitch
   const int kper = SPLIT ? ((K + (int)gridDim.z * PwCfg<T>::KC - 1) / ((int)gridDim.z * PwCfg<T>::KC)) * PwCfg<T>::KC : K;
   const int KB = SPLIT ? (int)blockIdx.z * kper : 0;
   const int KE = SPLIT ? (KB + kper < K ? KB + kper : K) : K;
-  const T* x1 = (const T*)a.x1;
-  const T* x = (const T*)(PRO == PW_PRO_DY ? a.xdy.g.u : a.x);
+  const T* x = (const T*)a.x;
   const T* w = (const T*)a.w;
   T* y = (T*)a.y;
-  const long ydiff = PRO == PW_PRO_DY ? (const T*)a.xdy.y - x : 0;   // the BN input y has x's layout
-  const int gmode = PRO == PW_PRO_DY ? a.xdy.g.mode : 0;
   const int svec = tid % VPR, srow = tid / VPR;  // staging: this thread's k-offset and first row
   int grow[NL];  // squeeze-excite gate / DropPath-mask row of each staged row (one division per row per block)
-  if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE || (PRO == PW_PRO_DY && gmode == MDS_G_MASK)) {
-    const long rpg = PRO == PW_PRO_DY ? a.xdy.g.rows_per_group : a.pro.rows_per_group;
+  if (PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE) {
+    const long rpg = a.pro.rows_per_group;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       const long m = m0 + srow + RPP * l;
@@ -97,7 +81,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
   for (int l = 0; l < NL; ++l) {
     const long m = m0 + srow + RPP * l;
     xok[l] = m < a.M;
-    xrow[l] = x + (xok[l] ? m : 0) * K0 + 8 * svec;
+    xrow[l] = x + (xok[l] ? m : 0) * K + 8 * svec;
   }
   for (int n0 = blockIdx.y * BN; n0 < N; n0 += gridDim.y * BN) {
     int nfr = (N - n0 - 64 * wn) >> 4;  // valid 16-column fragments of this wave
@@ -111,8 +95,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
     // POST: the next BatchNorm's table entries and this lane's post.y fragments are requested HERE, ahead of the K loop
     // (they were three exposed memory round trips in the epilogue: the table, then one per fragment row)
     RawV4<T> rys[POST ? MFW : 1][4];
-    float pb[4] = {0.f, 0.f, 0.f, 0.f}, pbias = 0.f;
-    if (TWO && a.bias && tid < BN && n0 + tid < N) pbias = a.bias[n0 + tid];
+    float pb[4] = {0.f, 0.f, 0.f, 0.f};
     if (EPI && tid < BN && n0 + tid < N) { pb[0] = a.epi.scale[n0 + tid]; pb[1] = a.epi.shift[n0 + tid]; }   // same for the output transform's table
     if (POST) {
       if (tid < BN && n0 + tid < N) {
@@ -129,8 +112,8 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       }
     }
 
-    constexpr int NS = DEEP ? 2 : 1;
-    RawV8<T> rx[NS][NL], rw[NS][NLW], ry[PRO == PW_PRO_DY ? NL : 1];
+    constexpr int NS = 1;
+    RawV8<T> rx[NS][NL], rw[NS][NLW];
     // the squeeze-excite gate row of every staged x vector travels WITH it (same issue point): loaded inside the staging
     // loop it was one exposed L2 round trip per K chunk - 18 of them in the 1152 -> 192 projections
     // (the variants that would spill with 8 more registers per row keep the in-loop load: 128-row tiles, BN_SILU_GATE)
@@ -147,37 +130,9 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
     }
     auto issue = [&](int kc, RawV8<T> (&tx)[NL], RawV8<T> (&tw)[NLW], float (&tg)[GPRE ? NL : 1][8]) {  // all global loads of one K-chunk
       const bool kok = kc + 8 * svec < KE;
-      if (DEEP) {   // straight-line: rows are clamped in xrow / wrow, channels past K read channel 0; zeroed when staged
-        const int ko = kok ? kc : -8 * svec;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-          tx[l].ld(xrow[l] + ko);
-          if (GPRE) load8f(a.pro.gate + (long)grow[l] * K + (kok ? kc + 8 * svec : 0), tg[l]);
-        }
-#pragma unroll
-        for (int l = 0; l < NLW; ++l) tw[l].ld(wrow[l] + ko);
-        return;
-      }
-      if (TWO) {   // which pair this chunk belongs to is uniform; the weight row is one contiguous [Kp | K1p] vector
-        const bool p1 = kc >= K0p;
-        const int kl = (p1 ? kc - K0p : kc) + 8 * svec;
-        const bool kin2 = kl < (p1 ? K1 : K0);
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-          const long m = m0 + srow + RPP * l;
-          const T* px = p1 ? x1 + (xok[l] ? m : 0) * K1 + kl : xrow[l] + kc;
-          if (xok[l] && kin2) tx[l].ld(px); else tx[l].zero();
-        }
-#pragma unroll
-        for (int l = 0; l < NLW; ++l) {
-          if (wok[l]) tw[l].ld(wrow[l] + kc); else tw[l].zero();
-        }
-        return;
-      }
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
         if (xok[l] && kok) tx[l].ld(xrow[l] + kc); else tx[l].zero();
-        if (PRO == PW_PRO_DY) { if (xok[l] && kok) ry[l].ld(xrow[l] + ydiff + kc); else ry[l].zero(); }
         if (GPRE) load8f(a.pro.gate + (long)grow[l] * K + (kok ? kc + 8 * svec : 0), tg[l]);   // grow is clamped: always legal
       }
 #pragma unroll
@@ -192,29 +147,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       if (PRO == MDS_PRO_NONE) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-          if (DEEP && !(xok[l] && kin)) tx[l].zero();
           tx[l].st(xs + (srow + RPP * l) * LD + 8 * svec);
-        }
-      } else if (PRO == PW_PRO_DY) {
-#pragma unroll
-        for (int l = 0; l < NLW; ++l) tw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);   // frees the filter registers first
-        float cA[8], cB[8], cD[8];
-        if (kin) { load8f(a.xdy.lin + kk, cA); load8f(a.xdy.lin + K + kk, cB); load8f(a.xdy.lin + 2 * K + kk, cD); }
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-          const int r = srow + RPP * l;
-          float u[8], yv[8];
-          tx[l].get(u);
-          ry[l].get(yv);
-          if (xok[l] && kin) {
-            const float mk = gmode == MDS_G_MASK ? a.xdy.g.mask[grow[l]] : 1.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = cA[j] * (u[j] * mk) + cB[j] * yv[j] + cD[j];
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = 0.f;   // rows past M / channels past K contribute nothing (D != 0)
-          }
-          store8(xs + r * LD + 8 * svec, u);
         }
       } else {
         float sc[8], sh[8];
@@ -242,27 +175,18 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] *= g[j];
             }
-          } else if (DEEP) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
           }
           store8(xs + r * LD + 8 * svec, v);
         }
       }
-      if (PRO != PW_PRO_DY) {
 #pragma unroll
-        for (int l = 0; l < NLW; ++l) {
-          if (DEEP && !(wok[l] && kin)) tw[l].zero();
-          tw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
-        }
-      }
+      for (int l = 0; l < NLW; ++l) tw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
       __syncthreads();
-      if (DEEP) issue(kc + 2 * KC, tx, tw, tg);            // refill this set (past K: clamped reads, never staged as data)
-      else if (kc + KC < KE) issue(kc + KC, tx, tw, tg);    // in flight while the MFMAs below run
-      const int ksteps = (KE - kc >= KC) ? KC / 32 : ((KE - kc + 31) >> 5);   // <= 0 for the phantom chunk of an odd count
+      if (kc + KC < KE) issue(kc + KC, tx, tw, tg);    // in flight while the MFMAs below run
+      const int ksteps = (KE - kc >= KC) ? KC / 32 : ((KE - kc + 31) >> 5);
 #pragma unroll
       for (int ks = 0; ks < KC / 32; ++ks) {
-        if (DEEP || ks < ksteps) {   // DEEP: no branch between a refill and its wait (channels past K are staged as zeros)
+        if (ks < ksteps) {
           typename MM::frag xf[MFW];
 #pragma unroll
           for (int mf = 0; mf < MFW; ++mf) xf[mf] = MM::prep(ld_frag(xs + (16 * MFW * wm + 16 * mf + i) * LD + 32 * ks + 8 * q));
@@ -276,15 +200,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
       }
     };
     if (!SPLIT || KB < KE) issue(KB, rx[0], rw[0], rg[0]);
-    if (DEEP) {
-      issue(KC, rx[NS - 1], rw[NS - 1], rg[NS - 1]);
-      for (int kc = 0; kc < K; kc += 2 * KC) {
-        chunk(kc, rx[0], rw[0], rg[0]);
-        chunk(kc + KC, rx[NS - 1], rw[NS - 1], rg[NS - 1]);
-      }
-    } else {
-      for (int kc = KB; kc < KE; kc += KC) chunk(kc, rx[0], rw[0], rg[0]);
-    }
+    for (int kc = KB; kc < KE; kc += KC) chunk(kc, rx[0], rw[0], rg[0]);
     if (SPLIT) {
       // partial tile -> split_part[z]; ticket; the last block of the tile sums the partials in z order (its own included:
       // the order is fixed, so the result does not depend on which block came last) and goes on to the epilogue
@@ -346,15 +262,12 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
     float ps[16], pss[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { ps[e] = 0.f; pss[e] = 0.f; }
-    float* pbn = (float*)smem;   // POST: [4][BN] scale, shift, mean, rstd of the tile's columns (over the finished x/w tiles); TWO: [4][:] = bias
-    if (POST || TWO) {
+    float* pbn = (float*)smem;   // POST: [4][BN] scale, shift, mean, rstd of the tile's columns (over the finished x/w tiles)
+    if (POST) {
       __syncthreads();           // every wave is done with the fragment reads of the last chunk
       if (tid < BN) {
-        if (POST) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) pbn[k * BN + tid] = pb[k];
-        }
-        if (TWO) pbn[4 * BN + tid] = pbias;
+        for (int k = 0; k < 4; ++k) pbn[k * BN + tid] = pb[k];
       }
       __syncthreads();
     }
@@ -383,14 +296,6 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || PRO == PW_PRO_DY || 
             const float z = v[nf][r] * sc[r] + sh[r];
             v[nf][r] = a.epi.mode == MDS_EPI_BN_SILU ? siluf_(z) : z;
           }
-        }
-      }
-      if (TWO) {
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-          const f32x4 bz = *(const f32x4*)(pbn + 4 * BN + 64 * wn + 16 * nf + 4 * q);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[nf][r] = ok ? v[nf][r] + bz[r] : 0.f;     // rows past M stay zero (statistics)
         }
       }
       if (a.residual && ok) {
@@ -480,19 +385,13 @@ int pw_fwd_wres_try(const mds_pw_fwd_args* a, mds_stream_t stream);   // k_pwr.h
 extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_fwd: bad dims");
   MDS_REQUIRE(a->K % 8 == 0 && a->N % 16 == 0, "pw_fwd: K=%d must be a multiple of 8, N=%d of 16", a->K, a->N);
-  const bool dy = a->xdy.mode != 0;
-  MDS_REQUIRE((dy || a->x) && a->w && a->y, "pw_fwd: null pointer");
+  MDS_REQUIRE(a->x && a->w && a->y, "pw_fwd: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || (a->pro.scale && a->pro.shift), "pw_fwd: prologue needs scale/shift");
   MDS_REQUIRE((a->pro.mode != MDS_PRO_BN_SILU_GATE && a->pro.mode != MDS_PRO_GATE) || (a->pro.gate && a->pro.rows_per_group > 0), "pw_fwd: gate prologue");
-  if (dy) {
-    MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE && a->xdy.g.u && a->xdy.y && a->xdy.lin, "pw_fwd: dy prologue needs u, y, lin and no other prologue");
-    MDS_REQUIRE(a->xdy.g.mode == MDS_G_PLAIN || (a->xdy.g.mode == MDS_G_MASK && a->xdy.g.mask && a->xdy.g.rows_per_group > 0),
-                "pw_fwd: dy prologue takes PLAIN or MASK gradient sources (SILU is folded upstream by MDS_POST_SILU)");
-  }
   const bool post = a->post.mode != MDS_POST_NONE;
   const bool epi = a->epi.mode != MDS_EPI_NONE;
   if (epi) {
-    MDS_REQUIRE(a->epi.scale && a->epi.shift && !a->stats && !post && !dy, "pw_fwd: an output transform needs scale/shift and excludes statistics, post statistics and the dy prologue");
+    MDS_REQUIRE(a->epi.scale && a->epi.shift && !a->stats && !post, "pw_fwd: an output transform needs scale/shift and excludes statistics and post statistics");
     MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || a->pro.mode == MDS_PRO_BN_SILU, "pw_fwd: an output transform takes the NONE, GATE or BN_SILU prologue");
   }
   if (post) {
@@ -500,27 +399,21 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
     MDS_REQUIRE(a->post.mode != MDS_POST_MASK || (a->post.mask && a->post.rows_per_group > 0), "pw_fwd: post mask");
     MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE && a->M < 4294967295L, "pw_fwd: post statistics are a data-gradient feature (no forward prologue)");
   }
-  const bool two = a->x1 != nullptr;
-  if (two) {
-    MDS_REQUIRE(a->K1 > 0 && a->K1 % 8 == 0 && a->x && !dy && !epi && a->pro.mode == MDS_PRO_NONE && !a->stats,
-                "pw_fwd: a second operand pair needs K1 %% 8 == 0, a plain first operand, no prologue, no output transform, no forward statistics");
-  }
   const bool split = a->split > 1;
   if (split) {
     MDS_REQUIRE(a->split <= MDS_PW_MAX_SPLIT && a->split_part && a->split_ticket, "pw_fwd: split-K needs split <= %d, a partial buffer and tickets", MDS_PW_MAX_SPLIT);
-    MDS_REQUIRE(!dy && !post && !two && !a->stats && (a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE),
-                "pw_fwd: split-K is an inference-plan feature (NONE / GATE prologue, no statistics, no post statistics, no dy prologue, one operand pair)");
+    MDS_REQUIRE(!post && !a->stats && (a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE),
+                "pw_fwd: split-K is an inference-plan feature (NONE / GATE prologue, no statistics, no post statistics)");
   }
-  if (!two && !split) { const int rc = pw_fwd_wres_try(a, stream); if (rc <= 0) return rc; }
+  if (!split) { const int rc = pw_fwd_wres_try(a, stream); if (rc <= 0) return rc; }
   // 128x64 tiles for the narrow projections (N <= 64: half of a 128-column tile would be padding;
   // 154 -> 119 us at 1.18 M x 128 -> 32); wider N measured 5-20 % slower with them despite 3 blocks/CU
   const int wn = (a->N <= 64 && !split) ? 1 : 2;
   const int BN = 64 * wn;
   // 64-row tiles below 400 k rows: twice the blocks for the stage-3..5 / 3D layers (isolated: -10...25 %;
   // inside the step, where the weight-gradient stream fills the idle CUs anyway, +1 %)
-  // (the dy-prologue variant keeps two operand tiles in flight: its 128-row form would spill)
   const long bar64 = mds_knob(MDS_KNOB_PW_BM64) > 0 ? 1000L * mds_knob(MDS_KNOB_PW_BM64) : 400000;
-  const int bm = (wn == 2 && (a->M <= bar64 || dy)) ? 64 : PW_BM;
+  const int bm = (wn == 2 && a->M <= bar64) ? 64 : PW_BM;
   MDS_REQUIRE(!split || bm == 64, "pw_fwd: split-K is for small M (64-row tiles)");
   const int mt = cdiv(a->M, bm), nt = cdiv(a->N, BN);
   int gy = 1;
@@ -528,39 +421,18 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   dim3 grid(mt, gy, split ? a->split : 1), block(256);
 #define PW_GOSPLIT(T, PRO, TAIL_) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
-       MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_, 0, false, true>), grid, block, smem, stream, *a); } while (0)
+       MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_, true>), grid, block, smem, stream, *a); } while (0)
 #define PW_GO2(T, PRO, TAIL_) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
        if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_>), grid, block, smem, stream, *a); \
        else if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 128, TAIL_>), grid, block, smem, stream, *a); \
        else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 1, 128, TAIL_>), grid, block, smem, stream, *a); } while (0)
 #define PW_GO(T, PRO) PW_GO2(T, PRO, 0)
-#define PW_GODY(T, TAIL_) \
-  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
-       if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 2, 64, TAIL_>), grid, block, smem, stream, *a); \
-       else MDS_LAUNCH((pw_fwd_kernel<T, PW_PRO_DY, 1, 128, TAIL_>), grid, block, smem, stream, *a); } while (0)
-#define PW_GODEEP(T, PRO, TAIL_) \
-  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
-       MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_, 1>), grid, block, smem, stream, *a); } while (0)
-#define PW_GOTWO(T, TAIL_) \
-  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
-       if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, MDS_PRO_NONE, 2, 64, TAIL_, 0, true>), grid, block, smem, stream, *a); \
-       else if (wn == 2) MDS_LAUNCH((pw_fwd_kernel<T, MDS_PRO_NONE, 2, 128, TAIL_, 0, true>), grid, block, smem, stream, *a); \
-       else MDS_LAUNCH((pw_fwd_kernel<T, MDS_PRO_NONE, 1, 128, TAIL_, 0, true>), grid, block, smem, stream, *a); } while (0)
-  const bool deep0 = !two && wn == 2 && bm == 64 && !dy && !epi && (a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE) &&
-                     mds_knob(MDS_KNOB_PW_DEEP) == 1;   // opt-in: measured 4 % SLOWER inside the step (2.87 -> 3.00 ms of pw_fwd)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
     if (split) {
       if (epi) { if (a->pro.mode == MDS_PRO_GATE) PW_GOSPLIT(T, MDS_PRO_GATE, 2); else PW_GOSPLIT(T, MDS_PRO_NONE, 2); }
       else { if (a->pro.mode == MDS_PRO_GATE) PW_GOSPLIT(T, MDS_PRO_GATE, 0); else PW_GOSPLIT(T, MDS_PRO_NONE, 0); }
     }
-    else if (deep0 && a->K >= 4 * PwCfg<T>::KC) {   // K-heavy layers: two K chunks in flight
-      if (post) PW_GODEEP(T, MDS_PRO_NONE, 1);
-      else if (a->pro.mode == MDS_PRO_GATE) PW_GODEEP(T, MDS_PRO_GATE, 0);
-      else PW_GODEEP(T, MDS_PRO_NONE, 0);
-    }
-    else if (two) { if (post) PW_GOTWO(T, 1); else PW_GOTWO(T, 0); }
-    else if (dy) { if (post) PW_GODY(T, 1); else PW_GODY(T, 0); }
     else if (post) PW_GO2(T, MDS_PRO_NONE, 1);
     else if (epi) { if (a->pro.mode == MDS_PRO_GATE) PW_GO2(T, MDS_PRO_GATE, 2); else if (a->pro.mode == MDS_PRO_BN_SILU) PW_GO2(T, MDS_PRO_BN_SILU, 2); else PW_GO2(T, MDS_PRO_NONE, 2); }
     else switch (a->pro.mode) {
@@ -574,8 +446,6 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   });
 #undef PW_GO
 #undef PW_GO2
-#undef PW_GODY
-#undef PW_GOTWO
 #undef PW_GOSPLIT
   return mds_check_launch("pw_fwd");
 }
@@ -617,18 +487,7 @@ MDS_DEV void wg_put(bf16_t* base, int off, float v0, float v1) {
 }
 MDS_DEV void wg_put(float* base, int off, float v0, float) { base[off] = v0; }
 
-// dy = A*g + B*y + D on 8 channels of one row (mds_dyp_t; gradient sources PLAIN / MASK)
-struct DyCoef { float A[8], B[8], D[8]; };
-MDS_DEV void dy_coef_load(const mds_dyp_t& d, int C, int c, DyCoef& k) {
-  load8f(d.lin + c, k.A); load8f(d.lin + C + c, k.B); load8f(d.lin + 2 * C + c, k.D);
-}
-MDS_DEV void dy_form(const mds_dyp_t& d, const DyCoef& k, long row, const float (&u)[8], const float (&yv)[8], float (&v)[8]) {
-  const float mk = d.g.mode == MDS_G_MASK ? d.g.mask[(unsigned)row / (unsigned)d.g.rows_per_group] : 1.0f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = k.A[j] * (u[j] * mk) + k.B[j] * yv[j] + k.D[j];
-}
-
-template <typename T, int PRO, int NF, int KF, bool DYP>
+template <typename T, int PRO, int NF, int KF>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, int rows_per_block) {
   typedef typename Frag<T>::type frag_t;
   constexpr int MW = WgCfg<T>::MW, LDT = WgCfg<T>::LDT;
@@ -647,11 +506,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
   long mend = mbeg + rows_per_block;
   if (mend > a.M) mend = a.M;
   const T* x = (const T*)a.x;
-  const T* dy = (const T*)(DYP ? a.dyp.g.u : a.dy);
-  const long ydiff = DYP ? (const T*)a.dyp.y - dy : 0;
-  static_assert(256 % YCH == 0, "a thread keeps one 8-channel slice of dy");
-  DyCoef dk;
-  if (DYP && n0 + 8 * (tid % YCH) < N) dy_coef_load(a.dyp, N, n0 + 8 * (tid % YCH), dk);
+  const T* dy = (const T*)a.dy;
   const int kfr = (K - kt0 >= KT) ? KF : ((K - kt0 + 15) >> 4);
 
   // when 256 % XCH == 0 a thread keeps the same 8-channel slice for every staged item: its BN
@@ -669,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
 #pragma unroll
     for (int v = 0; v < KF; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  RawV8<T> rx[XI][MW], ry[YI][MW], ryy[DYP ? YI : 1][MW];
+  RawV8<T> rx[XI][MW], ry[YI][MW];
   auto issue = [&](long mb) {   // every global load of one 64-row step
 #pragma unroll
     for (int p = 0; p < XI; ++p) {
@@ -687,7 +542,6 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
       for (int h = 0; h < MW; ++h) {
         const long m = mb + (it / YCH) * MW + h;
         if (it < YN && m < mend && n < N) ry[p][h].ld(dy + m * N + n); else ry[p][h].zero();
-        if (DYP) { if (it < YN && m < mend && n < N) ryy[p][h].ld(dy + ydiff + m * N + n); else ryy[p][h].zero(); }
       }
     }
   };
@@ -734,14 +588,6 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
 #pragma unroll
         for (int h = 0; h < MW; ++h) {
           ry[p][h].get(v[h]);
-          if (DYP) {
-            const long m = mb + (it / YCH) * MW + h;
-            float yv[8], u[8];
-            ryy[p][h].get(yv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = v[h][j];
-            if (m < mend && n0 + 8 * (it % YCH) < N) dy_form(a.dyp, dk, m, u, yv, v[h]);
-          }
         }
         const int ml = (it / YCH) * MW, yc = it % YCH;
 #pragma unroll
@@ -778,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
-        if (n < N && k < K) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r] * (a.nscale ? a.nscale[n] : 1.0f));
+        if (n < N && k < K) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r]);
       }
     }
 }
@@ -788,23 +634,18 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(mds_pw_wgrad_args a, i
 // stores, and no bf16->fp32->bf16 round trip without a prologue); a fragment — 8 rows of one
 // channel — is two ds_read_b64_tr_b16.  Row pitches are odd multiples of 32 bytes so the 8 rows a
 // 32-lane LDS cycle touches sit in distinct bank groups.
-// G > 1: the block is G groups of four waves.  Every group runs the same pipeline over its own 64-row steps of the block's
-// row range (step s belongs to group s % G) with its own staging buffers, and the G partial tiles are summed through LDS
-// before the atomics.  Why: ablation on MI355X (192 -> 1152, 18 400 rows) - 36 us = 10 skeleton + 16 exposed load latency +
-// 6 MFMA + 4 atomics at ~1 wave per SIMD; without atomics 4x the blocks ran in 19 us, with them in 40: the kernel wants
-// occupancy, the atomics want few blocks.  Groups give 4 waves per SIMD at the atomic count of one block.
-template <int PRO, int NF, int KF, bool DYP, int G>
-__global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a, int rows_per_block, int dbg) {
+// (Several four-wave groups per block - 1.3-2x faster alone, slower inside the step - were measured in round 3 and removed: DESIGN 5.)
+template <int PRO, int NF, int KF>
+__global__ __launch_bounds__(256, 2) void pw_wgrad_tr_kernel(mds_pw_wgrad_args a, int rows_per_block, int dbg) {
   typedef bf16_t T;
   constexpr int NT = 64 * NF, KT = 16 * KF, XCH = KT / 8, YCH = NT / 8;
   constexpr int LDX = KT + 16, LDY = NT + 16;           // elements; (KT+16)*2 B = odd * 32 B for KT % 32 == 0
   constexpr int XN = WG_ROWS * XCH, YN = WG_ROWS * YCH;  // staging items (rows x 8-channel chunks)
   constexpr int XI = (XN + 255) / 256, YI = (YN + 255) / 256;
   MDS_DYN_SMEM(smem);
-  const int grp = G > 1 ? MDS_UNIFORM((int)(threadIdx.x >> 8)) : 0;
-  T* xs = (T*)smem + grp * (WG_ROWS * (LDX + LDY));   // [WG_ROWS][LDX] of this group
+  T* xs = (T*)smem;                                   // [WG_ROWS][LDX]
   T* ds = xs + WG_ROWS * LDX;                         // [WG_ROWS][LDY]
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int K = a.K, N = a.N;
   const int ntiles_k = (K + KT - 1) / KT;
@@ -820,11 +661,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
   if (mend > a.M) mend = a.M;
   if (mbeg >= a.M) return;   // (row splits are rounded up to a multiple of 8; whole block, before any barrier)
   const T* x = (const T*)a.x;
-  const T* dy = (const T*)(DYP ? a.dyp.g.u : a.dy);
-  const long ydiff = DYP ? (const T*)a.dyp.y - dy : 0;
-  static_assert(256 % YCH == 0, "a thread keeps one 8-channel slice of dy");
-  DyCoef dk;
-  if (DYP && n0 + 8 * (tid % YCH) < N) dy_coef_load(a.dyp, N, n0 + 8 * (tid % YCH), dk);
+  const T* dy = (const T*)a.dy;
   const int kfr = (K - kt0 >= KT) ? KF : ((K - kt0 + 15) >> 4);
   constexpr bool FIXED_CH = (256 % XCH) == 0;
   float sc[8], sh[8];
@@ -840,7 +677,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
 
   // per-thread staging constants: row within a step, channel, validity, running pointers (the 64-bit
   // address arithmetic per load and step was most of this loop's instruction count)
-  RawV8<T> rx[XI], ry[YI], ryy[DYP ? YI : 1];
+  RawV8<T> rx[XI], ry[YI];
   int xr[XI], yr[YI];
   bool xok[XI], yok[YI];
   const T* px[XI];
@@ -850,16 +687,16 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
     const int it = tid + 256 * p, kx = kt0 + 8 * (it % XCH);
     xr[p] = it / XCH;
     xok[p] = it < XN && kx < K;
-    px[p] = x + (mbeg + WG_ROWS * grp + xr[p]) * K + (xok[p] ? kx : 0);
+    px[p] = x + (mbeg + xr[p]) * K + (xok[p] ? kx : 0);
   }
 #pragma unroll
   for (int p = 0; p < YI; ++p) {
     const int it = tid + 256 * p, n = n0 + 8 * (it % YCH);
     yr[p] = it / YCH;
     yok[p] = it < YN && n < N;
-    py[p] = dy + (mbeg + WG_ROWS * grp + yr[p]) * N + (yok[p] ? n : 0);
+    py[p] = dy + (mbeg + yr[p]) * N + (yok[p] ? n : 0);
   }
-  const long xstep = (long)WG_ROWS * G * K, ystep = (long)WG_ROWS * G * N;
+  const long xstep = (long)WG_ROWS * K, ystep = (long)WG_ROWS * N;
   // the squeeze-excite gate row of every staged x item is requested WITH the item (same issue point): loaded inside the
   // staging loop it cost one exposed L2 round trip per 64-row step - with <= 2 blocks per CU nothing hides it, and it was
   // most of the gated projections' weight-gradient time (94 us per launch inside the step against 56 us ungated)
@@ -880,16 +717,14 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
 #pragma unroll
     for (int p = 0; p < YI; ++p) {
       if (yok[p] && yr[p] < left) ry[p].ld(py[p]); else ry[p].zero();
-      if (DYP) { if (yok[p] && yr[p] < left) ryy[p].ld(py[p] + ydiff); else ryy[p].zero(); }
       py[p] += ystep;
     }
   };
-  issue(mbeg + WG_ROWS * grp);
+  issue(mbeg);
   // fragment rows of a 32-row k-step: 16-lane group q reads rows ra..ra+3 and ra+8..ra+11
   const int ra = 16 * (q >> 1) + 4 * (q & 1);
   const int lrow = (i >> 2), lcol = 4 * (i & 3);  // this lane's part of the 4x16 block it helps to gather
-  for (long mb0 = mbeg; mb0 < mend; mb0 += WG_ROWS * G) {   // every group makes the same number of trips (block barriers)
-    const long mb = mb0 + WG_ROWS * grp;
+  for (long mb = mbeg; mb < mend; mb += WG_ROWS) {
     __syncthreads();  // previous step's fragment reads are done
 #pragma unroll
     for (int p = 0; p < XI; ++p) {
@@ -923,25 +758,10 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
 #pragma unroll
     for (int p = 0; p < YI; ++p) {
       const int it = tid + 256 * p;
-      if (it < YN) {
-        if (!DYP) {
-          ry[p].st(ds + (it / YCH) * LDY + 8 * (it % YCH));
-        } else {
-          const long m = mb + yr[p];
-          float u[8], yv[8], v[8];
-          ry[p].get(u);
-          ryy[p].get(yv);
-          if (yok[p] && m < mend) dy_form(a.dyp, dk, m, u, yv, v);
-          else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-          }
-          store8(ds + (it / YCH) * LDY + 8 * (it % YCH), v);
-        }
-      }
+      if (it < YN) ry[p].st(ds + (it / YCH) * LDY + 8 * (it % YCH));
     }
     __syncthreads();
-    if (mb0 + WG_ROWS * G < mend && !(dbg & 4)) issue(mb + WG_ROWS * G);   // next step's loads fly under this step's MFMAs (rows past mend: zeros)
+    if (mb + WG_ROWS < mend && !(dbg & 4)) issue(mb + WG_ROWS);   // next step's loads fly under this step's MFMAs (rows past mend: zeros)
 #pragma unroll
     for (int ks = 0; ks < WG_ROWS / 32; ++ks) {
       if (dbg & 2) break;
@@ -965,35 +785,6 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
       }
     }
   }
-  if (G > 1) {
-    // sum the G partial tiles through LDS ([group][register][thread]: conflict-free both ways); group g then owns the
-    // fragments j with j % G == g, so every wave of the block issues 1/G of the tile's atomics
-    float* red = (float*)smem;
-    __syncthreads();   // the last step's fragment reads are done: the staging buffers are free
-#pragma unroll
-    for (int u = 0; u < NF; ++u)
-#pragma unroll
-      for (int v = 0; v < KF; ++v)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[(grp * (NF * KF * 4) + (u * KF + v) * 4 + r) * 256 + tid] = acc[u][v][r];
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < NF; ++u)
-#pragma unroll
-      for (int v = 0; v < KF; ++v) {
-        if ((u * KF + v) % G != grp) continue;     // wave-uniform
-        const int k = kt0 + 16 * v + i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float t = 0.f;
-#pragma unroll
-          for (int g2 = 0; g2 < G; ++g2) t += red[(g2 * (NF * KF * 4) + (u * KF + v) * 4 + r) * 256 + tid];
-          const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
-          if (n < N && k < K && !(dbg & 1)) atomicAdd(a.dw + (long)n * K + k, t * (a.nscale ? a.nscale[n] : 1.0f));
-        }
-      }
-    return;
-  }
 #pragma unroll
   for (int u = 0; u < NF; ++u)
 #pragma unroll
@@ -1002,7 +793,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * (NF * wave + u) + 4 * q + r;
-        if (n < N && k < K && !(dbg & 1)) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r] * (a.nscale ? a.nscale[n] : 1.0f));
+        if (n < N && k < K && !(dbg & 1)) atomicAdd(a.dw + (long)n * K + k, acc[u][v][r]);
       }
     }
 }
@@ -1010,7 +801,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 2 : G) void pw_wgrad_tr_kernel(md
 extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_wgrad: bad dims");
   MDS_REQUIRE(a->K % 8 == 0 && a->N % 8 == 0, "pw_wgrad: K, N must be multiples of 8");
-  MDS_REQUIRE(a->x && (a->dy || a->dyp.mode) && a->dw, "pw_wgrad: null pointer");
+  MDS_REQUIRE(a->x && a->dy && a->dw, "pw_wgrad: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE || (a->pro.scale && a->pro.shift), "pw_wgrad: prologue needs scale/shift");
   MDS_REQUIRE((a->pro.mode != MDS_PRO_BN_SILU_GATE && a->pro.mode != MDS_PRO_GATE) || (a->pro.gate && a->pro.rows_per_group > 0), "pw_wgrad: gate prologue");
   MDS_REQUIRE(a->M < 2147483647L, "pw_wgrad: M too large");
@@ -1024,46 +815,25 @@ extern "C" int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream) {
   // stream beside the dependent chain, where every block they hold is a CU slot the critical kernel does not get:
   // inside the training step 128 blocks in total measured best (448: +0.25 ms per step, 896: +0.8 ms, 32...224: flat).
   // The multi-million-row layers still want <= 2048 rows per block.
-  const bool dyp = a->dyp.mode != 0;
-  const bool tr = a->dtype == MDS_BF16 && !mds_switch(MDS_SW_WG_OLD);
-  // Groups per block (bf16 kernel): 4 four-wave groups need <= 128 VGPRs (no dy prologue, not the BN+SiLU+gate form).
-  // ALONE four groups are 1.3-2x faster than one (MI355X: 192 -> 1152 at 18 400 rows 36.7 -> 26.1 us, 3D 192 -> 576 32.7 -> 16.8);
-  // INSIDE the training step these launches share the chip with the dependent chain, a 16-wave block with 128 KB of LDS owns
-  // its CU, and the step measured 14.23 ms against 14.04 - so the default stays one group (MDS_KNOB_WG_GROUPS selects 2 / 4).
-  int G = 1;
-  {
-    const int kg = mds_knob(MDS_KNOB_WG_GROUPS);       // 2 / 4: every layer; 12 / 14: only the 18 400-row layers (stage 5, 3D tail)
-    const int g = kg % 10;
-    if (tr && !dyp && a->pro.mode != MDS_PRO_BN_SILU_GATE && (g == 2 || g == 4) && (kg < 10 || a->M <= 20000)) G = g;
-  }
-  long want_blocks = (mds_knob(MDS_KNOB_WG_BLOCKS) > 0 ? mds_knob(MDS_KNOB_WG_BLOCKS) : (G > 1 ? 256 : 192)) / tiles;   // budget re-swept with the XCD-aligned splits: 128 / 192 / 224 / 288 -> 13.88 / 13.77 / 13.78 / 13.78 ms per step (was 128)
-  if (G == 1 && want_blocks < a->M / 2048) want_blocks = a->M / 2048;
-  if (G > 1 && want_blocks < a->M / 16384) want_blocks = a->M / 16384;
+  const bool tr = a->dtype == MDS_BF16;     // the transposing-LDS-read kernel; fp32 takes the generic one
+  long want_blocks = (mds_knob(MDS_KNOB_WG_BLOCKS) > 0 ? mds_knob(MDS_KNOB_WG_BLOCKS) : 192) / tiles;   // budget re-swept with the XCD-aligned splits: 128 / 192 / 224 / 288 -> 13.88 / 13.77 / 13.78 / 13.78 ms per step (was 128)
+  if (want_blocks < a->M / 2048) want_blocks = a->M / 2048;
   if (tr && !(mds_knob(MDS_KNOB_WG_DBG) & 32)) {   // row splits in multiples of 8: split s and all its output tiles run on XCD s % 8 (see the kernel)
     want_blocks = (want_blocks + 4) / 8 * 8;
     if (want_blocks < 8) want_blocks = 8;
   }
   if (want_blocks < 1) want_blocks = 1;
   long rpb = (a->M + want_blocks - 1) / want_blocks;
-  rpb = ((rpb + WG_ROWS * G - 1) / (WG_ROWS * G)) * (WG_ROWS * G);
+  rpb = ((rpb + WG_ROWS - 1) / WG_ROWS) * WG_ROWS;
   if (rpb < 4 * WG_ROWS) rpb = 4 * WG_ROWS;
-  dim3 grid(cdiv(a->M, rpb), tiles), block(256 * G);
+  dim3 grid(cdiv(a->M, rpb), tiles), block(256);
   if (tr) grid = dim3((unsigned)((cdiv(a->M, rpb) + 7) / 8 * 8 * tiles), 1);
-  if (dyp) {
-    MDS_REQUIRE(a->dyp.g.u && a->dyp.y && a->dyp.lin, "pw_wgrad: dy prologue needs u, y, lin");
-    MDS_REQUIRE(a->dyp.g.mode == MDS_G_PLAIN || (a->dyp.g.mode == MDS_G_MASK && a->dyp.g.mask && a->dyp.g.rows_per_group > 0),
-                "pw_wgrad: dy prologue takes PLAIN or MASK gradient sources");
-  }
 #define WG_GO(T, PRO) \
   do { const size_t smem_ = (size_t)(KT + NT) * WgCfg<T>::LDT * sizeof(T); \
-       if (dyp) MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4, true>), grid, block, smem_, stream, *a, (int)rpb); \
-       else MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4, false>), grid, block, smem_, stream, *a, (int)rpb); } while (0)
+       MDS_LAUNCH((pw_wgrad_kernel<T, PRO, 2, 4>), grid, block, smem_, stream, *a, (int)rpb); } while (0)
 #define WGT_GO(PRO) \
   do { const size_t smem_ = (size_t)WG_ROWS * (KT + 16 + NT + 16) * sizeof(bf16_t); \
-       if (dyp) MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4, true, 1>), grid, block, smem_, stream, *a, (int)rpb, mds_knob(MDS_KNOB_WG_DBG)); \
-       else if (G == 4) MDS_LAUNCH((pw_wgrad_tr_kernel<PRO == MDS_PRO_BN_SILU_GATE ? 0 : PRO, 2, 4, false, 4>), grid, block, (size_t)4 * 32 * 256 * 4, stream, *a, (int)rpb, mds_knob(MDS_KNOB_WG_DBG)); \
-       else if (G == 2) MDS_LAUNCH((pw_wgrad_tr_kernel<PRO == MDS_PRO_BN_SILU_GATE ? 0 : PRO, 2, 4, false, 2>), grid, block, (size_t)2 * 32 * 256 * 4 > 2 * smem_ ? (size_t)2 * 32 * 256 * 4 : 2 * smem_, stream, *a, (int)rpb, mds_knob(MDS_KNOB_WG_DBG)); \
-       else MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4, false, 1>), grid, block, smem_, stream, *a, (int)rpb, mds_knob(MDS_KNOB_WG_DBG)); } while (0)
+       MDS_LAUNCH((pw_wgrad_tr_kernel<PRO, 2, 4>), grid, block, smem_, stream, *a, (int)rpb, mds_knob(MDS_KNOB_WG_DBG)); } while (0)
   if (tr) {
     switch (a->pro.mode) {
       case MDS_PRO_NONE: WGT_GO(MDS_PRO_NONE); break;

@@ -263,7 +263,7 @@ int pw_fwd_wres_try(const mds_pw_fwd_args* a, mds_stream_t stream) {
   const int knob = mds_knob(MDS_KNOB_PW_WRES);
   if (knob == 1) return 1;
   const bool forced = knob == 2;                    // tests: take this kernel at any M, 8 blocks per n-tile
-  if (a->xdy.mode != 0 || a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE || a->residual) return 1;
+  if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE || a->residual) return 1;
   const int K = a->K, N = a->N;
   const int KS = (K + 31) / 32;
   if (K < 72 || (KS != 3 && KS != 4 && KS != 6) || N < 128) return 1;

@@ -370,11 +370,11 @@ extern "C" int mds_stem_wgrad(const mds_stem_wgrad_args* a, mds_stream_t stream)
   const bool dyp = a->dyp.mode != 0;
   MDS_REQUIRE(a->x && (a->dy || dyp) && a->dw, "stem_wgrad: null pointer");
   if (dyp) {
-    MDS_REQUIRE(a->dtype == MDS_BF16 && !mds_switch(MDS_SW_STEM_OLD), "stem_wgrad: the dy prologue is a bf16 feature");
+    MDS_REQUIRE(a->dtype == MDS_BF16, "stem_wgrad: the dy prologue is a bf16 feature");
     MDS_REQUIRE(a->dyp.g.u && a->dyp.y && a->dyp.bn && a->dyp.lin && (a->dyp.g.mode == MDS_G_PLAIN || a->dyp.g.mode == MDS_G_SILU),
                 "stem_wgrad: dy prologue needs u, y, bn, lin and a PLAIN or SILU gradient source");
   }
-  if (a->dtype == MDS_BF16 && !mds_switch(MDS_SW_STEM_OLD)) {
+  if (a->dtype == MDS_BF16) {
     const int tiles_a = cdiv(a->OH, SW_ROWS), tiles_b = cdiv(a->OW, SW_COLS);
     const long total = (long)a->N * tiles_a * tiles_b;
     const int tpb = (int)cdiv(total, total < 768 ? total : 768);   // three blocks per CU

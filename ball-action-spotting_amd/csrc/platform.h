@@ -162,11 +162,7 @@ MDS_DEV unsigned xcd_contiguous(unsigned id, unsigned n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-// ------------------------------------------------------------------ developer switches
-// MDS_*_OLD environment variables select the previous kernel generation of a family for A/B timing.
-// They are read ONCE per process (k_misc.hip), never on the launch path.
-enum { MDS_SW_DW_OLD = 0, MDS_SW_CONV_OLD, MDS_SW_WG_OLD, MDS_SW_STEM_OLD, MDS_SW_COUNT };
-bool mds_switch(int id);
+// ------------------------------------------------------------------ developer knobs
 int mds_knob(int id);   // mds_dev_set() values (0 = default), see include/mds.h
 
 // ------------------------------------------------------------------ error plumbing (C ABI)

@@ -36,8 +36,7 @@ EPI_NONE, EPI_AFFINE, EPI_BN_SILU = 0, 1, 2
 
 class Grad:
     """A gradient tensor handed from one backward closure to the next.  `reduced` names the BatchNorm layer
-    whose backward sums (sum g, sum g*xhat) the PRODUCING kernel already took in its epilogue (mds_poststat_t);
-    with POST_SILU the buffer holds g = u*silu'(z) instead of u."""
+    whose backward sums (sum g, sum g*xhat) the PRODUCING kernel already took in its epilogue (mds_poststat_t)."""
     __slots__ = ("buf", "reduced")
 
     def __init__(self, buf, reduced=None):
@@ -118,31 +117,6 @@ class BNL:
         self.bwd_finalize(pb, seg, frozen)
         pb.op(seg, "bn_bwd_apply", dtype=pb.code, M=self.count, C=self.C, g=gsrc, y=y, bn=self.buf, coef=self.coef, dy=dy)
 
-    def backward_wg(self, pb, seg, gsrc, y, dy, x, K, dw, wide_act, group_rows=0):
-        """finalize + the apply pass that also accumulates a 1x1 weight gradient (mds_bn_bwd_apply_wg): dW[c][k] = sum_m wide[m][c] x[m][k]
-        with wide = dy (wide_act 0) or silu(bn(y)) * gate (wide_act 1); the slabs' partial tiles are added into `dw` by a finishing
-        launch on the second stream.  The sums were taken by the producer of the gradient source (reduce=False callers only)."""
-        self.bwd_finalize(pb, seg, False)
-        slabs = int(pb.lib.fn["bn_bwd_apply_wg_slabs"](int(self.count), int(self.C), int(K), int(group_rows), int(wide_act), int(pb.code)))
-        assert slabs > 0
-        part = pb.f32(slabs * self.C * K)
-        pb.op(seg, "bn_bwd_apply_wg", dtype=pb.code, M=self.count, C=self.C, g=gsrc, y=y, bn=self.buf, lin=self.lin, dy=dy, K=K, x=x,
-              wide_act=wide_act, group_rows=group_rows, slabs=slabs, part=part)
-        pb.op(seg, "wg_finish", C=self.C, K=K, slabs=slabs, transpose=wide_act, part=part, dw=dw)
-
-    @staticmethod
-    def wg_ok(C, K):
-        return (C % 64 == 0 or C % 96 == 0) and K in (48, 96, 112, 192)
-
-    def backward_fused(self, pb, seg, gsrc, y, reduce=True, frozen=False):
-        """reduce (unless the producer of u took the sums) / finalize; returns the dy-prologue descriptor that the
-        consumers of dy evaluate on load (mds_dyp_t) — no apply pass, no dy tensor.  gsrc: PLAIN or MASK."""
-        assert gsrc["mode"] in (G_PLAIN, G_MASK)
-        if reduce:
-            self.bwd_reduce(pb, seg, gsrc, y)
-        self.bwd_finalize(pb, seg, frozen)
-        return dict(_struct="mds_dyp_t", mode=1, g=gsrc, y=y, bn=self.buf, lin=self.lin)
-
     def head(self, y, mode, mask=None, rpg=0):
         """what a producing data-gradient GEMM needs to take this layer's backward sums in its epilogue"""
         return dict(bn=self, y=y, mode=mode, mask=mask, rpg=rpg)
@@ -197,12 +171,6 @@ def op_cost(name, kw, es):
     if name in ("se_bwd_reduce", "bn_bwd_reduce"):
         n = g("M") * g("C") if name == "bn_bwd_reduce" else g("groups") * g("rows_per_group") * g("C")
         return 2 * n * es, 10 * n
-    if name == "pw_dgrad":             # the apply pass's wide operands (g, y in; dy out when stored) + the narrow output (+ residual) + the filter
-        M, K, N = g("M"), g("K"), g("N")
-        wide = (2 if g("dyp") is not None else 1) + (1 if g("dy_out") is not None else 0)
-        return (wide * M * K + M * N * (2 if g("residual") is not None else 1) + N * K) * es, 2 * M * K * N + 4 * M * K
-    if name == "bn_bwd_apply_wg":      # the apply pass's three wide operands + the narrow operand once + the partial tiles
-        return 3 * g("M") * g("C") * es + g("M") * g("K") * es + g("slabs") * g("C") * g("K") * 4, 2 * g("M") * g("C") * g("K") + 12 * g("M") * g("C")
     if name in ("bn_bwd_apply", "gem_bwd"):
         n = g("M") * g("C") if name == "bn_bwd_apply" else g("groups") * g("rows_per_group") * g("C")
         return 3 * n * es, 12 * n
@@ -213,52 +181,12 @@ def gsrc(mode, u, gate=None, dpooled=None, mask=None, rpg=0):
     return dict(_struct="mds_gsrc_t", mode=mode, u=u, gate=gate, dpooled=dpooled, mask=mask, rows_per_group=rpg)
 
 
-_MASKED = {}
-
-
 def _hip_path():
     with open("/proc/self/maps") as f:
         for line in f:
             if "libamdhip64" in line:
                 return line.split()[-1]
     raise RuntimeError("libamdhip64 is not mapped in this process")
-
-
-def _masked_stream(device):
-    """MDS_SIDE_CUS=n[:stride[:first]]: the weight-gradient stream is created with a compute-unit mask (hipExtStreamCreateWithCUMask) of
-    n CUs - mask bit first + j * stride for j < n - so that its launches cannot take CU slots from the dependent chain on the
-    other CUs.  Unset / 0: an ordinary stream.  One masked stream per device (HIP has no cheap destroy for them inside a step)."""
-    spec = os.environ.get("MDS_SIDE_CUS", "0")
-    prio = os.environ.get("MDS_SIDE_PRIO", "")
-    if spec in ("", "0") and prio == "":
-        return None
-    key = (device.index, spec, prio)
-    if key not in _MASKED and spec in ("", "0"):
-        # MDS_SIDE_PRIO=<int>: an unmasked stream of that HIP priority (hipDeviceGetStreamPriorityRange: larger = lower priority)
-        import ctypes
-        hip = ctypes.CDLL(_hip_path())
-        h = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, int(prio))   # 1 = hipStreamNonBlocking
-        if rc != 0 or not h.value:
-            raise RuntimeError(f"hipStreamCreateWithPriority failed: {rc}")
-        _MASKED[key] = torch.cuda.ExternalStream(h.value, device=device)
-    if key not in _MASKED:
-        import ctypes
-        parts = [int(v) for v in spec.split(":")]
-        n, stride, first = parts[0], (parts[1] if len(parts) > 1 else 1), (parts[2] if len(parts) > 2 else 0)
-        hip = ctypes.CDLL(_hip_path())
-        words = (ctypes.c_uint32 * 8)()
-        for j in range(n):
-            b = first + j * stride
-            words[b >> 5] |= 1 << (b & 31)
-        h = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
-        if rc != 0 or not h.value:
-            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
-        _MASKED[key] = torch.cuda.ExternalStream(h.value, device=device)
-    return _MASKED[key]
 
 
 class Plan:
@@ -276,22 +204,11 @@ class Plan:
         self.need_grad = need_grad
         self.enc_grad = enc_grad and need_grad
         self.m = module
-        # 0: reduce / finalize / apply kernels everywhere; 1: BN backward folded into every 1x1 GEMM that touches it;
-        # 2: only the NARROW layers (the projections' BN3 / BN2: dy formed on load from two narrow tensors, sums in the
-        #    epilogue of a GEMM with a narrow output) — the wide ones keep their streaming apply pass.
-        # MDS_FUSE_BN_BWD: 3 (default) = the data-gradient GEMM that produces a block's input gradient also takes the sums of the
-        # BatchNorm backward that consumes it (mds_poststat_t): 22 bn_bwd_reduce launches less, +0.5 % measured.  1 / 2 = dy formed
-        # on load in the GEMMs as well (all layers / narrow layers): measured a net loss in the register-staged GEMM (227 / 236
-        # vs 244 windows/s), kept with their tests.  0 = every reduce and apply is its own launch.
-        self.fuse_mode = int(os.environ.get("MDS_FUSE_BN_BWD", "3"))
-        self.fuse_bn_bwd = self.fuse_mode >= 1
-        # MDS_WG_RIDE (bit 0: BN1 / conv_pw, bit 1: BN2 / conv_pwl): the 1x1 weight gradients of the inverted-residual blocks ride on
-        # the BatchNorm-backward apply passes (mds_bn_bwd_apply_wg) instead of re-reading the wide tensors on the second stream
-        self.wg_ride = int(os.environ.get("MDS_WG_RIDE", "0"))
-        # MDS_PW_DGRAD=1 (default): the expansions' data gradient forms dy on load and stores it for the weight gradient
-        # (mds_pw_dgrad, k_pwd.hip) - BN1's apply launch and the second read of dy leave the dependent chain
-        self.pw_dgrad = os.environ.get("MDS_PW_DGRAD", "0") == "1"
-        self.bn1_lin = int(os.environ.get("MDS_BN1_LIN", "0"))      # 0 = off; else the smallest rows x channels the linear form is used for
+        # MDS_FUSE_BN_BWD=1 (default): the data-gradient GEMM that produces a block's input gradient also takes the sums of the
+        # BatchNorm backward that consumes it (mds_poststat_t): 22 bn_bwd_reduce launches less.  0: every reduce is its own launch.
+        # (Forming dy on load inside the GEMMs - all layers / narrow layers only - and the linear form of BatchNorm backward were
+        # measured slower in rounds 2 and 3 and are no longer part of the product: DESIGN 5.)
+        self.fuse_bn_bwd = os.environ.get("MDS_FUSE_BN_BWD", "1") != "0"
         # inference plans (eval-mode BatchNorm, no gradient): producers store activated outputs (mds_epi_t)
         self.eval_epilogues = (not training) and (not need_grad) and os.environ.get("MDS_EVAL_EPI", "1") == "1"
         self.in_flight = False
@@ -513,24 +430,19 @@ class Plan:
                             wi=wi, **common)
         return dxb
 
-    def _pw_bwd(self, seg, xin, pro, M, K, N_, wparam, dy, need_dx, residual=None, frozen=False, head=None, wgrad=True):
-        """wgrad (+ dgrad) of a 1x1 conv y[M][N] = pro(x)[M][K] w^T.  `dy` is a materialised tensor or a dy-prologue
-        descriptor (BNL.backward_fused); `head`: take the next BatchNorm backward's sums in the dgrad epilogue."""
-        fused = isinstance(dy, dict)
-        if not frozen and wgrad:
-            self.op(seg, "pw_wgrad", dtype=self.code, M=M, K=K, N=N_, x=xin, dy=None if fused else dy, dw=self.grad(wparam),
-                    pro=pro or dict(mode=0), **({"dyp": dy} if fused else {}))
+    def _pw_bwd(self, seg, xin, pro, M, K, N_, wparam, dy, need_dx, residual=None, frozen=False, head=None):
+        """wgrad (+ dgrad) of a 1x1 conv y[M][N] = pro(x)[M][K] w^T from the materialised dy; `head`: take the next BatchNorm
+        backward's sums in the dgrad epilogue."""
+        if not frozen:
+            self.op(seg, "pw_wgrad", dtype=self.code, M=M, K=K, N=N_, x=xin, dy=dy, dw=self.grad(wparam), pro=pro or dict(mode=0))
         if not need_dx:
             return None
         wt = self.pack(wparam, cabi.MDS_PACK_IO_FLIP, N_, K, 1)       # [K][N]
         dx = self.act(M, K)
         extra = {}
-        if fused:
-            extra["xdy"] = dy
         if head is not None:
             extra["post"] = head["bn"].post(head)
-        self.op(seg, "pw_fwd", dtype=self.code, M=M, K=N_, N=K, x=None if fused else dy, w=wt, y=dx, pro=dict(mode=0),
-                residual=residual, stats=None, **extra)
+        self.op(seg, "pw_fwd", dtype=self.code, M=M, K=N_, N=K, x=dy, w=wt, y=dx, pro=dict(mode=0), residual=residual, stats=None, **extra)
         return Grad(dx, head["bn"] if head is not None else None)
 
     def _ir_block_eval(self, fseg, blk, bn1, bn2, bn3, xin, N, T, IH, IW, OH, OW, pt, pl, stride, groups, has_skip, kt):
@@ -604,19 +516,11 @@ class Plan:
                 rows_per_group=rpg, shortcut=xin if has_skip else None, out=xout)
         self.taps.append(dict(tag=f"{fseg}.ir{len(self.taps)}", buf=xout, bn=None, rows=Mout, C=cout))
 
-        fuse = self.fuse_bn_bwd
-
         def bwd(seg, dout, nxt_head):
             g3 = gsrc(G_MASK, dout.buf, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout.buf)
-            if fuse and self.fuse_mode != 3:
-                # BN3 backward: sums by the producer of dout when that was a 1x1 data-gradient GEMM, dy formed on load
-                dy3 = bn3.backward_fused(self, seg, g3, y3, reduce=dout.reduced is not bn3, frozen=frozen)
-            else:       # (mode 3: only the sums move into the producer's epilogue; dy stays materialised)
-                dy3 = self.act(Mout, cout)
-                bn3.backward(self, seg, g3, y3, dy3, reduce=dout.reduced is not bn3, frozen=frozen)
-            ride2 = bool(self.wg_ride & 2) and not frozen and not isinstance(dy3, dict) and BNL.wg_ok(mid, cout) and Mout % rpg == 0
-            ride1 = bool(self.wg_ride & 1) and not frozen and BNL.wg_ok(mid, cin) and not (fuse and self.fuse_mode == 1) and not self.bn1_lin
-            u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen, wgrad=not ride2).buf
+            dy3 = self.act(Mout, cout)      # (the sums may have been taken by the producer of dout, a 1x1 data-gradient GEMM's epilogue)
+            bn3.backward(self, seg, g3, y3, dy3, reduce=dout.reduced is not bn3, frozen=frozen)
+            u2 = self._pw_bwd(seg, a2, gate_pro, Mout, mid, cout, blk.conv_pwl.weight, dy3, True, frozen=frozen).buf
             dgate, dpool = self.zero_bwd64(groups * mid), self.f32(groups * mid)
             nblk = self.lib.fn["se_bwd_reduce_blocks"](rpg, mid)
             bnsums = self.f32(groups * nblk * 4 * mid)
@@ -634,57 +538,15 @@ class Plan:
             self.op(seg, "se_fc_bwd_data", _struct="mds_se_fc_bwd_args", **sekw)
             self.op(seg, "se_fc_bwd_params", _struct="mds_se_fc_bwd_args", **sekw)     # parameter gradients: second stream
             dy2 = self.act(Mout, mid)
-            if ride2:     # BN2's apply pass also accumulates dW(conv_pwl) = (silu(z2) * gate)^T dy3
-                bn2.backward_wg(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, dy3, cout,
-                                self.grad(blk.conv_pwl.weight), 1, group_rows=rpg)
-            else:
-                bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, reduce=False, frozen=frozen)
+            bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, reduce=False, frozen=frozen)
             g1 = self.act(Min, mid)
             self.op(seg, "dw_bwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
                     pad_l=pl, kt=kt, x=y1, dy=dy2, w=wdw, g=g1, dw=self.f32(mid * kt * 9) if frozen else self.grad(blk.conv_dw.weight),
                     pro=bn1.pro(), mean=bn1.mean, rstd=bn1.rstd, stats=bn1.bstats)
-            if fuse and self.fuse_mode == 1:
-                dy1 = bn1.backward_fused(self, seg, gsrc(G_PLAIN, g1), y1, reduce=False, frozen=frozen)
-            elif self.bn1_lin and Min * mid >= self.bn1_lin:
-                # MDS_BN1_LIN=<min elements> (experiment): the data gradient in the LINEAR form of BatchNorm backward -
-                # dx = g1 (A.W) + x (W^T diag(B) W) + D W, no dy on the dependent chain; the apply pass and the weight gradient
-                # that needs its dy both move to the second stream
-                bn1.bwd_finalize(self, seg, frozen)
-                Kp, K1p = (mid + 63) // 64 * 64, (cin + 63) // 64 * 64
-                wcat, bias = self.act(cin, Kp + K1p), self.f32(cin)
-                self.op(seg, "bn_lin_prep", dtype=self.code, Cmid=mid, Cin=cin, w=P(blk.conv_pw.weight), lin=bn1.lin, wcat=wcat, bias=bias)
-                dx = self.act(Min, cin)
-                extra = {"post": nxt_head["bn"].post(nxt_head)} if nxt_head is not None else {}
-                self.op(seg, "pw_fwd", dtype=self.code, M=Min, K=mid, N=cin, x=g1, w=wcat, y=dx, pro=dict(mode=0),
-                        residual=dout.buf if has_skip else None, stats=None, x1=xin, K1=cin, bias=bias, **extra)
-                if not frozen:
-                    dy1 = self.act(Min, mid)
-                    self.op(seg, "bn_bwd_apply", dtype=self.code, M=Min, C=mid, g=gsrc(G_PLAIN, g1), y=y1, bn=bn1.buf, coef=bn1.coef, dy=dy1, _side=1)
-                    self.op(seg, "pw_wgrad", dtype=self.code, M=Min, K=cin, N=mid, x=xin, dy=dy1, dw=self.grad(blk.conv_pw.weight), pro=dict(mode=0))
-                return Grad(dx, nxt_head["bn"] if nxt_head is not None else None)
-            elif (self.pw_dgrad and not ride1 and self.fuse_mode in (0, 3) and self.lib.fn["pw_dgrad_ok"](int(Min), int(mid), int(cin)) == 1
-                  and (nxt_head is None or nxt_head["mode"] in (POST_PLAIN, POST_MASK))):
-                # BN1's apply pass folded into the data gradient (dy formed on load, stored once for the weight gradient)
-                bn1.bwd_finalize(self, seg, frozen)
-                dy1 = None if frozen else self.act(Min, mid)
-                dx = self.act(Min, cin)
-                extra = {"post": nxt_head["bn"].post(nxt_head)} if nxt_head is not None else {}
-                self.op(seg, "pw_dgrad", dtype=self.code, M=Min, K=mid, N=cin, x=None,
-                        dyp=dict(_struct="mds_dyp_t", mode=1, g=gsrc(G_PLAIN, g1), y=y1, bn=bn1.buf, lin=bn1.lin), dy_out=dy1,
-                        w=self.pack(blk.conv_pw.weight, cabi.MDS_PACK_IO_FLIP, mid, cin, 1), y=dx,
-                        residual=dout.buf if has_skip else None, **extra)
-                if not frozen:
-                    self.op(seg, "pw_wgrad", dtype=self.code, M=Min, K=cin, N=mid, x=xin, dy=dy1, dw=self.grad(blk.conv_pw.weight),
-                            pro=dict(mode=0))
-                return Grad(dx, nxt_head["bn"] if nxt_head is not None else None)
-            elif ride1:   # BN1's apply pass also accumulates dW(conv_pw) = dy1^T x
-                dy1 = self.act(Min, mid)
-                bn1.backward_wg(self, seg, gsrc(G_PLAIN, g1), y1, dy1, xin, cin, self.grad(blk.conv_pw.weight), 0)
-            else:
-                dy1 = self.act(Min, mid)
-                bn1.backward(self, seg, gsrc(G_PLAIN, g1), y1, dy1, reduce=False, frozen=frozen)
+            dy1 = self.act(Min, mid)
+            bn1.backward(self, seg, gsrc(G_PLAIN, g1), y1, dy1, reduce=False, frozen=frozen)
             return self._pw_bwd(seg, xin, None, Min, cin, mid, blk.conv_pw.weight, dy1, True,
-                                residual=dout.buf if has_skip else None, frozen=frozen, head=nxt_head, wgrad=not ride1)
+                                residual=dout.buf if has_skip else None, frozen=frozen, head=nxt_head)
 
         bwd.head = bn3.head(y3, POST_MASK if mask is not None else POST_PLAIN, mask, rpg)
         bwd.lo = self._lo(blk)
@@ -762,13 +624,10 @@ class Plan:
         xenc = cur
 
         def proj_bwd(seg, dfeat, nxt_head):
-            if dfeat.reduced is bnp and self.fuse_mode == 3:
-                dyp = self.act(M, cf)
+            dyp = self.act(M, cf)
+            if dfeat.reduced is bnp:      # the 3D tail's last data-gradient GEMM stored g = dfeat*silu'(z) and took the sums
                 bnp.backward(self, seg, gsrc(G_PLAIN, dfeat.buf), yp, dyp, reduce=False)
-            elif dfeat.reduced is bnp:    # the 3D tail's last data-gradient GEMM stored g = dfeat*silu'(z) and took the sums
-                dyp = bnp.backward_fused(self, seg, gsrc(G_PLAIN, dfeat.buf), yp, reduce=False)
             else:
-                dyp = self.act(M, cf)
                 bnp.backward(self, seg, gsrc(G_SILU, dfeat.buf), yp, dyp)
             return self._pw_bwd(seg, xenc, None, M, cenc, cf, m.conv2d_projection[0].weight, dyp, need_dx=not fr, head=nxt_head)
 
@@ -823,33 +682,15 @@ class Plan:
                 rows_per_group=rpg, shortcut=xin if has_skip else None, out=xout)
         self.taps.append(dict(tag=f"f2d.er{len(self.taps)}", buf=xout, bn=None, rows=M, C=cout))
 
-        fuse = self.fuse_bn_bwd
-
         def bwd(seg, dout, nxt_head):
             if fr:
                 return None
             g2 = gsrc(G_MASK, dout.buf, mask=mask, rpg=rpg) if mask is not None else gsrc(G_PLAIN, dout.buf)
             dya = self.act(M, mid)
-            if fuse and self.fuse_mode == 1:
-                # BN2 (narrow) backward folded into the projection's weight / data gradient; that data-gradient GEMM
-                # stores g_a = u_a*silu'(z_a) and takes BN1's sums over it, so BN1's apply reads a PLAIN source
-                dyb = bn2.backward_fused(self, seg, g2, yb, reduce=dout.reduced is not bn2)
-                ga = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True, head=bn1.head(ya, POST_SILU))
-                bn1.backward(self, seg, gsrc(G_PLAIN, ga.buf), ya, dya, reduce=False)
-            else:
-                if fuse and self.fuse_mode != 3:      # mode 2: only the narrow BN2 is folded (sums possibly taken by the producer of dout)
-                    dyb = bn2.backward_fused(self, seg, g2, yb, reduce=dout.reduced is not bn2)
-                else:
-                    dyb = self.act(M, cout)
-                    bn2.backward(self, seg, g2, yb, dyb, reduce=dout.reduced is not bn2)
-                if fuse and self.fuse_mode == 3 and os.environ.get("MDS_POST_SILU", "0") == "1":
-                    # the projection's data-gradient GEMM stores g_a = u_a*silu'(z_a) and takes BN1's sums over it
-                    # (measured: +0.33 ms in the 4 GEMMs for -0.26 ms of reduce launches: a wash, off by default)
-                    ga = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True, head=bn1.head(ya, POST_SILU))
-                    bn1.backward(self, seg, gsrc(G_PLAIN, ga.buf), ya, dya, reduce=False)
-                else:
-                    ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
-                    bn1.backward(self, seg, gsrc(G_SILU, ua.buf), ya, dya)
+            dyb = self.act(M, cout)
+            bn2.backward(self, seg, g2, yb, dyb, reduce=dout.reduced is not bn2)
+            ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
+            bn1.backward(self, seg, gsrc(G_SILU, ua.buf), ya, dya)
             self._conv_wgrad(seg, xin, pro_in, N, IH, IW, cin, OH, OW, mid, blk.stride, pads, dya, blk.conv_exp.weight)
             return Grad(self._conv_dgrad(seg, dya, N, IH, IW, cin, mid, blk.stride, blk.conv_exp.weight, pads,
                                          dout.buf if has_skip else None))
@@ -992,7 +833,7 @@ class Plan:
 
     # (the stem's weight gradient stays on the dependent chain: it is its last launch, and the second stream still has the first
     #  3x3 layer's weight gradient to finish - 14.30 vs 14.35 ms per step)
-    SIDE_OPS = ("pw_wgrad", "conv_wgrad", "se_fc_bwd_params", "wg_finish")
+    SIDE_OPS = ("pw_wgrad", "conv_wgrad", "se_fc_bwd_params")
     BUCKET_ELEMS = 1_500_000
 
     def _lo(self, *mods_or_params):
@@ -1107,7 +948,7 @@ class Plan:
         if self.device.type != "cuda" or os.environ.get("MDS_SIDE_STREAM", "1") == "0":
             return None
         if getattr(self, "_side", None) is None:
-            self._side = _masked_stream(self.device) or torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device)
             self._side_events = []
             self._side_flags = {}
         return self._side

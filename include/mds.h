@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 125
+#define MDS_VERSION 127
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -50,10 +50,8 @@ const char* mds_last_error(void);
 #define MDS_KNOB_CONV_BLOCKS 0
 #define MDS_KNOB_DW_ORDER 1      /* depthwise grids: 0 = XCD-aware remap (default), 1 = channel chunk fastest, 2 = strip fastest (the former default) */
 #define MDS_KNOB_PW_WRES 2     /* 1: mds_pw_fwd never takes the filter-resident kernel (A/B switch); 2: takes it at any M (tests); 3: lower row bar */
-#define MDS_KNOB_PW_DEEP 3     /* 1: mds_pw_fwd keeps TWO K chunks in flight for the K-heavy layers (study variant: slower inside the step) */
 #define MDS_KNOB_WG_DBG 4      /* ablation bits of the 1x1 weight-gradient kernels (measurement only) */
 #define MDS_KNOB_WG_BLOCKS 5   /* split-M block budget of mds_pw_wgrad (0 = default) */
-#define MDS_KNOB_WG_GROUPS 6   /* 2 / 4: mds_pw_wgrad runs that many four-wave groups per block (faster alone, slower inside the step) */
 #define MDS_KNOB_DW3_L 7       /* strip length of the 3x3x3 sliding-window kernels (0 = default) */
 #define MDS_KNOB_STREAM_BLOCKS 8  /* block cap of the grid-stride elementwise kernels (0 = default) */
 #define MDS_KNOB_DW2_L 9         /* strip length of the 3x3 stride-1 sliding-window kernels (0 = default rule) */
@@ -63,8 +61,7 @@ const char* mds_last_error(void);
 #define MDS_KNOB_PW_BM64 13        /* row bar (in thousands) below which mds_pw_fwd takes 64-row tiles (0 = default 400) */
 #define MDS_KNOB_REDUCE_PASSES 14  /* rows passes per block of the grouped reduce kernels (0 = default 32) */
 #define MDS_KNOB_DW2_BLOCKS 15     /* block target of the 3x3 stride-1 strip rule (0 = default 640) */
-#define MDS_KNOB_BWG_BLOCKS 16     /* block target of mds_bn_bwd_apply_wg (0 = default: one resident round) */
-#define MDS_KNOB_COUNT 17
+#define MDS_KNOB_COUNT 16
 int mds_dev_set(int knob, int value);
 /* Completion event of the NEXT launches of the calling thread (a hipEvent_t as void*; NULL disarms).  While armed, every kernel
  * this thread launches through the library is issued with the event as its STOP event (hipExtLaunchKernelGGL), i.e. the event is
@@ -166,16 +163,8 @@ typedef struct {
   mds_pro_t pro;
   const void* residual; /* optional [M][N], added after the product                            */
   double* stats;         /* optional [SLOTS][2][N]                                               */
-  mds_dyp_t xdy;        /* data-gradient use: xdy.mode == 1 -> the x operand is dy formed on load
-                           (channels = K; `x` ignored, pro must be NONE)                         */
   mds_poststat_t post;  /* data-gradient use: BN-backward sums of the NEXT layer in the epilogue */
-  mds_epi_t epi;        /* eval-mode output transform (no statistics, no post, no dy prologue with it) */
-  /* second operand pair + bias row - the LINEAR form of BatchNorm backward in a data gradient (mds_bn_lin_prep):
-   *   y[m][n] = sum_k x[m][k] w[n][k] + sum_j x1[m][j] w[n][Kp + j] + bias[n],   Kp = K rounded up to 64
-   * w is then [N][Kp + K1p] (K1p = K1 rounded up to 64, padding columns zero); plain prologue only            */
-  const void* x1;       /* optional [M][K1] */
-  int K1;
-  const float* bias;    /* optional [N] */
+  mds_epi_t epi;        /* eval-mode output transform (no statistics, no post with it) */
   /* split-K for the small-M launches of inference plans (a 920-row layer is 15-30 blocks that each walk 36 K chunks
    * one memory round trip at a time): grid.z = split blocks share a tile, each stores its fp32 partial tile to
    * split_part[z][M][N]; the LAST block to finish a tile (split_ticket, self-resetting) adds the partials in z order -
@@ -190,33 +179,6 @@ int mds_pw_fwd_split(long M, int K, int N, int dtype);   /* recommended split-K 
 #define MDS_PW_SPLIT_TILE_ROWS 64   /* tiles of a launch = ceil(M / 64) * ceil(N / 128) */
 #define MDS_PW_SPLIT_TICKET_STRIDE 32   /* ints between two tiles' tickets: one 128-byte line each (atomics on one line serialise, ~0.13 us apiece) */
 
-/* The linear form of BatchNorm backward (replaces mds_bn_bwd_apply for the BatchNorm behind a 1x1 expansion y = x W^T,
- * W fp32 [Cmid][Cin], multidim_stacker.py:106 / timm conv_pw).  With dy = A*g + B*y + D (mds_bn_bwd_finalize `lin`):
- *   dx = dy W = g (A.W) + y (B.W) + D W = g (A.W) + x (W^T diag(B) W) + D W     (no read of y, no dy tensor)
- *   dW = dy^T x = A.(g^T x) + B.(W (x^T x)) + D (sum_m x)^T
- * mds_bn_lin_prep packs the data-gradient operands: wcat [Cin][Kp + K1p] with row k = { A[n] W[n][k], n < Cmid | 0 |
- * Q[j][k] = sum_n B[n] W[n][j] W[n][k], j < Cin | 0 } (Kp, K1p: Cmid, Cin rounded up to 64) and bias[k] = sum_n D[n] W[n][k];
- * mds_bn_lin_wgrad adds the last two terms of dW from gram = x^T x [Cin][Cin] and colsum = sum_m x [Cin]
- * (the first is mds_pw_wgrad with dy = g and nscale = A).                                                          */
-typedef struct {
-  int dtype;            /* storage type of wcat */
-  int Cmid, Cin;
-  const float* w;       /* [Cmid][Cin] */
-  const float* lin;     /* [3][Cmid] A, B, D */
-  void* wcat;           /* [Cin][Kp + K1p] */
-  float* bias;          /* [Cin] */
-} mds_bn_lin_prep_args;
-int mds_bn_lin_prep(const mds_bn_lin_prep_args* a, mds_stream_t stream);
-typedef struct {
-  int Cmid, Cin;
-  const float* w;       /* [Cmid][Cin] */
-  const float* lin;     /* [3][Cmid] */
-  const float* gram;    /* [Cin][Cin] x^T x (fp32, e.g. from mds_pw_wgrad with dy = x) */
-  const double* colsum; /* fp64 [SLOTS][2][Cin] statistic slots whose row 0 sums to sum_m x[m][:] */
-  float* dw;            /* [Cmid][Cin] += */
-} mds_bn_lin_wgrad_args;
-int mds_bn_lin_wgrad(const mds_bn_lin_wgrad_args* a, mds_stream_t stream);
-
 /* weight gradient of the 1x1 convolution: dw[N][K] += sum_m dy[m][n] * pro(x)[m][k] (fp32,
  * atomically accumulated into a caller-zeroed buffer laid out like the PyTorch parameter).     */
 typedef struct {
@@ -227,31 +189,8 @@ typedef struct {
   const void* dy; /* [M][N]                                      */
   float* dw;      /* [N][K] fp32                                 */
   mds_pro_t pro;
-  mds_dyp_t dyp;  /* dyp.mode == 1 -> the dy operand is formed on load (channels = N; `dy` ignored) */
-  const float* nscale;  /* optional [N]: row n of the accumulated tile is multiplied by nscale[n] before it is added to dw */
 } mds_pw_wgrad_args;
 int mds_pw_wgrad(const mds_pw_wgrad_args* a, mds_stream_t stream);
-
-/* ---- data gradient of a 1x1 EXPANSION convolution (K = mid wide, N = cin <= 192) with the BatchNorm-backward apply pass
- * folded in (round 4, k_pwd.hip): dx[M][N] = dy[M][K] w[N][K]^T (+ residual), dy = A*g + B*y + D formed on load (dyp) and, if
- * dy_out is given, stored for the weight gradient; optionally the next BatchNorm backward's sums over dx (post: PLAIN / MASK).
- * A block owns 64 rows and all N columns and streams K: every wide element is read once.  Replaces mds_bn_bwd_apply +
- * mds_pw_fwd on the dependent chain (native_batch_norm_backward + the input half of convolution_backward behind
- * multidim_stacker.py:124-134 / timm InvertedResidual).                                                                 */
-typedef struct {
-  int dtype;
-  long M;
-  int K, N;             /* K: a multiple of 32 in 64 .. 2048; N: 48, 96, 112 or 192 */
-  const void* x;        /* [M][K] dy, when dyp.mode == 0 */
-  mds_dyp_t dyp;        /* mode 1: dy formed on load from g (PLAIN) and y */
-  void* dy_out;         /* optional [M][K]: the formed dy is also stored */
-  const void* w;        /* [N][K] (MDS_PACK_IO_FLIP of the conv weight) */
-  void* y;              /* [M][N] out */
-  const void* residual; /* optional [M][N], added */
-  mds_poststat_t post;  /* NONE, PLAIN or MASK */
-} mds_pw_dgrad_args;
-int mds_pw_dgrad(const mds_pw_dgrad_args* a, mds_stream_t stream);
-int mds_pw_dgrad_ok(long M, int K, int N);   /* 1 if mds_pw_dgrad takes the shape */
 
 /* ---- K2/K3: dense 3x3 convolution as an MFMA implicit GEMM over a tap list.
  * For output sub-grid point (a,b), a<A, b<B of image n:
@@ -561,47 +500,6 @@ typedef struct {
   void* dy;
 } mds_bn_bwd_apply_args;
 int mds_bn_bwd_apply(const mds_bn_bwd_apply_args* a, mds_stream_t stream);
-
-/* ---- BatchNorm-backward apply pass with a 1x1 weight gradient riding on it (round 4).  In the backward of an
- * inverted-residual block (multidim_stacker.py:124-134 and the timm twin) two streaming passes already touch exactly the
- * wide operands of the block's two 1x1 weight gradients; this entry point is mds_bn_bwd_apply (same dy, bit for bit in
- * bf16) that ALSO accumulates, per (row slab, channel chunk) block,
- *   wide_act == 0:  P[c][k] = sum_m dy[m][c] * x[m][k]                  dy = this pass's result (BN1: the weight gradient
- *                                                                       of conv_pw, x = the block input [M][K])
- *   wide_act == 1:  P[c][k] = sum_m (silu(z[m][c]) * gate[grp][c]) * x[m][k]   z = y*scale + shift (BN2: the weight gradient
- *                                                                       of the gated projection conv_pwl, x = its dy [M][K];
- *                                                                       g.mode must be MDS_G_SE_SILU, whose gate it is)
- * on the matrix cores (the 64 x CW tile goes through LDS; the narrow operand's K <= 192 columns are the whole tile width,
- * so every wide element is loaded once).  Each slab's tile is STORED (no atomics) to part[slab][C][K]; mds_wg_finish adds
- * the slabs in slab order into the parameter gradient - bit-identical from run to run.
- * Replaces one aten::convolution_backward weight-gradient GEMM per call (no second read of the wide tensor).          */
-typedef struct {
-  int dtype;
-  long M;
-  int C;                /* wide channels: the BatchNorm's; a multiple of 64 or of 96 */
-  mds_gsrc_t g;         /* MDS_G_PLAIN, or MDS_G_SE_SILU */
-  const void* y;        /* [M][C] raw conv output (pre-BN) */
-  const float* bn;      /* [4][C] scale, shift, mean, rstd */
-  const float* lin;     /* [3][C] A, B, D of dy = A*g + B*y + D (mds_bn_bwd_finalize) */
-  void* dy;             /* [M][C] out */
-  int K;                /* narrow width: 48, 96, 112 or 192 */
-  const void* x;        /* [M][K] narrow operand */
-  int wide_act;
-  long group_rows;      /* > 0: slabs never straddle a multiple of group_rows (required with MDS_G_SE_SILU: = g.rows_per_group) */
-  int slabs;            /* mds_bn_bwd_apply_wg_slabs(M, C, K, group_rows, wide_act, dtype) */
-  float* part;          /* fp32 [slabs][C][K] scratch, fully overwritten */
-} mds_bn_bwd_apply_wg_args;
-int mds_bn_bwd_apply_wg(const mds_bn_bwd_apply_wg_args* a, mds_stream_t stream);
-int mds_bn_bwd_apply_wg_slabs(long M, int C, int K, long group_rows, int wide_act, int dtype);   /* number of row slabs (rows of part) the launch will use */
-
-/* dw (+)= sum over slabs of part[s][C][K] in slab order; transpose: dw is [K][C] (the gated projection's [cout][mid]) */
-typedef struct {
-  int C, K, slabs;
-  int transpose;
-  const float* part;
-  float* dw;
-} mds_wg_finish_args;
-int mds_wg_finish(const mds_wg_finish_args* a, mds_stream_t stream);
 
 /* ---- K11: GeM pooling over (H,W) of silu(bn(y)) for every (b, t, c):  multidim_stacker.py:35-45
  * pooled[b][t*C + c] = (mean_hw clamp(a, eps)^p)^(1/p);  fp32 math.                              */

@@ -239,14 +239,14 @@ def _bn_bwd_lin(be, g, y, bn, gamma):
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,C,N,gmode,res,post", [
-    (300, 48, 64, 0, False, 0),       # PLAIN dy prologue
+    (300, 48, 64, 0, False, 0),       # no post statistics
     (260, 96, 144, 3, True, 2),       # MASK gradient source + residual + MASK post statistics, two n-tiles
     (515, 16, 32, 0, True, 3),        # narrow (128x64 tile variant) + SILU post statistics (g stored)
     (130, 192, 16, 3, False, 1),      # several k-chunks, PLAIN post statistics
 ])
 def test_pw_fwd_bn_backward_fusion(be, dt, M, C, N, gmode, res, post):
-    """data-gradient GEMM with BatchNorm backward folded in on both sides: the operand dy = BN'(g) is formed on load
-    from (u, y, lin), and the sums of the NEXT BatchNorm backward are taken over the output tile."""
+    """data-gradient GEMM whose epilogue takes the sums of the NEXT BatchNorm backward over the output tile (mds_poststat_t); its
+    operand is the materialised dy = BN'(g) of this layer (mds_bn_bwd_apply's result)."""
     code, tdt = DT[dt]
     g_ = torch.Generator().manual_seed(M + 13 * C + post)
     rpg = 37
@@ -264,10 +264,7 @@ def test_pw_fwd_bn_backward_fusion(be, dt, M, C, N, gmode, res, post):
     gsrc_ref = u.float() * (mask[grp, None] if gmode == 3 else 1.0)
     z.backward(gsrc_ref)
     dy_ref = yf.grad
-    bn = _bn_setup(be, y, gamma, beta)
-    lin = _bn_bwd_lin(be, gsrc_ref, y, bn, gamma)
-    ud, yd = be.t(u), be.t(y)
-    xdy = cabi.dyp(cabi.gsrc(gmode, ud, None, None, be.t(mask), rpg), yd, bn, lin)
+    dyd = be.t(dy_ref.to(tdt))
     out = torch.full((M, N), float("nan")).to(tdt).to(be.device)
     # next layer's BatchNorm (the one whose backward sums the epilogue takes)
     ys = (torch.randn(M, N, generator=g_) * 1.2 - 0.2).to(tdt)
@@ -278,8 +275,8 @@ def test_pw_fwd_bn_backward_fusion(be, dt, M, C, N, gmode, res, post):
     kw = {}
     if post:
         kw["post"] = cabi.poststat(post, be.t(ys), bn2, st2, be.t(mask2), rpg)
-    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=C, N=N, x=None, w=be.t(w), y=out, pro=cabi.pro(0),
-                                residual=be.t(r) if res else None, stats=None, xdy=xdy, **kw))
+    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=C, N=N, x=dyd, w=be.t(w), y=out, pro=cabi.pro(0),
+                                residual=be.t(r) if res else None, stats=None, **kw))
     be.sync()
     dyq = dy_ref.to(tdt).float() if dt == "bf16" else dy_ref
     v = dyq @ w.float().t() + (r.float() if res else 0.0)
@@ -294,41 +291,6 @@ def test_pw_fwd_bn_backward_fusion(be, dt, M, C, N, gmode, res, post):
         s = st2.sum(0).cpu()
         assert_close(s[0], gq.sum(0), "f32", scale=50 * M ** 0.5, msg="post sum g")
         assert_close(s[1], (gq * xh).sum(0), "f32", scale=50 * M ** 0.5, msg="post sum g*xhat")
-
-
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,K,N,mode,gmode", [(500, 32, 64, 0, 0), (333, 48, 144, 2, 3), (700, 112, 32, 4, 3), (90, 16, 16, 0, 0)])
-def test_pw_wgrad_dy_prologue(be, dt, M, K, N, mode, gmode):
-    code, tdt = DT[dt]
-    g_ = torch.Generator().manual_seed(M * 5 + N)
-    rpg = 97
-    groups = (M + rpg - 1) // rpg
-    grp = torch.arange(M) // rpg
-    x = torch.randn(M, K, generator=g_).to(tdt)
-    u = torch.randn(M, N, generator=g_).to(tdt)
-    y = (1.3 * torch.randn(M, N, generator=g_) - 0.4).to(tdt)
-    gamma = 1 + 0.2 * torch.randn(N, generator=g_); beta = 0.1 * torch.randn(N, generator=g_)
-    mask = (torch.rand(groups, generator=g_) < 0.7).float() / 0.7
-    scale, shift, gate = _mk_pro(be, mode, K, groups, g_)
-    yf = y.float().requires_grad_(True)
-    gsrc_ref = u.float() * (mask[grp, None] if gmode == 3 else 1.0)
-    F.batch_norm(yf, None, None, gamma, beta, True, 0.1, 1e-5).backward(gsrc_ref)
-    bn = _bn_setup(be, y, gamma, beta)
-    lin = _bn_bwd_lin(be, gsrc_ref, y, bn, gamma)
-    dw = torch.zeros(N, K, device=be.device)
-    dyp = cabi.dyp(cabi.gsrc(gmode, be.t(u), None, None, be.t(mask), rpg), be.t(y), bn, lin)
-    be.call("pw_wgrad", cabi.make("mds_pw_wgrad_args", dtype=code, M=M, K=K, N=N, x=be.t(x), dy=None, dw=dw,
-                                  pro=cabi.pro(mode, scale, shift, gate, rpg), dyp=dyp))
-    be.sync()
-    a = x.float()
-    if mode == 4:
-        a = a * gate.cpu()[grp]
-    else:
-        a = _apply_pro(a, mode, scale, shift, gate, rpg)
-    dyq = yf.grad
-    if dt == "bf16":
-        a, dyq = a.to(tdt).float(), dyq.to(tdt).float()
-    assert_close(dw, dyq.t() @ a, dt, scale=M ** 0.5, msg="dw")
 
 
 @pytest.fixture
@@ -363,25 +325,6 @@ def test_pw_fwd_filter_resident(be, force_filter_resident, dt, M, K, N, res, sta
     (200, 704, 192, True, False, 1),     # 11 chunks, two n-tiles, residual, PLAIN post statistics
     (130, 1096, 144, False, False, 3),   # K % 64 != 0, ragged n-tile, SILU post statistics
 ])
-def test_pw_fwd_two_chunks_in_flight(be, dt, M, K, N, res, stats, post):
-    """the K-heavy study variant of the general kernel (MDS_KNOB_PW_DEEP: two K chunks in flight, straight-line clamped loads)"""
-    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 1), "dev_set")
-    try:
-        _run_pw_plain(be, dt, M, K, N, res, stats, post, False)
-    finally:
-        be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 0)
-
-
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,K,N,res", [(300, 320, 128, False), (200, 704, 192, True)])
-def test_pw_fwd_two_chunks_in_flight_gated(be, dt, M, K, N, res):
-    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 1), "dev_set")
-    try:
-        test_pw_fwd(be, dt, M, K, N, 4, res, True)   # gated projection (MDS_PRO_GATE) with statistics
-    finally:
-        be.lib.fn["dev_set"](cabi.MDS_KNOB_PW_DEEP, 0)
-
-
 def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken):
     code, tdt = DT[dt]
     g_ = torch.Generator().manual_seed(M + 3 * K + post)
@@ -436,90 +379,3 @@ def _wcat(w0, w1):
     out[:, Kp:Kp + K1] = w1
     return out
 
-
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,K0,K1,N,res,post", [(300, 192, 48, 48, False, 0), (200, 672, 112, 112, True, 2), (130, 96, 24, 32, True, 0),
-                                                (260, 1152, 192, 192, False, 1), (400300, 64, 16, 16, False, 0)])
-def test_pw_fwd_two_operand_pairs_and_bias(be, dt, M, K0, K1, N, res, post):
-    """y = x w0^T + x1 w1^T + bias (+ residual) (+ the next BatchNorm's backward sums): the data gradient in its linear form"""
-    if M > 100000 and be.name == "emu":
-        pytest.skip("large-M tile path is exercised on the GPU")
-    code, tdt = DT[dt]
-    g_ = torch.Generator().manual_seed(M + K0 + N)
-    rpg = 50
-    groups = (M + rpg - 1) // rpg
-    x = torch.randn(M, K0, generator=g_).to(tdt)
-    x1 = torch.randn(M, K1, generator=g_).to(tdt)
-    w0 = (torch.randn(N, K0, generator=g_) / K0 ** 0.5).to(tdt)
-    w1 = (torch.randn(N, K1, generator=g_) / K1 ** 0.5).to(tdt)
-    bias = torch.randn(N, generator=g_)
-    r = torch.randn(M, N, generator=g_).to(tdt)
-    out = torch.full((M, N), float("nan")).to(tdt).to(be.device)
-    kw = {}
-    if post:
-        ys = (torch.randn(M, N, generator=g_) * 1.2 - 0.2).to(tdt)
-        gamma2 = 1 + 0.2 * torch.randn(N, generator=g_); beta2 = 0.1 * torch.randn(N, generator=g_)
-        mask2 = (torch.rand(groups, generator=g_) < 0.6).float() / 0.6
-        bn2 = _bn_setup(be, ys, gamma2, beta2)
-        st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device, dtype=torch.float64)
-        kw["post"] = cabi.poststat(post, be.t(ys), bn2, st, be.t(mask2), rpg)
-    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K0, N=N, x=be.t(x), w=be.t(_wcat(w0, w1)), y=out, pro=cabi.pro(0),
-                                residual=be.t(r) if res else None, stats=None, x1=be.t(x1), K1=K1, bias=be.t(bias), **kw))
-    be.sync()
-    v = x.float() @ w0.float().t() + x1.float() @ w1.float().t() + bias + (r.float() if res else 0.0)
-    assert_close(out, v, dt, msg="y")
-    if post:
-        b2 = bn2.cpu()
-        gq = v.to(tdt).float() if dt == "bf16" else v
-        if post == 2:
-            gq = gq * mask2[torch.arange(M) // rpg][:, None]
-        xhat = (ys.float() - b2[2]) * b2[3]
-        s = st.sum(0).cpu().float()
-        assert_close(s[0], gq.sum(0), dt, scale=M ** 0.5, msg="sum g")
-        assert_close(s[1], (gq * xhat).sum(0), dt, scale=M ** 0.5, msg="sum g xhat")
-
-
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,Cin,Cmid", [(700, 48, 192), (333, 112, 672), (500, 192, 1152)])
-def test_bn_backward_linear_form_equals_the_materialised_dy(be, dt, M, Cin, Cmid):
-    """dx = dy W and dW = dy^T x for dy = A g + B y + D, y = x W^T (a train-mode BatchNorm behind a 1x1 expansion), computed
-    WITHOUT y and without a dy tensor: mds_bn_lin_prep + the two-pair mds_pw_fwd; mds_pw_wgrad(nscale = A) + the Gram matrix
-    (mds_pw_wgrad with dy = x) + column sums + mds_bn_lin_wgrad - against the direct evaluation in float64"""
-    code, tdt = DT[dt]
-    g_ = torch.Generator().manual_seed(M + Cin)
-    x = torch.randn(M, Cin, generator=g_).to(tdt)
-    W = torch.randn(Cmid, Cin, generator=g_) / Cin ** 0.5
-    g = torch.randn(M, Cmid, generator=g_).to(tdt)
-    lin = torch.stack([1 + 0.3 * torch.randn(Cmid, generator=g_), 0.2 * torch.randn(Cmid, generator=g_), 0.1 * torch.randn(Cmid, generator=g_)])
-    A, B, D = lin.double()
-    xd, Wd, gd = x.double(), W.double(), g.double()
-    y = xd @ Wd.t()
-    dy = A * gd + B * y + D
-    dx_ref, dW_ref = dy @ Wd, dy.t() @ xd
-    # ---- data gradient
-    Kp, K1p = (Cmid + 63) // 64 * 64, (Cin + 63) // 64 * 64
-    wcat = torch.full((Cin, Kp + K1p), float("nan")).to(tdt).to(be.device)
-    bias = torch.empty(Cin, device=be.device)
-    be.call("bn_lin_prep", cabi.make("mds_bn_lin_prep_args", dtype=code, Cmid=Cmid, Cin=Cin, w=be.t(W), lin=be.t(lin), wcat=wcat, bias=bias))
-    be.sync()
-    wc = wcat.float().cpu()
-    torch.testing.assert_close(wc[:, :Cmid], (A[:, None] * Wd).t().float(), rtol=1e-2 if dt == "bf16" else 1e-5, atol=1e-2 if dt == "bf16" else 1e-6)
-    Q = (Wd.t() * B) @ Wd
-    torch.testing.assert_close(wc[:, Kp:Kp + Cin], Q.t().float(), rtol=2e-2 if dt == "bf16" else 1e-4, atol=2e-2 if dt == "bf16" else 1e-5)
-    assert wc[:, Cmid:Kp].abs().sum() == 0 and wc[:, Kp + Cin:].abs().sum() == 0 and torch.isfinite(wc).all()
-    torch.testing.assert_close(bias.cpu(), (D @ Wd).float(), rtol=1e-4, atol=1e-4)
-    dx = torch.empty(M, Cin, device=be.device).to(tdt)
-    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=Cmid, N=Cin, x=be.t(g), w=wcat, y=dx, pro=cabi.pro(0), residual=None,
-                                stats=None, x1=be.t(x), K1=Cin, bias=bias))
-    be.sync()
-    assert_close(dx, dx_ref.float(), dt, scale=3.0, msg="dx")
-    # ---- weight gradient
-    dW = torch.zeros(Cmid, Cin, device=be.device)
-    gram = torch.zeros(Cin, Cin, device=be.device)
-    be.call("pw_wgrad", cabi.make("mds_pw_wgrad_args", dtype=code, M=M, K=Cin, N=Cmid, x=be.t(x), dy=be.t(g), dw=dW, pro=cabi.pro(0), nscale=be.t(lin[0].contiguous())))
-    be.call("pw_wgrad", cabi.make("mds_pw_wgrad_args", dtype=code, M=M, K=Cin, N=Cin, x=be.t(x), dy=be.t(x), dw=gram, pro=cabi.pro(0)))
-    cs = torch.zeros(cabi.MDS_STAT_SLOTS, 2, Cin, dtype=torch.float64)
-    cs[7, 0] = xd.sum(0)
-    be.call("bn_lin_wgrad", cabi.make("mds_bn_lin_wgrad_args", Cmid=Cmid, Cin=Cin, w=be.t(W), lin=be.t(lin), gram=gram, colsum=be.t(cs), dw=dW))
-    be.sync()
-    assert_close(dW, dW_ref.float(), dt, scale=M ** 0.5, msg="dW")
