@@ -69,8 +69,14 @@ def motion_kernel(ksize: int, angle: float, direction: float) -> np.ndarray:
 class TrainAugmentations(nn.Module):
     """``get_train_augmentations(size)`` with size = (width, height) like the reference's configs (image_size)."""
 
-    def __init__(self, size, seed: Optional[int] = None):
+    def __init__(self, size, seed: Optional[int] = None, compose_geometric: bool = True):
+        """compose_geometric=True (default): camera move, rotation, resized crop and flip are composed into ONE resampling of
+        the input - less interpolation blur and no intermediate zero borders than the reference, identical to it whenever at
+        most one of them fires (64 % of the samples at the reference's probabilities).  False: the REFERENCE ORDER - each
+        geometric stage resamples the previous stage's output as kornia's nn.Sequential does
+        (src/ball_action/augmentations.py:10-13); result-identical to the reference for every sample, up to two more passes."""
         super().__init__()
+        self.compose_geometric = bool(compose_geometric)
         self.width, self.height = int(size[0]), int(size[1])
         r = self.height / self.width                       # `size = size[::-1]; ratio = size[0] / size[1]`
         self.cfg = dict(camera=dict(degrees=(-2.5, 2.5), translate=(0.1, 0.05), scale=(0.95, 1.05), p=0.2),
@@ -131,13 +137,14 @@ class TrainAugmentations(nn.Module):
 
     # ------------------------------------------------------------------ host tables
     @staticmethod
-    def frame_maps(s: dict, t: int, h: int, w: int) -> Optional[np.ndarray]:
-        """(T, 6) float32 destination -> source maps of the geometric stages of one sample, or None when none fires"""
-        if not any(k in s for k in ("camera", "rotation", "crop", "flip")):
-            return None
-        fwd = np.tile(np.eye(3), (t, 1, 1))
+    def stage_matrices(s: dict, t: int, h: int, w: int) -> List[np.ndarray]:
+        """source -> destination matrices ((T, 3, 3) float64) of the geometric stages of one sample that fire, in the
+        reference's order: camera move, rotation, resized crop; the horizontal flip - a pure re-indexing of the destination,
+        exact under bilinear sampling - is folded into the last of them (or stands alone)"""
+        out = []
         if "camera" in s:
             p = s["camera"]
+            fwd = np.tile(np.eye(3), (t, 1, 1))
 
             def lin(a, b):        # src/augmentations.py tensor_linspace: start * linspace(1, 0) + end * linspace(0, 1)
                 we = np.linspace(0.0, 1.0, t, dtype=np.float32).astype(np.float64)
@@ -151,36 +158,57 @@ class TrainAugmentations(nn.Module):
             al, be = ss * np.cos(aa), ss * np.sin(aa)
             fwd[:, 0, 0], fwd[:, 0, 1], fwd[:, 0, 2] = al, be, (1 - al) * cx - be * cy + tx
             fwd[:, 1, 0], fwd[:, 1, 1], fwd[:, 1, 2] = -be, al, be * cx + (1 - al) * cy + ty
+            out.append(fwd)
         if "rotation" in s:
-            fwd = _rotation_matrix((w - 1) / 2.0, (h - 1) / 2.0, float(s["rotation"])) @ fwd
+            out.append(np.tile(_rotation_matrix((w - 1) / 2.0, (h - 1) / 2.0, float(s["rotation"])), (t, 1, 1)))
         if "crop" in s:
             x0, y0, cw, ch = s["crop"]
             sx, sy = (w - 1) / max(cw - 1, 1), (h - 1) / max(ch - 1, 1)         # resize(..., align_corners=True) of the slice
-            fwd = np.array([[sx, 0, -x0 * sx], [0, sy, -y0 * sy], [0, 0, 1.0]]) @ fwd
+            out.append(np.tile(np.array([[sx, 0, -x0 * sx], [0, sy, -y0 * sy], [0, 0, 1.0]]), (t, 1, 1)))
         if "flip" in s:
-            fwd = np.array([[-1.0, 0, w - 1], [0, 1, 0], [0, 0, 1]]) @ fwd
-        inv = np.linalg.inv(fwd)
-        return inv[:, :2, :].reshape(t, 6).astype(np.float32)
+            fl = np.array([[-1.0, 0, w - 1], [0, 1, 0], [0, 0, 1]])
+            if out:
+                out[-1] = fl @ out[-1]
+            else:
+                out.append(np.tile(fl, (t, 1, 1)))
+        return out
+
+    @staticmethod
+    def frame_maps(s: dict, t: int, h: int, w: int, compose: bool = True) -> List[np.ndarray]:
+        """(T, 6) float32 destination -> source maps, one per resampling pass of this sample: a single composed map
+        (compose=True), or one per geometric stage in the reference's order; [] when no geometric stage fires"""
+        ms = TrainAugmentations.stage_matrices(s, t, h, w)
+        if not ms:
+            return []
+        if compose:
+            fwd = ms[0]
+            for m in ms[1:]:
+                fwd = m @ fwd
+            ms = [fwd]
+        return [np.linalg.inv(m)[:, :2, :].reshape(t, 6).astype(np.float32) for m in ms]
+
+    NWARP = 3          # resampling pass slots (camera move, rotation, resized crop in reference order; one when composed)
+    SLOT_SHARP, SLOT_TAPS, NSLOTS = 3, 4, 5
 
     def _jobs(self, params, t, h, w):
-        """per pass: the job table (ctypes array) of every sample; plus the (B, T, 6) maps"""
+        """per pass slot: the job table (ctypes array) of every sample; plus the (NWARP, B, T, 6) maps of the resampling slots"""
         Job = cabi.STRUCTS["mds_aug_job"]
         b = len(params)
-        maps = np.zeros((b, t, 6), dtype=np.float32)
-        maps[:, :, 0] = 1.0
-        maps[:, :, 4] = 1.0
-        passes = [(Job * b)(), (Job * b)(), (Job * b)()]
-        used = [False, False, False]
+        maps = np.zeros((self.NWARP, b, t, 6), dtype=np.float32)
+        maps[..., 0] = 1.0
+        maps[..., 4] = 1.0
+        passes = [(Job * b)() for _ in range(self.NSLOTS)]
+        used = [False] * self.NSLOTS
         need_scratch = 0
         for i, s in enumerate(params):
-            mp = self.frame_maps(s, t, h, w)
-            chain = [("warp" if mp is not None else "copy", 0)]
-            if mp is not None:
-                maps[i] = mp
+            mps = self.frame_maps(s, t, h, w, self.compose_geometric)
+            chain = [("warp", j) for j in range(len(mps))] or [("copy", 0)]
+            for j, mp in enumerate(mps):
+                maps[j, i] = mp
             if "sharpness" in s:
-                chain.append(("sharp", 1))
+                chain.append(("sharp", self.SLOT_SHARP))
             if "motion_blur" in s:
-                chain.append(("taps", 2))
+                chain.append(("taps", self.SLOT_TAPS))
             if len(chain) > 1 and chain[0][0] == "copy":
                 chain = chain[1:]                         # no resampling: the first filter reads the input directly
             for k, (kind, slot) in enumerate(chain):
@@ -230,7 +258,8 @@ class TrainAugmentations(nn.Module):
         b = len(params)
         raw = b"".join(bytes(p) for p, u_ in zip(passes, used) if u_) + maps.tobytes()
         table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device, non_blocking=True)
-        return dict(table=table, used=used, nused=sum(used), need_scratch=need_scratch, shape=(b, t, h, w), jsz=C.sizeof(cabi.STRUCTS["mds_aug_job"]) * b)
+        return dict(table=table, used=used, nused=sum(used), need_scratch=need_scratch, shape=(b, t, h, w), jsz=C.sizeof(cabi.STRUCTS["mds_aug_job"]) * b,
+                    map_bytes=b * t * 6 * 4)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, params: Optional[List[dict]] = None, noise: Optional[torch.Tensor] = None, prepared: Optional[dict] = None):
@@ -263,10 +292,11 @@ class TrainAugmentations(nn.Module):
             noise = noise.to(device=dev, dtype=torch.float32).contiguous()
         with torch.cuda.device(dev) if x.is_cuda else _Null():
             k = 0
-            for slot in range(3):
+            for slot in range(self.NSLOTS):
                 if not used[slot]:
                     continue
-                args = cabi.make("mds_aug_args", B=b, T=t, H=h, W=w, buf=bufs, jobs=table.data_ptr() + k * jsz, maps=maps_ptr, noise=noise)
+                mp = maps_ptr + (slot if slot < self.NWARP else 0) * prepared["map_bytes"]       # each resampling slot has its own maps
+                args = cabi.make("mds_aug_args", B=b, T=t, H=h, W=w, buf=bufs, jobs=table.data_ptr() + k * jsz, maps=mp, noise=noise)
                 lib.check(lib.fn["aug_pass"](C.byref(args), stream), "aug_pass")
                 k += 1
         self._last = (table, x, out, noise)      # the launches are asynchronous: their operands outlive this call
@@ -281,6 +311,6 @@ class _Null:
         return False
 
 
-def get_train_augmentations(size) -> nn.Module:
-    """src/ball_action/augmentations.py:7 / src/action/augmentations.py:7"""
-    return TrainAugmentations(size)
+def get_train_augmentations(size, compose_geometric: bool = True) -> nn.Module:
+    """src/ball_action/augmentations.py:7 / src/action/augmentations.py:7; compose_geometric=False = the reference's stage order"""
+    return TrainAugmentations(size, compose_geometric=compose_geometric)

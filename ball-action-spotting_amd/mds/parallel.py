@@ -76,6 +76,7 @@ class BucketedSync:
         self.handles, self.comm, self.events = [], None, []
         self.timing = False          # bench: record an event pair around every slice's all-reduce on the communication stream
         self.last_timing = None      # [(lo, hi, microseconds)] of the last step when `timing` is on
+        self.last_exposed_ms = None  # with `timing`: end of the last backward kernel -> end of the last all-reduce (what the step waits for)
 
     def active(self):
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
@@ -113,12 +114,20 @@ class BucketedSync:
         for h, _, _ in self.handles:
             h.wait()
         if self.comm is not None:
-            torch.cuda.current_stream(plan.device).wait_stream(self.comm)
+            cur = torch.cuda.current_stream(plan.device)
+            if self.timing:          # the backward's own work ends here on the compute stream; the collectives end on the communication stream
+                eb, ec = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                eb.record(cur); ec.record(self.comm)
+                self._texp = (eb, ec)
+            cur.wait_stream(self.comm)
         self.buckets = [(lo, hi) for _, lo, hi in self.handles]     # kept for inspection by tests
         if self.timing and getattr(self, "_tev", None):
             torch.cuda.synchronize(plan.device)
             self.last_timing = [(lo, hi, round(e0.elapsed_time(e1) * 1e3, 1)) for lo, hi, e0, e1 in self._tev]
             self._tev = []
+            if getattr(self, "_texp", None):
+                self.last_exposed_ms = round(max(self._texp[0].elapsed_time(self._texp[1]), 0.0), 4)
+                self._texp = None
         self.handles, self.events = [], []
         return dist.get_world_size(self.group)
 

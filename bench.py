@@ -66,9 +66,10 @@ def focal_loss(logits, target, gamma=1.2, alpha=-1.0):
     return loss.mean()
 
 
-def cpu_baseline(max_seconds=20.0):
+def cpu_baseline(max_seconds=20.0, frames=15, frozen=False):
     """The oracle (CPU restatement pinned to the reference) on the host cores, fp32 eager fwd+bwd of ONE
-    full 15x736x1280 window, repeated until ~20 s of CPU work are spent (best pass reported).  If a single
+    full 15x736x1280 window (config 4: 33 frames, 2D encoder frozen, BatchNorm in train mode), repeated until ~20 s of
+    CPU work are spent (best pass reported).  If a single
     full-size pass exceeds the budget the sample falls back to a quarter of the pixels (15x368x640, same
     network and frame count) and the rate is scaled by 1/4 — the `sample` string says which was used.
     A bf16-autocast pass of the quarter-size sample is timed beside it (SURVEY §8d asks for both)."""
@@ -78,12 +79,15 @@ def cpu_baseline(max_seconds=20.0):
     threads = min(cores, 32)       # eager convolutions stop scaling (and oversubscribe) well before 256 threads
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0, num_frames=frames)
     m = orc.MultiDimStacker(**kw).train()
+    if frozen:
+        for p_ in m.conv2d_encoder.parameters():
+            p_.requires_grad_(False)
     tgt = torch.tensor([[1.0, 0.0]])
 
     def run(h, w, budget, amp=False, max_n=12):
-        x = torch.rand(1, 15, h, w, generator=torch.Generator().manual_seed(1234))
+        x = torch.rand(1, frames, h, w, generator=torch.Generator().manual_seed(1234))
         times, t_start = [], time.time()
         while True:
             t0 = time.time()
@@ -95,19 +99,21 @@ def cpu_baseline(max_seconds=20.0):
             if time.time() - t_start > budget or len(times) >= max_n:
                 return times
 
-    frac, shape = 1, "15x736x1280"
+    frac, shape = 1, f"{frames}x736x1280"
     times = run(736, 1280, max_seconds)
     if len(times) == 1 and times[0] > max_seconds:          # host too slow for full windows: bounded sample
-        frac, shape = 4, "15x368x640"
+        frac, shape = 4, f"{frames}x368x640"
         times = run(368, 640, max_seconds)
     timed = times[1:] if len(times) > 1 else times          # the first pass warms the allocator up
     sec = min(timed)
-    scaled = "" if frac == 1 else f", scaled x1/{frac} to 15x736x1280 windows"
+    scaled = "" if frac == 1 else f", scaled x1/{frac} to {frames}x736x1280 windows"
     out = {"value": round(1.0 / (sec * frac), 5), "unit": "frame-windows/s", "cores": threads, "kind": "port",
            "host_logical_cores": cores,
-           "sample": f"oracle fp32 eager fwd+bwd of 1 window of {shape} (batch 1), best of {len(timed)} timed passes "
+           "sample": f"oracle fp32 eager {'encoder fwd (frozen, train-mode BN) + tail fwd+bwd' if frozen else 'fwd+bwd'} of 1 window of {shape} (batch 1), best of {len(timed)} timed passes "
                      f"({sum(times):.1f} s of CPU work in total){scaled}; {threads} threads of {cores} logical cores used",
            "sec_per_sample": round(sec, 3)}
+    if frozen:
+        return out
     try:
         tb = run(368, 640, 6.0, amp=True, max_n=3)
         out["bf16_autocast"] = {"value": round(1.0 / (min(tb) * 4), 5), "unit": "frame-windows/s",
@@ -272,9 +278,12 @@ def bench_predict(args, dev, rank, world):
 
     CH = args.chunk
 
+    last = {}
+
     def run(tta, cdt, graphs=True, chunk=CH):
         """K frames through the predictor, `chunk` consecutive frames per call (1 = the reference's frame-by-frame API)"""
         sp = StreamPredictor(model, frame_size=(1280, 736), tta=tta, compute_dtype=cdt, use_graphs=graphs)
+        last["sp"] = sp
         idx = 0
 
         def feed(nfr):
@@ -318,6 +327,11 @@ def bench_predict(args, dev, rank, world):
         torch.cuda.synchronize()
         return 50 / (time.perf_counter() - t0)
 
+    if args.predict_fbf_only:        # the kernel-trace child: only the reference's frame-by-frame API, fp32
+        el = run(False, None, chunk=1)
+        if rank == 0:
+            print(json.dumps({"metric": "frames/sec, frame-by-frame API (trace child)", "value": round(K / el, 2), "unit": "frames/s"}))
+        return
     el = run(False, None)
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -333,6 +347,37 @@ def bench_predict(args, dev, rank, world):
                                         "bf16_frames_per_s": round(K / run(False, "bf16", chunk=1), 1),
                                         "fp32_no_graph_frames_per_s": round(K / run(False, None, graphs=False, chunk=1), 1)},
                  "round1_module_call_path_frames_per_s": round(module_path(False), 1)}
+    kroof = None
+    if rank == 0 and world == 1 and args.predict_kernel_trace:
+        # per-kernel roofline of the reference's frame-by-frame API: algorithmic bytes / flops per launch from the plans'
+        # own cost table, launch durations from a rocprofv3 --kernel-trace --stats child run of this script on that path
+        fbf_fps = K / run(False, None, chunk=1)
+        sp = last["sp"]
+        cost = {}
+        for c in sp.plans.values():
+            for plan in (c["p2d"], c["ptail"]):
+                for seg, ops in plan.bound.items():
+                    for (name, *_), (nb, fl) in zip(ops, plan.costs[seg]):
+                        e = cost.setdefault(kernel_family(name + "_kernel"), [0, 0.0, 0.0])
+                        e[0] += 1; e[1] += nb; e[2] += fl
+        kt = trace_child(["--config", "predict", "--predict-fbf-only"], steps=300, timeout=400)
+        if kt:
+            kt.pop("_steps")
+            fams = {k: v for k, v in kt.items() if k in cost and cost[k][1] > 0}
+            tot_us = sum(v["total_us"] for v in kt.values())
+            if fams:
+                dom = max(fams, key=lambda k: fams[k]["total_us"])
+                n, nb, fl = cost[dom]
+                avg_b, avg_f, avg_us = nb / n, fl / n, fams[dom]["avg_us"]
+                gbs, tfl = avg_b / avg_us / 1e3, avg_f / avg_us / 1e6
+                hbm = avg_b / (HBM_PEAK_GBS * 1e9) >= avg_f / (MFMA_PEAK_TFLOPS * 1e12)
+                kroof = {"kernel": dom, "bound": "hbm" if hbm else "mfma", "achieved": round(gbs if hbm else tfl, 2),
+                         "peak": HBM_PEAK_GBS if hbm else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm else "TFLOP/s",
+                         "frac": round(gbs / HBM_PEAK_GBS if hbm else tfl / MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                         "avg_launch_us": round(avg_us, 2), "launches_per_frame": n, "alg_bytes_per_launch": int(avg_b),
+                         "alg_flops_per_launch": int(avg_f), "share_of_kernel_time": round(fams[dom]["total_us"] / tot_us, 3),
+                         "path": f"frame by frame (the reference's API), fp32, {fbf_fps:.0f} frames/s; durations: rocprofv3 --kernel-trace --stats child run",
+                         "us_per_frame_by_family": {k: round(v["avg_us"] * cost[k][0], 1) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["total_us"])[:8]}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import multidim_stacker_ref as orc
@@ -353,13 +398,13 @@ def bench_predict(args, dev, rank, world):
         t_frame = el / K
         out = {"metric": "frames/sec, sliding-window inference (src/predictors.py) on raw 720x1280 frames padded to 736x1280", "value": round(fps, 2),
                "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(t_frame * 1e3, 4), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32 (1x1 / 3x3 products as split-bf16: three bf16 MFMAs, >= 16 significant bits)", "data": "synthetic",
                "config": {"workload": f"sliding-window predictor over a stream of raw uint8 frames, 15-frame window stride 2, no TTA, fp32, {CH} consecutive "
                                       "frames per call (offline prediction of a half; a step = one frame); one independent stream per GPU",
                           "parallelism": f"replicas x{world}"},
                "roofline": {"bound": "mfma", "frac_whole_path": round(max(35.9e9 / (MFMA_PEAK_TFLOPS * 1e12), 0.12e9 / (HBM_PEAK_GBS * 1e9)) / t_frame, 5),
                             "definition": "SURVEY.md 8(d) config 5: 35.9 GFLOP, 0.12 GB per frame; launch-latency bound in practice",
-                            "kernel": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None},
+                            **(kroof or {"kernel": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None})},
                "cpu_baseline": cpu, **extra}
         print(json.dumps(out))
     if world > 1:
@@ -393,6 +438,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--chunk", type=int, default=8, help="--config predict: consecutive frames per predictor call")
     ap.add_argument("--torch-step", action="store_true", help="torch's focal loss + torch.optim.AdamW(fused=True) instead of mds.train")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
+    ap.add_argument("--predict-kernel-trace", action="store_true", help="--config predict: rocprofv3 kernel-trace child of the frame-by-frame path -> per-kernel roofline")
+    ap.add_argument("--predict-fbf-only", action="store_true", help="--config predict: time only the reference's frame-by-frame API in fp32 (the trace child)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 300 if args.config == "predict" else 20
@@ -406,12 +454,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but only {torch.cuda.device_count()} visible devices (one rank per GPU)"
+    assert local < torch.cuda.device_count(), f"LOCAL_RANK {local} has no device of its own"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
+        devs = [None] * world                       # every rank on its own device: N ranks sharing one GPU would not be an N-GPU line
+        dist.all_gather_object(devs, (os.uname().nodename, torch.cuda.current_device()))
+        assert len(set(devs)) == world, f"ranks share devices: {devs}"
 
     if args.config == "predict":
         return bench_predict(args, dev, rank, world)
@@ -486,9 +540,13 @@ def main():
             fence()
             sync.timing = False
             sl = sync.last_timing or []
-            par_info = {"rccl_ranks": world, "backend": dist.get_backend(), "allreduce_slices_in_backward_order":
+            par_info = {"rccl_ranks": world, "backend": dist.get_backend(), "devices_in_use": world,
+                        "allreduce_slices_in_backward_order":
                         [{"elems": hi - lo, "MB": round((hi - lo) * 4 / 1e6, 2), "us": us} for lo, hi, us in sl],
-                        "note": "rank 0, communication stream; the slices overlap the rest of the backward pass"}
+                        "allreduce_exposed_ms": sync.last_exposed_ms,
+                        "note": "rank 0, communication stream; the slices overlap the rest of the backward pass; allreduce_exposed_ms = end of the "
+                                "last backward kernel on the compute stream -> end of the last all-reduce (what the step waits for); model: "
+                                "27.1 MB ring all-reduce over xGMI ~0.31 ms at 8 ranks, all but the last slice hidden (DESIGN 2e)"}
     assert torch.isfinite(loss).item(), "non-finite loss"
 
     # ---- per-kernel pass: HIP event pairs around every launch (on the launch stream).  Keyed by HIP kernel:
@@ -570,15 +628,23 @@ def main():
                                                              sorted(fams.items(), key=lambda kv: -kv[1]["total_us"])[:12]}})
             roofline.update(pmc_for(dom, extra))
 
+    if rank == 0 and roofline is None and work:       # no per-kernel pass (the config 4 child run): the whole-path fraction needs none
+        t_window = elapsed / args.steps / B
+        roofline = {"kernel": None, "bound": "hbm" if work["bytes"] / (HBM_PEAK_GBS * 1e9) >= work["flop"] / (MFMA_PEAK_TFLOPS * 1e12) else "mfma",
+                    "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                    "frac_whole_path": round(max(work["flop"] / (MFMA_PEAK_TFLOPS * 1e12), work["bytes"] / (HBM_PEAK_GBS * 1e9)) / t_window, 4),
+                    "whole_path": {"mfma_frac": round(work["flop"] * wps / world / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                                   "hbm_alg_frac_block_granular": round(work["bytes"] * wps / world / (HBM_PEAK_GBS * 1e9), 4),
+                                   "definition": "SURVEY.md 8(d): max(F/2.5e15, B/8e12) / t_window; per-kernel fields need --profile-steps > 0"}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(max_seconds=args.cpu_seconds, frames=T, frozen=long)
     others = None
     if rank == 0 and world == 1 and args.config == "train" and full and not args.no_other_configs:
         # BASELINE.json configs[3] and configs[4] beside the headline line (child runs of this script, 20 steps / 300 frames)
         torch.cuda.empty_cache()      # (the children are separate processes on the same 288 GB device)
-        others = {"long004": other_config("long004", ["--steps", "20", "--warmup", "5", "--no-cpu-baseline"]),
-                  "predict": other_config("predict", ["--steps", "300"])}
+        others = {"long004": other_config("long004", ["--steps", "20", "--warmup", "5", "--cpu-seconds", "8"]),
+                  "predict": other_config("predict", ["--steps", "300", "--predict-kernel-trace"])}
 
     if rank == 0:
         stepk = "torch focal loss / optimizer" if args.torch_step else "mds.train fused focal loss / multi-tensor optimizer"

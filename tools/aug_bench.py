@@ -27,3 +27,11 @@ for k, p in cases.items():
     print(f"{k:28s} {ms:7.3f} ms   {2 * nb / ms / 1e6:7.1f} GB/s (read + write once; launches alone)   host tables {host:6.3f} ms")
 ms = t_ms(lambda: mod(x), reps=50)
 print(f"{'sampled (reference p)':28s} {ms:7.3f} ms per batch incl. host sampling + table upload")
+
+# the reference-order mode (compose_geometric=False): every geometric stage is its own resampling pass
+ref = augment.get_train_augmentations((1280, 736), compose_geometric=False)
+for k in ("crop+flip+rot+camera", "rot+crop", "rotation"):
+    prep = ref.prepare(cases[k], 15, 736, 1280, dev)
+    print(f"{'reference order: ' + k:40s} {t_ms(lambda: ref(x, prepared=prep)):7.3f} ms (launches alone)")
+ref.rng.seed(0); mod.rng.seed(0)
+print(f"{'sampled (reference p), reference order':40s} {t_ms(lambda: ref(x), reps=50):7.3f} ms per batch   composed: {t_ms(lambda: mod(x), reps=50):7.3f} ms")
