@@ -21,7 +21,7 @@ template <> struct CvLd<bf16_t> { static const int v = 48; };   // 96 B: 32 B x 
 template <> struct CvLd<float> { static const int v = 40; };     // 160 B
 
 template <typename T, int PRO, int IS, int NFR>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW, int tg) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_fwd_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW, int tg) {   // fp32 (parity path): one block per CU, 512 registers - two spilled 100-286 VGPRs
   typedef typename Frag<T>::type frag_t;
   constexpr int LD = CvLd<T>::v, BN = 16 * NFR;
   constexpr int MF = (IS == 1) ? 4 : 2;        // 16-pixel row fragments per wave
@@ -265,7 +265,7 @@ struct CvqGeom {
   int goy[4], gox[4], gA[4], gB[4];
 };
 
-template <typename T, int MF, int NFR> struct CvqOcc { static const int v = (sizeof(T) == 4 || MF * NFR >= 8 || NFR == 4) ? 2 : 3; };
+template <typename T, int MF, int NFR> struct CvqOcc { static const int v = (sizeof(T) == 4 && MF * NFR >= 8) ? 1 : ((sizeof(T) == 4 || MF * NFR >= 8 || NFR == 4) ? 2 : 3); };   // fp32 wide tiles: one block per CU (two spilled 119-151 VGPRs)
 
 // X3 (fp32 inference plans, a.epi.mode != NONE): split-bf16 products, see Mma<float, true> in platform.h
 template <typename T, bool HASPRO, int IS, int MF, int NFR, bool X3 = false>

@@ -101,7 +101,7 @@ extern "C" int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 3) void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 3) void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
   __shared__ float red[256 * 8];
   __shared__ float red2[256 * 8 * 2];
   const RowMap m = rowmap(a.C, gridDim.z, blockIdx.z);

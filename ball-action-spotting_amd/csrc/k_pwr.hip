@@ -263,7 +263,9 @@ int pw_fwd_wres_try(const mds_pw_fwd_args* a, mds_stream_t stream) {
   const int knob = mds_knob(MDS_KNOB_PW_WRES);
   if (knob == 1) return 1;
   const bool forced = knob == 2;                    // tests: take this kernel at any M, 8 blocks per n-tile
-  if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE || a->residual) return 1;
+  // (the POST form of this kernel - BatchNorm-backward sums of the next layer in the epilogue - needed 137-667 spilled VGPRs and
+  //  no layer of the network reaches it: post statistics belong to block-INPUT gradients, whose N is narrow.  General kernel.)
+  if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE || a->residual || a->post.mode != MDS_POST_NONE) return 1;
   const int K = a->K, N = a->N;
   const int KS = (K + 31) / 32;
   if (K < 72 || (KS != 3 && KS != 4 && KS != 6) || N < 128) return 1;
@@ -272,7 +274,7 @@ int pw_fwd_wres_try(const mds_pw_fwd_args* a, mds_stream_t stream) {
   const size_t esz = a->dtype == MDS_BF16 ? 2 : 4;
   size_t pitch = (size_t)KS * 32 * esz;
   if ((pitch / 32) % 2 == 0) pitch += 32;           // 32 B x odd: conflict-free ds_read_b128 lane groups
-  const bool post = a->post.mode != MDS_POST_NONE;
+  const bool post = false;
   const size_t smem = (size_t)(BN + 64) * pitch + (post ? 4 * BN * sizeof(float) : 0) + (esz == 2 ? 4 * 32 * (16 * NF + 8) * 2 : 0);
   if (smem > 160 * 1024) return 1;
   const int bpc = smem <= 80 * 1024 ? 2 : 1;        // co-resident blocks per CU
@@ -289,11 +291,11 @@ int pw_fwd_wres_try(const mds_pw_fwd_args* a, mds_stream_t stream) {
   if (gx > MT) gx = (int)MT;
   const int LDK = (int)(pitch / esz);
   dim3 grid(gx, nt), block(256);
-#define PWR_GO3(T, TAIL_, NF_, KS_) MDS_LAUNCH((pw_fwd_wres_kernel<T, TAIL_, NF_, KS_, 3>), grid, block, smem, stream, *a, LDK, (int)MT)
+#define PWR_GO3(T, TAIL_, NF_, KS_) MDS_LAUNCH((pw_fwd_wres_kernel<T, TAIL_, NF_, KS_, (sizeof(T) == 4 && KS_ == 6) ? 2 : 3>), grid, block, smem, stream, *a, LDK, (int)MT)   /* fp32 K = 192: two row tiles in flight (three spilled 35-103 VGPRs) */
 #define PWR_GO2(T, TAIL_, NF_) do { if (KS == 3) PWR_GO3(T, TAIL_, NF_, 3); else if (KS == 4) PWR_GO3(T, TAIL_, NF_, 4); else PWR_GO3(T, TAIL_, NF_, 6); } while (0)
 #define PWR_GO(T, TAIL_) do { if (NF == 3) PWR_GO2(T, TAIL_, 3); else PWR_GO2(T, TAIL_, 4); } while (0)
   MDS_DISPATCH_DTYPE(a->dtype, T, {
-    if (post) PWR_GO(T, 1); else PWR_GO(T, 0);
+    PWR_GO(T, 0);
   });
 #undef PWR_GO
 #undef PWR_GO2
