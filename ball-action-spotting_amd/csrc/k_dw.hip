@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
 // backward: window of dy [5 slices][3 rows][3 cols] around the thread's input row; per input pixel
 //   da[it] = sum_{dt,ky,kx} dy[it+1-dt][iy+1-ky][ix+1-kx] * w[dt][ky][kx],   dw[tap] += act[it] * (same dy)
 #ifndef MDS_DW3B_OCC
-#define MDS_DW3B_OCC 2     /* bf16: two blocks per CU with 38 spilled VGPRs against one block without spills: see DESIGN 5 (round 4 A/B) */
+#define MDS_DW3B_OCC 2     /* bf16: two blocks per CU with 38 spilled VGPRs (round 3: already at two blocks per CU; one block per CU halves the waves in flight of a kernel bound by its loads) */
 #endif
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : MDS_DW3B_OCC) void dw3_bwd_kernel(mds_dw_bwd_args a, DwStrips g) {
