@@ -22,6 +22,7 @@ template <> struct CvLd<float> { static const int v = 40; };     // 160 B
 
 template <typename T, int PRO, int IS, int NFR>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void conv_fwd_kernel(mds_conv_fwd_args a, int dymin, int dxmin, int TH, int TW, int tg) {   // fp32 (parity path): one block per CU, 512 registers - two spilled 100-286 VGPRs
+  MDS_CHAIN_PRIO();
   typedef typename Frag<T>::type frag_t;
   constexpr int LD = CvLd<T>::v, BN = 16 * NFR;
   constexpr int MF = (IS == 1) ? 4 : 2;        // 16-pixel row fragments per wave
@@ -270,6 +271,7 @@ template <typename T, int MF, int NFR> struct CvqOcc { static const int v = (siz
 // X3 (fp32 inference plans, a.epi.mode != NONE): split-bf16 products, see Mma<float, true> in platform.h
 template <typename T, bool HASPRO, int IS, int MF, int NFR, bool X3 = false>
 __global__ __launch_bounds__(256, (CvqOcc<T, MF, NFR>::v)) void conv_fwd_q_kernel(mds_conv_fwd_args a, CvqGeom gq) {
+  MDS_CHAIN_PRIO();
   typedef Mma<T, X3> MM;
   constexpr int TA = 4 * MF, BNQ = 16 * NFR, MAXX = CVQ_MAXX;
   MDS_DYN_SMEM(smem);

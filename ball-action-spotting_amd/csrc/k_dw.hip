@@ -311,6 +311,7 @@ MDS_DEV DwBlock dw_block(const DwStrips& g) {
 template <typename T, int R, bool POOL = false>
 // (fp32 six-row bands at 168 VGPRs spilled 56-63 registers: 1.3-1.5 TB/s in the fp32 inference plans; two blocks per CU for that variant)
 __global__ __launch_bounds__(256, (sizeof(T) == 4 && R == 6) ? 2 : MDS_DW2F_OCC) void dw2_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
+  MDS_CHAIN_PRIO();
   constexpr int NR = R + 2;
   typedef Pair<T> P;
   typedef typename P::raw_t raw_t;
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && R == 6) ? 2 : MDS_DW2F_OCC)
 //   dw[ky][kx]  += act[iy][ix] * dy[iy+1-ky][ix+1-kx]           (each input pixel owned by one thread)
 template <typename T, int R>
 __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwStrips g) {
+  MDS_CHAIN_PRIO();
   constexpr int NR = R + 2;
   typedef Pair<T> P;
   typedef typename P::raw_t raw_t;
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void dw2_bwd_kernel(mds_dw_bwd_args a, DwSt
 #define DW3_T 5
 template <typename T, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
+  MDS_CHAIN_PRIO();
   constexpr int TT = DW3_T;
   typedef Pair<T> P;
   typedef typename P::raw_t raw_t;
@@ -687,6 +690,7 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
 #endif
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : MDS_DW3B_OCC) void dw3_bwd_kernel(mds_dw_bwd_args a, DwStrips g) {
+  MDS_CHAIN_PRIO();
   constexpr int TT = DW3_T;
   typedef Pair<T> P;
   typedef typename P::raw_t raw_t;
@@ -834,6 +838,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : MDS_DW3B_OCC) void dw3_bw
 // column consumes two new input columns (window col 0 <- old col 2).
 template <typename T, bool POOL = false>
 __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwStrips g) {
+  MDS_CHAIN_PRIO();
   constexpr int R = 3, NR = 2 * R + 1;
   typedef Pair<T> P;
   typedef typename P::raw_t raw_t;
@@ -941,6 +946,7 @@ __global__ __launch_bounds__(256, 3) void dw2s_fwd_kernel(mds_dw_fwd_args a, DwS
 // tap kx iff (p + PL - kx) is even -> window column (p+PL-kx+2)/2 - PL   (all compile-time).
 template <typename T, int PT, int PL>
 __global__ __launch_bounds__(256, 2) void dw2s_bwd_kernel(mds_dw_bwd_args a, DwStrips g) {
+  MDS_CHAIN_PRIO();
   constexpr int R = 4;
   typedef Pair<T> P;
   typedef typename P::raw_t raw_t;

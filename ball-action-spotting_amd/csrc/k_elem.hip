@@ -5,6 +5,7 @@
 // ------------------------------------------------------------------ bn_res
 template <typename T>
 __global__ __launch_bounds__(256) void bn_res_kernel(mds_bn_res_args a) {
+  MDS_CHAIN_PRIO();
   const RowMap m = rowmap(a.C);
   if (!m.valid) return;
   const int c0 = m.chunk * 8;
@@ -46,6 +47,7 @@ extern "C" int mds_bn_res(const mds_bn_res_args* a, mds_stream_t stream) {
 // grid = (blocks_per_group, groups); block walks rows of its group.
 template <typename T>
 __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
+  MDS_CHAIN_PRIO();
   __shared__ float red[256 * 8];
   const RowMap m = rowmap(a.C, gridDim.z, blockIdx.z);
   const int c0 = m.c0;
@@ -102,6 +104,7 @@ extern "C" int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream) {
 
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 3) void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
+  MDS_CHAIN_PRIO();
   __shared__ float red[256 * 8];
   __shared__ float red2[256 * 8 * 2];
   const RowMap m = rowmap(a.C, gridDim.z, blockIdx.z);
@@ -189,6 +192,7 @@ extern "C" int mds_se_bwd_reduce(const mds_se_bwd_reduce_args* a, mds_stream_t s
 // ------------------------------------------------------------------ BN backward reduce / apply
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_args a) {
+  MDS_CHAIN_PRIO();
   __shared__ float red[256 * 8 * 2];
   const RowMap m = rowmap(a.C, gridDim.y, blockIdx.y);
   const int c0 = m.c0;
@@ -255,6 +259,7 @@ extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t s
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(mds_bn_bwd_apply_args a) {
+  MDS_CHAIN_PRIO();
   const RowMap m = rowmap(a.C);
   if (!m.valid) return;
   const int c0 = m.chunk * 8;

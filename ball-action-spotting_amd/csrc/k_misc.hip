@@ -102,6 +102,7 @@ MDS_DEV void fin_slot_sums(const S* stats, int C, int c, int sg, double (&red)[2
   red[0][sg][cl] = s; red[1][sg][cl] = ss;
 }
 __global__ __launch_bounds__(256) void bn_finalize_kernel(mds_bn_finalize_args a) {
+  MDS_CHAIN_PRIO();
   __shared__ double red[2][8][FIN_CH];
   const int cl = threadIdx.x % FIN_CH, sg = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
@@ -172,6 +173,7 @@ extern "C" int mds_bn_eval_table(const mds_bn_eval_job* jobs_dev, int njobs, int
 
 // ------------------------------------------------------------------ BN finalize (bwd)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mds_bn_bwd_finalize_args a) {
+  MDS_CHAIN_PRIO();
   __shared__ double red[2][8][FIN_CH];
   const int cl = threadIdx.x % FIN_CH, sg = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
@@ -254,6 +256,7 @@ MDS_DEV void se_matvec_rc(const float* w, const V* v, int R, int C, float (&part
   } while (0)
 template <int RB>
 __global__ __launch_bounds__(256) void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
+  MDS_CHAIN_PRIO();
   __shared__ float part[4][SE_RMAX], hid[SE_RMAX], act[SE_RMAX];
   const int g = blockIdx.x, c = blockIdx.y * SE_CCH + threadIdx.x;
   const bool cok = c < a.C;
@@ -290,6 +293,7 @@ extern "C" int mds_se_fc_fwd(const mds_se_fc_fwd_args* a, mds_stream_t stream) {
 //   mds_se_bwd_reduce:  sum g = sum_grp gate*A1 + dpooled*A3 ;  sum g*xh = sum_grp gate*A2 + dpooled*A4
 template <int RB>
 __global__ __launch_bounds__(256) void se_bwd_a_kernel(mds_se_fc_bwd_args a) {
+  MDS_CHAIN_PRIO();
   __shared__ float part[4][SE_RMAX], dh[SE_RMAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x, C = a.C, R = a.R;

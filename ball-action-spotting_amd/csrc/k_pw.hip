@@ -36,6 +36,7 @@ template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 //   split_part[z][M][N] (fp32), the last block to finish the tile (ticket) adds them in z order and runs the epilogue.
 template <typename T, int PRO, int WN, int BM, int TAIL, bool SPLIT = false>
 __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+  MDS_CHAIN_PRIO();
   static_assert(!SPLIT || (TAIL != 1 && (PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && WN == 2 && BM == 64), "SPLIT variants");
   constexpr bool POST = TAIL == 1, EPI = TAIL == 2;
   typedef typename Frag<T>::type frag_t;

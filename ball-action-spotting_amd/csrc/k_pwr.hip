@@ -26,6 +26,7 @@
 // (that version ran no faster with three tiles in flight than with one).
 template <typename T, int TAIL, int NF, int KS, int D>
 __global__ __launch_bounds__(256, 2) void pw_fwd_wres_kernel(mds_pw_fwd_args a, int LDK, int MT) {
+  MDS_CHAIN_PRIO();
   constexpr bool POST = TAIL == 1;
   constexpr int YM = POST ? 2 : 1, YN = POST ? NF : 1;
   typedef typename Frag<T>::type frag_t;

@@ -10,6 +10,7 @@
 
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(mds_stem_fwd_args a) {
+  MDS_CHAIN_PRIO();
   typedef typename Frag<T>::type frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int i = lane & 15, q = lane >> 4;

@@ -48,6 +48,12 @@ MDS_DEV f32x4 ld_coherent4(const float* p) {
 extern thread_local void* mds_tl_stop_event;   // k_misc.hip (mds_launch_event)
 // all of this lane's outstanding vector-memory operations (loads returned, stores acknowledged): s_waitcnt vmcnt(0)
 MDS_DEV void mds_wait_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // gfx9 encoding: vmcnt = 0, expcnt / lgkmcnt = max (no wait)
+// kernels of the DEPENDENT CHAIN raise their waves' issue priority (s_setprio): where they share a SIMD with a wave of the second
+// stream (weight gradients), the chain's wave is served first.  -DMDS_CHAIN_PRIO_LEVEL=0 builds the library without it (A/B).
+#ifndef MDS_CHAIN_PRIO_LEVEL
+#define MDS_CHAIN_PRIO_LEVEL 3
+#endif
+#define MDS_CHAIN_PRIO() __builtin_amdgcn_s_setprio(MDS_CHAIN_PRIO_LEVEL)
 #define MDS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MDS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  /* wave-uniform value -> scalar register */
 #define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
