@@ -43,7 +43,7 @@ __global__ void pack_kernel(const mds_pack_job* jobs, int njobs) {
     // src [O][27] -> dst [O][32]
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < O * 32; e += gridDim.x * blockDim.x) {
       int o = e >> 5, k = e & 31;
-      Elem<T>::st(dst + e, k < 27 ? jb.src[o * 27 + k] * (jb.oscale ? jb.oscale[o] : 1.0f) : 0.0f);
+      Elem<T>::st(dst + e, k < 27 ? jb.src[o * 27 + k] : 0.0f);
     }
     return;
   }
@@ -53,17 +53,11 @@ __global__ void pack_kernel(const mds_pack_job* jobs, int njobs) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < O * I; e += gridDim.x * blockDim.x) d32[e] = jb.src[(e % O) * I + e / O];
     return;
   }
-  if (jb.kind == MDS_PACK_COPY_F32) {
-    float* d32 = (float*)jb.dst;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x)
-      d32[e] = jb.src[e] * (jb.oscale ? jb.oscale[e / (I * taps)] : 1.0f);
-    return;
-  }
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     // e indexes the destination
     if (jb.kind == MDS_PACK_OI) {
       int i = e % I, t = (e / I) % taps, o = e / (I * taps);
-      Elem<T>::st(dst + e, jb.src[(o * I + i) * taps + t] * (jb.oscale ? jb.oscale[o] : 1.0f));
+      Elem<T>::st(dst + e, jb.src[(o * I + i) * taps + t]);
     } else {  // MDS_PACK_IO_FLIP: dst [I][taps][O], tap flipped
       int o = e % O, t = (e / O) % taps, i = e / (O * taps);
       Elem<T>::st(dst + e, jb.src[(o * I + i) * taps + (taps - 1 - t)]);
@@ -158,8 +152,7 @@ __global__ __launch_bounds__(256) void bn_eval_table_kernel(const mds_bn_eval_jo
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < jb.C; c += gridDim.x * blockDim.x) {
     const float mean = jb.running_mean[c], rstd = 1.0f / sqrtf(jb.running_var[c] + jb.eps);
     const float sc = jb.gamma[c] * rstd;
-    jb.out[c] = jb.fold ? 1.0f : sc;
-    if (jb.fold) jb.fold[c] = sc;
+    jb.out[c] = sc;
     jb.out[jb.C + c] = jb.beta[c] - mean * sc;
     jb.out[2 * jb.C + c] = mean;
     jb.out[3 * jb.C + c] = rstd;

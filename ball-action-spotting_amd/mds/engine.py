@@ -82,14 +82,6 @@ class BNL:
         self.bstats = pb.zero_bwd64(SLOTS * 2 * C_) if pb.need_grad else None      # fp64 slots (include/mds.h)
         self.coef = pb.f32(3 * C_) if pb.need_grad else None
         self.lin = pb.f32(3 * C_) if pb.need_grad else None     # A, B, D of dy = A*g + B*y + D (mds_dyp_t)
-        self.fold = None      # inference plans: [C] eval-mode scale folded into the producer's packed weights (BNL.folded)
-
-    def folded(self, pb):
-        """inference plans (the BN-folded encoder): this layer's scale gamma * rstd goes into the producing
-        convolution's packed weights (mds_pack_job.oscale) and the table's scale row becomes 1 - returns the [C] scale buffer"""
-        if self.fold is None:
-            self.fold = pb.f32(self.C)
-        return self.fold
 
     scale = property(lambda s: s.buf.sub(0, s.C))
     shift = property(lambda s: s.buf.sub(s.C, s.C))
@@ -220,8 +212,6 @@ class Plan:
         self.fuse_bn_bwd = os.environ.get("MDS_FUSE_BN_BWD", "1") != "0"
         # inference plans (eval-mode BatchNorm, no gradient): producers store activated outputs (mds_epi_t)
         self.eval_epilogues = (not training) and (not need_grad) and os.environ.get("MDS_EVAL_EPI", "1") == "1"
-        # inference plans: the eval-mode BatchNorm scale is folded into the packed weights (MDS_FOLD_BN=0: applied in the epilogue)
-        self.fold_bn = self.eval_epilogues and os.environ.get("MDS_FOLD_BN", "1") == "1"
         self.in_flight = False
         self.generation = 0      # bumped by every grad-enabled forward: a stale autograd node must not run
         self.profile = None      # list -> run() brackets every launch with HIP events
@@ -310,10 +300,10 @@ class Plan:
         self._mask_total += n
         return l
 
-    def pack(self, param, kind, O, I, taps, oscale=None):
+    def pack(self, param, kind, O, I, taps):
         n = O * 32 if kind == cabi.MDS_PACK_STEM else O * I * taps
-        dst = self._own(n, torch.float32 if kind in (cabi.MDS_PACK_IO_F32, cabi.MDS_PACK_COPY_F32) else self.tdt)
-        self.pack_jobs.append((param, dst, kind, O, I, taps, oscale))
+        dst = self._own(n, torch.float32 if kind == cabi.MDS_PACK_IO_F32 else self.tdt)
+        self.pack_jobs.append((param, dst, kind, O, I, taps))
         return dst
 
     def op(self, seg, name, **kw):
@@ -381,8 +371,7 @@ class Plan:
     def _pw(self, seg, x, M, K, N_, wparam, pro=None, stats_bn=None, residual=None, wt=None, epi_mode=None):
         """epi_mode (inference plans only): the output is stored as act(bn(y)) (+ residual), mds_epi_t"""
         y = self.act(M, N_)
-        fold = stats_bn.folded(self) if (epi_mode is not None and wt is None and self.fold_bn) else None
-        w = wt if wt is not None else self.pack(wparam, cabi.MDS_PACK_OI, N_, K, 1, oscale=fold)
+        w = wt if wt is not None else self.pack(wparam, cabi.MDS_PACK_OI, N_, K, 1)
         if epi_mode is not None:
             assert self.eval_epilogues and stats_bn is not None
             stats_bn.finalize(self, seg)      # eval table
@@ -401,7 +390,7 @@ class Plan:
         bn = BNL(self, bn_mod, Cout, N * OH * OW)
         dy, dx, wi = geo.taps_fwd(pt, pl)
         y = self.act(N * OH * OW, Cout)
-        w = self.pack(wparam, cabi.MDS_PACK_OI, Cout, Cin, 9, oscale=bn.folded(self) if (self.eval_epilogues and self.fold_bn) else None)
+        w = self.pack(wparam, cabi.MDS_PACK_OI, Cout, Cin, 9)
         extra = dict(stats=bn.stats)
         if self.eval_epilogues:
             extra = dict(stats=None, epi=dict(_struct="mds_epi_t", mode=EPI_BN_SILU, scale=bn.scale, shift=bn.shift))
@@ -469,8 +458,7 @@ class Plan:
         def epi(bn, mode):
             return dict(_struct="mds_epi_t", mode=mode, scale=bn.scale, shift=bn.shift)
         a1 = self.act(Min, mid)
-        fb = self.fold_bn
-        self.op(fseg, "pw_fwd", dtype=self.code, M=Min, K=cin, N=mid, x=xin, w=self.pack(blk.conv_pw.weight, cabi.MDS_PACK_OI, mid, cin, 1, oscale=bn1.folded(self) if fb else None),
+        self.op(fseg, "pw_fwd", dtype=self.code, M=Min, K=cin, N=mid, x=xin, w=self.pack(blk.conv_pw.weight, cabi.MDS_PACK_OI, mid, cin, 1),
                 y=a1, pro=dict(mode=0), residual=None, stats=None, epi=epi(bn1, EPI_BN_SILU), **self._split(Min, cin, mid))
         a2 = self.act(Mout, mid)
         R = blk.se.rd
@@ -478,8 +466,7 @@ class Plan:
         # the depthwise pass stores the activation AND takes its per-image channel means (the squeeze-excite input): no se_pool launch
         fuse_pool = groups == N and os.environ.get("MDS_EVAL_POOL", "1") == "1"
         self.op(fseg, "dw_fwd", dtype=self.code, N=N, T=T, IH=IH, IW=IW, C=mid, OH=OH, OW=OW, stride=stride, pad_t=pt,
-                pad_l=pl, kt=kt, x=a1, w=self.pack(blk.conv_dw.weight, cabi.MDS_PACK_COPY_F32, mid, 1, kt * 9, oscale=bn2.folded(self)) if fb else P(blk.conv_dw.weight),
-                y=a2, pro=dict(mode=0), stats=None, epi=epi(bn2, EPI_BN_SILU),
+                pad_l=pl, kt=kt, x=a1, w=P(blk.conv_dw.weight), y=a2, pro=dict(mode=0), stats=None, epi=epi(bn2, EPI_BN_SILU),
                 pool=pooled if fuse_pool else None, pool_inv=1.0 / rpg if fuse_pool else 0.0)
         if not fuse_pool:
             self.op(fseg, "se_pool", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, y=a2, scale=None, shift=None,
@@ -491,7 +478,7 @@ class Plan:
                 w2t=w2t)
         xout = self.act(Mout, cout)
         self.op(fseg, "pw_fwd", dtype=self.code, M=Mout, K=mid, N=cout, x=a2,
-                w=self.pack(blk.conv_pwl.weight, cabi.MDS_PACK_OI, cout, mid, 1, oscale=bn3.folded(self) if fb else None), y=xout,
+                w=self.pack(blk.conv_pwl.weight, cabi.MDS_PACK_OI, cout, mid, 1), y=xout,
                 pro=dict(mode=PRO_GATE, scale=None, shift=None, gate=gate, rows_per_group=rpg),
                 residual=xin if has_skip else None, stats=None, epi=epi(bn3, EPI_AFFINE), **self._split(Mout, mid, cout))
         return xout, OH, OW
@@ -575,7 +562,7 @@ class Plan:
         OH, OW, pt, pl = geo.conv_geometry(H, W, 2)
         y0 = self.act(N * OH * OW, 32)
         bn0 = BNL(self, enc.bn1, 32, N * OH * OW)
-        wst = self.pack(enc.conv_stem.weight, cabi.MDS_PACK_STEM, 32, 27, 1, oscale=bn0.folded(self) if (self.eval_epilogues and self.fold_bn) else None)
+        wst = self.pack(enc.conv_stem.weight, cabi.MDS_PACK_STEM, 32, 27, 1)
         extra = {}
         if self.ingest is not None:      # raw frames: [nsrc][3][src_h][src_w] uint8, images beyond nsrc are the mirrored TTA copies
             src_h, src_w, nsrc = self.ingest
@@ -785,11 +772,10 @@ class Plan:
         Job = cabi.STRUCTS["mds_pack_job"]
         jobs = (Job * max(len(self.pack_jobs), 1))()
         self.pack_max = 1
-        for j, (p, dst, kind, O, I, taps, oscale) in enumerate(self.pack_jobs):
+        for j, (p, dst, kind, O, I, taps) in enumerate(self.pack_jobs):
             jobs[j].src = p.detach().data_ptr()
             jobs[j].dst = dst.resolve().data_ptr()
             jobs[j].kind, jobs[j].O, jobs[j].I, jobs[j].taps = kind, O, I, taps
-            jobs[j].oscale = oscale.resolve().data_ptr() if oscale is not None else None
             self.pack_max = max(self.pack_max, dst.numel)
         self.pack_table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         self.param_ptrs = tuple(p.data_ptr() for p, *_ in self.pack_jobs)
@@ -797,11 +783,10 @@ class Plan:
             BJ = cabi.STRUCTS["mds_bn_eval_job"]
             bj = (BJ * len(self.eval_bn))()
             for j, bn_ in enumerate(self.eval_bn):
-                m, C_, out, fold = bn_.mod, bn_.C, bn_.buf, bn_.fold
+                m, C_, out = bn_.mod, bn_.C, bn_.buf
                 bj[j].gamma, bj[j].beta = m.weight.detach().data_ptr(), m.bias.detach().data_ptr()
                 bj[j].running_mean, bj[j].running_var = m.running_mean.data_ptr(), m.running_var.data_ptr()
                 bj[j].out, bj[j].eps, bj[j].C = out.resolve().data_ptr(), float(m.eps), C_
-                bj[j].fold = fold.resolve().data_ptr() if fold is not None else None
             self.eval_bn_table = torch.frombuffer(bytearray(bytes(bj)), dtype=torch.uint8).to(dev)
             self.eval_bn_maxc = max(e.C for e in self.eval_bn)
             self.param_ptrs += tuple(t.data_ptr() for e in self.eval_bn for t in (e.mod.weight, e.mod.bias, e.mod.running_mean, e.mod.running_var))
@@ -1018,8 +1003,7 @@ class Plan:
         return ts
 
     def refresh_weights(self):
-        """the weight-dependent prefix of a forward: the eval-mode BatchNorm table, then the packed filter copies (which take
-        the folded scales from it)"""
+        """the weight-dependent prefix of a forward: the eval-mode BatchNorm table and the packed filter copies"""
         if self.eval_bn:
             self.lib.check(self.lib.fn["bn_eval_table"](self.eval_bn_table.data_ptr(), len(self.eval_bn), self.eval_bn_maxc,
                                                         self._stream()), "bn_eval_table")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 128
+#define MDS_VERSION 129
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -353,9 +353,6 @@ typedef struct {
   float* out;
   float eps;
   int C;
-  float* fold;     /* optional [C]: the scale gamma * rstd is written HERE and out's scale row becomes 1 - the producing convolution's
-                      packed weights are then multiplied by it (mds_pack_job.oscale: "BN-folded" inference weights, src/predictors.py
-                      runs the network in eval mode), and its output transform only adds the shift */
 } mds_bn_eval_job;
 int mds_bn_eval_table(const mds_bn_eval_job* jobs_dev, int njobs, int max_c, mds_stream_t stream);
 
@@ -709,12 +706,10 @@ int mds_frame_luma(const mds_frame_luma_args* a, mds_stream_t stream);
 #define MDS_PACK_IO_FLIP 1 /* [O][I][taps] -> [I][taps-1-t][O] (data-gradient pack)            */
 #define MDS_PACK_STEM 2    /* [O][3][3][3] -> [O][32] zero padded                              */
 #define MDS_PACK_IO_F32 3  /* [O][I] -> [I][O], kept in fp32 whatever `dtype` (squeeze-excite w2) */
-#define MDS_PACK_COPY_F32 4 /* [O][I][taps] copied as it is, kept in fp32 (depthwise filters with a folded BatchNorm scale) */
 typedef struct {
   const float* src;
   void* dst;
   int kind, O, I, taps;
-  const float* oscale;   /* optional [O]: output channel o's weights are multiplied by oscale[o] (eval-mode BatchNorm scale folded in) */
 } mds_pack_job;
 int mds_pack_weights(const mds_pack_job* jobs_dev, int njobs, int max_elems, int dtype,
                      mds_stream_t stream);
