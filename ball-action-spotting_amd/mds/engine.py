@@ -1018,9 +1018,8 @@ class Plan:
         if self.masks:
             if mask_override is not None:
                 self.mask_arena.tensor.copy_(mask_override.to(self.device, torch.float32).view(-1))
-            else:
-                r = torch.rand(self._mask_total, device=self.device)
-                self.mask_arena.tensor.copy_((r < self.mask_keep).float() / self.mask_keep)
+            else:       # Bernoulli(keep) / keep in two launches (was five: rand, compare, cast, divide, copy)
+                self.mask_arena.tensor.bernoulli_(self.mask_keep).div_(self.mask_keep)
         if refresh:
             self.refresh_weights()
         if self.update_running and self._bn_buffers:
