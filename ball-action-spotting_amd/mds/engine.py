@@ -759,8 +759,20 @@ class Plan:
         dev = self.device
         self.zf_arena.numel, self.zb_arena.numel, self.mask_arena.numel, self.zb64_arena.numel = self._zf, self._zb, self._mask_total, self._zb64
         self.zf64_arena.numel = self._zf64
-        for arena in (self.zf_arena, self.zb_arena, self.mask_arena, self.grad_arena, self.zb64_arena, self.zf64_arena):
-            arena.tensor = torch.zeros(max(arena.numel, 1), dtype=arena.dtype, device=dev)
+        self.mask_arena.tensor = torch.zeros(max(self.mask_arena.numel, 1), dtype=torch.float32, device=dev)
+        # everything a pass zeroes lives in ONE buffer per pass (fp64 part first: 8-byte aligned), so that begin_forward /
+        # begin_backward are one memset each instead of two / three dependent launches in front of the first kernel
+        def carve(*arenas):
+            size = lambda a: max(a.numel, 1) * (8 if a.dtype == torch.float64 else 4)
+            pad = lambda n: (n + 255) // 256 * 256           # every arena starts on a 256-byte boundary (16-byte vector accesses)
+            raw = torch.zeros(sum(pad(size(a)) for a in arenas), dtype=torch.uint8, device=dev)
+            off = 0
+            for a in arenas:
+                a.tensor = raw[off:off + size(a)].view(a.dtype)
+                off += pad(size(a))
+            return raw
+        self._zero_fwd = carve(self.zf64_arena, self.zf_arena)
+        self._zero_bwd = carve(self.zb64_arena, self.zb_arena, self.grad_arena)
         for l in self._lazy:
             l.tensor = (torch.zeros if l.kind == "own0" else torch.empty)(max(l.numel, 1), dtype=l.dtype, device=dev)
         if self.masks:
@@ -1011,10 +1023,8 @@ class Plan:
 
     def begin_forward(self, mask_override=None, refresh=True):
         """refresh=False (the stream predictor): the caller runs refresh_weights() itself, and only when a parameter changed"""
-        if self.zf_arena.numel:
-            self.zf_arena.tensor.zero_()
-        if self.zf64_arena.numel:
-            self.zf64_arena.tensor.zero_()
+        if self.zf_arena.numel or self.zf64_arena.numel:
+            self._zero_fwd.zero_()
         if self.masks:
             if mask_override is not None:
                 self.mask_arena.tensor.copy_(mask_override.to(self.device, torch.float32).view(-1))
@@ -1028,9 +1038,7 @@ class Plan:
             torch.autograd.graph.increment_version(self._bn_buffers)
 
     def begin_backward(self):
-        self.zb_arena.tensor.zero_()
-        self.zb64_arena.tensor.zero_()
-        self.grad_arena.tensor.zero_()
+        self._zero_bwd.zero_()
 
     def stale(self):
         cur = tuple(p.data_ptr() for p, *_ in self.pack_jobs)
