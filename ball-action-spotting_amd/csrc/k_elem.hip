@@ -260,9 +260,11 @@ extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t s
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(mds_bn_bwd_apply_args a) {
   MDS_CHAIN_PRIO();
-  const RowMap m = rowmap(a.C);
+  // C = 1152: 144 eight-channel chunks per row would leave 112 of 256 threads idle - two column slices (blockIdx.y) of 72
+  // chunks x 3 rows per pass instead, as in the reduce kernels (row_slices)
+  const RowMap m = rowmap(a.C, gridDim.y, blockIdx.y);
   if (!m.valid) return;
-  const int c0 = m.chunk * 8;
+  const int c0 = m.c0;
   float sc[8], sh[8], mu[8], rs[8], k0[8], k1[8], k2[8];
   load8f(a.bn + 0 * a.C + c0, sc);
   load8f(a.bn + 1 * a.C + c0, sh);
@@ -288,7 +290,11 @@ extern "C" int mds_bn_bwd_apply(const mds_bn_bwd_apply_args* a, mds_stream_t str
   MDS_REQUIRE(a && a->M < 4294967295L, "bn_bwd_apply: M must be below 2^32 rows");
   MDS_REQUIRE(a && a->M > 0 && a->C % 8 == 0 && a->C <= 2048, "bn_bwd_apply: bad dims");
   MDS_REQUIRE(a->g.u && a->y && a->bn && a->coef && a->dy, "bn_bwd_apply: null pointer");
-  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_apply_kernel<T>, dim3(stream_blocks(a->M, a->C)), dim3(256), 0, stream, *a));
+  const int ns = row_slices(a->C);
+  long nb = (a->M + rows_per_pass(a->C, ns) - 1) / rows_per_pass(a->C, ns);
+  const long cap = (mds_knob(MDS_KNOB_STREAM_BLOCKS) ? mds_knob(MDS_KNOB_STREAM_BLOCKS) : 2048) / ns;
+  if (nb > cap) nb = cap;
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_apply_kernel<T>, dim3((unsigned)nb, ns), dim3(256), 0, stream, *a));
   return mds_check_launch("bn_bwd_apply");
 }
 

@@ -313,10 +313,11 @@ def force_filter_resident(be):
     (2560, 96, 144, False, True, 0),     # no ragged row tile: only the straight-line trips, plus a ragged n-tile block
 ])
 def test_pw_fwd_filter_resident(be, force_filter_resident, dt, M, K, N, res, stats, post):
-    """k_pwr.hip: the short-K / wide-N kernel (filter tile resident in LDS, column sums once per block)"""
+    """k_pwr.hip: the short-K / wide-N kernel (filter tile resident in LDS, column sums once per block).  Launches with post
+    statistics take the GENERAL kernel since round 4 (that form spilled 137-667 VGPRs and no layer reaches it) - same checks."""
     if dt == "f32" and K > 96:
         pytest.skip("fp32 filter tile of K > 96 does not fit two blocks per CU: general kernel")
-    _run_pw_plain(be, dt, M, K, N, res, stats, post, True)
+    _run_pw_plain(be, dt, M, K, N, res, stats, post, post == 0)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
