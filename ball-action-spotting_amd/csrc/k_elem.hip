@@ -58,22 +58,22 @@ __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
     if (prebn) { load8f(a.scale + c0, sc); load8f(a.shift + c0, sh); }
     const T* y = (const T*)a.y + (long)blockIdx.y * a.rows_per_group * a.C;
     T* act = a.act ? (T*)a.act + (long)blockIdx.y * a.rows_per_group * a.C : (T*)0;
-    // 4 rows per trip: the loads are issued together (a single 16-byte load in flight per thread
-    // leaves the kernel latency-bound at ~2 TB/s)
-    const long stride = (long)gridDim.x * m.rpb;
-    for (long r = (long)blockIdx.x * m.rpb + m.rsub; r < a.rows_per_group; r += 4 * stride) {
-      RawV8<T> raw[4];
+    // four row slots per thread, ROLLING: a slot is refilled (next trip's row) as soon as its registers are converted, so three
+    // to four 16-byte loads stay in flight per thread all the time (issue-all / wait-all / compute had the memory pipe idle
+    // during the compute phase and the VALU idle during the wait).  Rows past the end read row 0 again (clamped: no branch
+    // around a load - a conditional load costs a vmcnt(0)).
+    const long R = a.rows_per_group, stride = (long)gridDim.x * m.rpb, r0 = (long)blockIdx.x * m.rpb + m.rsub;
+    RawV8<T> raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const long rr = r0 + k * stride; raw[k].ld(y + (rr < R ? rr : 0) * a.C + c0); }
+    for (long r = r0; r < R; r += 4 * stride) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const long rr = r + k * stride;
-        raw[k].ld(y + (rr < a.rows_per_group ? rr : r) * a.C + c0);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const long rr = r + k * stride;
-        if (rr < a.rows_per_group) {
-          float v[8];
-          raw[k].get(v);
+        const long rr = r + k * stride, rn = rr + 4 * stride;
+        float v[8];
+        raw[k].get(v);
+        raw[k].ld(y + (rn < R ? rn : 0) * a.C + c0);
+        if (rr < R) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { if (prebn) v[j] = siluf_(v[j] * sc[j] + sh[j]); acc[0][j] += v[j]; }
           if (act) store8(act + rr * a.C + c0, v);
@@ -102,8 +102,16 @@ extern "C" int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream) {
   return mds_check_launch("se_pool");
 }
 
+#ifndef MDS_SEBR_OCC
+#define MDS_SEBR_OCC 3
+#endif
+// row slots of se_bwd_reduce: four spill 13 registers at three blocks per CU (+0.2 ms per step), at two blocks per CU they are
+// as fast as two slots at three (13.45 against 13.46 ms; 13.52 with the issue-all / wait-all loop)
+#ifndef MDS_SEBR_SLOTS
+#define MDS_SEBR_SLOTS 2
+#endif
 template <typename T>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 3) void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : MDS_SEBR_OCC) void se_bwd_reduce_kernel(mds_se_bwd_reduce_args a) {
   MDS_CHAIN_PRIO();
   __shared__ float red[256 * 8];
   __shared__ float red2[256 * 8 * 2];
@@ -124,21 +132,26 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : 3) void se_bwd_reduce_ker
     const long base = (long)blockIdx.y * a.rows_per_group * a.C;
     const T* y = (const T*)a.y + base;
     const T* u = (const T*)a.u + base;
-    const long stride = (long)gridDim.x * m.rpb;
-    for (long r0 = (long)blockIdx.x * m.rpb + m.rsub; r0 < a.rows_per_group; r0 += 4 * stride) {
-      RawV8<T> rv[4], ru[4];   // four rows per trip, loads issued together
+    // rolling row slots (see se_pool_kernel)
+    const long R = a.rows_per_group, stride = (long)gridDim.x * m.rpb, rb = (long)blockIdx.x * m.rpb + m.rsub;
+    constexpr int NSL = MDS_SEBR_SLOTS;
+    RawV8<T> rv[NSL], ru[NSL];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const long rr = r0 + k * stride < a.rows_per_group ? r0 + k * stride : r0;
-        rv[k].ld(y + rr * a.C + c0);
-        ru[k].ld(u + rr * a.C + c0);
-      }
+    for (int k = 0; k < NSL; ++k) {
+      const long rr = rb + k * stride < R ? rb + k * stride : 0;
+      rv[k].ld(y + rr * a.C + c0);
+      ru[k].ld(u + rr * a.C + c0);
+    }
+    for (long r0 = rb; r0 < R; r0 += NSL * stride) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (r0 + k * stride >= a.rows_per_group) break;
+      for (int k = 0; k < NSL; ++k) {
+        const long rr = r0 + k * stride, rn = rr + NSL * stride < R ? rr + NSL * stride : 0;
         float v[8], uu[8];
         rv[k].get(v);
         ru[k].get(uu);
+        rv[k].ld(y + rn * a.C + c0);
+        ru[k].ld(u + rn * a.C + c0);
+        if (rr >= R) continue;
         if (fuse_bn) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -207,22 +220,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_ar
     const T* ug = (const T*)a.g.u;
     // 4 rows per trip, all 8 loads issued together: the grid is capped at 512 blocks (atomic tail), so a single
     // row in flight per thread left 16 KB per CU outstanding - a latency-bound 3 TB/s
-    const long stride = (long)gridDim.x * m.rpb;
-    for (long row = (long)blockIdx.x * m.rpb + m.rsub; row < a.M; row += 4 * stride) {
-      RawV8<T> ry[4], ru[4];
+    // rolling row slots (see se_pool_kernel)
+    const long stride = (long)gridDim.x * m.rpb, rb = (long)blockIdx.x * m.rpb + m.rsub;
+    RawV8<T> ry[4], ru[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long rr = rb + k * stride < a.M ? rb + k * stride : 0;
+      ry[k].ld(y + rr * a.C + c0);
+      ru[k].ld(ug + rr * a.C + c0);
+    }
+    for (long row = rb; row < a.M; row += 4 * stride) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const long rr = row + k * stride < a.M ? row + k * stride : row;
-        ry[k].ld(y + rr * a.C + c0);
-        ru[k].ld(ug + rr * a.C + c0);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const long rr = row + k * stride;
+        const long rr = row + k * stride, rn = rr + 4 * stride < a.M ? rr + 4 * stride : 0;
+        float v[8], z[8], u[8], g[8];
+        ry[k].get(v);
+        ru[k].get(u);
+        ry[k].ld(y + rn * a.C + c0);
+        ru[k].ld(ug + rn * a.C + c0);
         if (rr < a.M) {
-          float v[8], z[8], u[8], g[8];
-          ry[k].get(v);
-          ru[k].get(u);
 #pragma unroll
           for (int j = 0; j < 8; ++j) z[j] = v[j] * sc[j] + sh[j];
           eval_g_u(a.g, rr, c0, a.C, z, u, g);
@@ -257,6 +273,9 @@ extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t s
   return mds_check_launch("bn_bwd_reduce");
 }
 
+#ifndef MDS_APPLY_SLOTS
+#define MDS_APPLY_SLOTS 2
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(mds_bn_bwd_apply_args a) {
   MDS_CHAIN_PRIO();
@@ -275,15 +294,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(mds_bn_bwd_apply_args
   load8f(a.coef + 2 * a.C + c0, k2);
   const T* y = (const T*)a.y;
   T* dy = (T*)a.dy;
-  for (long row = (long)blockIdx.x * m.rpb + m.rsub; row < a.M; row += (long)gridDim.x * m.rpb) {
-    float v[8], z[8], g[8];
-    load8(y + row * a.C + c0, v);
+  // two rolling row slots (see se_pool_kernel): the next rows of both operands are requested before this row's arithmetic
+  const T* ug = (const T*)a.g.u;
+  const long stride = (long)gridDim.x * m.rpb, rb = (long)blockIdx.x * m.rpb + m.rsub;
+  constexpr int NSL = MDS_APPLY_SLOTS;
+  RawV8<T> ry[NSL], ru[NSL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = v[j] * sc[j] + sh[j];
-    eval_g<T>(a.g, row, c0, a.C, z, g);
+  for (int k = 0; k < NSL; ++k) {
+    const long rr = rb + k * stride < a.M ? rb + k * stride : 0;
+    ry[k].ld(y + rr * a.C + c0);
+    ru[k].ld(ug + rr * a.C + c0);
+  }
+  for (long row = rb; row < a.M; row += NSL * stride) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = k0[j] * (g[j] - k1[j] - (v[j] - mu[j]) * rs[j] * k2[j]);
-    store8(dy + row * a.C + c0, g);
+    for (int k = 0; k < NSL; ++k) {
+      const long rr = row + k * stride, rn = rr + NSL * stride < a.M ? rr + NSL * stride : 0;
+      float v[8], z[8], u[8], g[8];
+      ry[k].get(v);
+      ru[k].get(u);
+      ry[k].ld(y + rn * a.C + c0);
+      ru[k].ld(ug + rn * a.C + c0);
+      if (rr < a.M) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = v[j] * sc[j] + sh[j];
+        eval_g_u(a.g, rr, c0, a.C, z, u, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = k0[j] * (g[j] - k1[j] - (v[j] - mu[j]) * rs[j] * k2[j]);
+        store8(dy + rr * a.C + c0, g);
+      }
+    }
   }
 }
 extern "C" int mds_bn_bwd_apply(const mds_bn_bwd_apply_args* a, mds_stream_t stream) {
