@@ -81,12 +81,9 @@ __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
       }
     }
   }
-  block_reduce_rows<1>(acc, m, red);
-  if (m.valid && m.rsub == 0) {
-    const float inv = 1.0f / (float)a.rows_per_group;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(a.pooled + (long)blockIdx.y * a.C + c0 + j, (double)(acc[0][j] * inv));
-  }
+  const float inv = 1.0f / (float)a.rows_per_group;
+  double* pooled = a.pooled + (long)blockIdx.y * a.C + m.cbase;
+  block_reduce_channels<1>(acc, m, red, [&](int, int ch, float s) { atomicAdd(pooled + ch, (double)(s * inv)); });
 }
 // blocks per group of a reduce kernel: every block ends with O(C) atomics / partial stores, so it
 // must own enough rows to amortise them (8 passes made the C = 1152 layers tail-bound: 1.2 TB/s)
@@ -174,11 +171,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 2 : MDS_SEBR_OCC) void se_bwd
       }
     }
   }
-  block_reduce_rows<1>(acc, m, red);
-  if (m.valid && m.rsub == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(a.dgate + (long)blockIdx.y * a.C + c0 + j, (double)acc[0][j]);
-  }
+  double* dgate = a.dgate + (long)blockIdx.y * a.C + m.cbase;
+  block_reduce_channels<1>(acc, m, red, [&](int, int ch, float s) { atomicAdd(dgate + ch, (double)s); });
   if (fuse_bn) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -251,15 +245,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_ar
       }
     }
   }
-  block_reduce_rows<2>(acc, m, red);
-  if (m.valid && m.rsub == 0) {
-    double* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * a.C;     // fp64 slots (include/mds.h)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(st + c0 + j, (double)acc[0][j]);
-      atomicAdd(st + a.C + c0 + j, (double)acc[1][j]);
-    }
-  }
+  double* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * a.C + m.cbase;     // fp64 slots (include/mds.h)
+  block_reduce_channels<2>(acc, m, red, [&](int v, int ch, float s) { atomicAdd(st + (long)v * a.C + ch, (double)s); });
 }
 extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M < 4294967295L, "bn_bwd_reduce: M must be below 2^32 rows");
@@ -268,7 +255,8 @@ extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t s
   MDS_REQUIRE(a->g.mode == MDS_G_PLAIN || a->g.mode == MDS_G_SILU || a->g.rows_per_group > 0, "bn_bwd_reduce: rows_per_group");
   const int ns = row_slices(a->C);
   long nb = (a->M + rows_per_pass(a->C, ns) - 1) / rows_per_pass(a->C, ns);
-  if (nb > 512 / ns) nb = 512 / ns;   // 2C atomics per block into 32 slots: 512 blocks measured best (1024: +40 %)
+  const long rcap = mds_knob(MDS_KNOB_REDUCE_BLOCKS) > 0 ? mds_knob(MDS_KNOB_REDUCE_BLOCKS) : 512;
+  if (nb > rcap / ns) nb = rcap / ns;
   MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_reduce_kernel<T>, dim3((unsigned)nb, ns), dim3(256), 0, stream, *a));
   return mds_check_launch("bn_bwd_reduce");
 }
@@ -391,11 +379,8 @@ __global__ __launch_bounds__(256) void gem_partial_kernel(int groups, long rows_
       }
     }
   }
-  block_reduce_rows<1>(acc, m, red);
-  if (m.valid && m.rsub == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(accum + (long)blockIdx.x * C + c0 + j, (double)acc[0][j]);
-  }
+  double* dst = accum + (long)blockIdx.x * C;
+  block_reduce_channels<1>(acc, m, red, [&](int, int ch, float s) { atomicAdd(dst + ch, (double)s); });
 }
 __global__ void gem_finish_kernel(int n, float rows, const float* pp, const double* accum, float* pooled) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
