@@ -52,7 +52,7 @@ def bench_dw(which):
         nin, nout = x.numel(), y.numel()
         if which == "dw_fwd":
             a = cabi.make("mds_dw_fwd_args", dtype=1, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=s, pad_t=pt, pad_l=pl,
-                          kt=kt, x=x, w=w, y=y, pro=pro, stats=st)
+                          kt=kt, x=x, w=w, y=y, pro=pro, stats=None if os.environ.get("KB_NOSTATS") else st)
             timeit(f"dw_fwd {tag}", lambda: lib.call("dw_fwd", a, stream()), (nin + nout) * 2, 2 * 9 * kt * nout)
         else:
             dy = rnd(N * T * OH * OW, C); g = torch.empty_like(x); dw = torch.zeros(C, kt * 9, device=dev)
@@ -106,7 +106,7 @@ def bench_conv(which):
             y = torch.empty(N * OH * OW, Cout, device=dev, dtype=BF); st = torch.zeros(SLOTS, 2, Cout, device=dev, dtype=torch.float64)
             a = cabi.make("mds_conv_fwd_args", dtype=1, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout, A=OH, B=OW, oy0=0,
                           ox0=0, os=1, **{"is": s}, ntaps=9, dy=dy_, dx=dx_, wi=wi, wtaps=9, x=x, w=w, y=y, pro=pro,
-                          residual=None, stats=st)
+                          residual=None, stats=None if os.environ.get("KB_NOSTATS") else st)
             timeit(f"conv_fwd {tag}", lambda: lib.call("conv_fwd", a, stream()), (x.numel() + y.numel()) * 2, flops)
         else:
             dyt = rnd(N * OH * OW, Cout); dw = torch.zeros(Cout, Cin, 3, 3, device=dev)
