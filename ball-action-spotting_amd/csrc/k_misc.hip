@@ -222,31 +222,57 @@ extern "C" int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream
 #define SE_RMAX 64
 #define SE_CCH 256
 
-// out[r] = sum_c w[r][c] * v[c] for all r < R at once: every thread walks its channels
-// (c = tid, tid + 256, ...) with R accumulators, so the R*C/256 loads of a thread are independent
-// and coalesced; then wave shuffles + one LDS hop.  (R dots done one after another by a wave cost
-// 40 us of dependent latency.)
-template <int RB, typename V>  // RB = R rounded up to 16: no per-r branches, so the loads stay back-to-back; V: float or double vector
-MDS_DEV void se_matvec_rc(const float* w, const V* v, int R, int C, float (&part)[4][SE_RMAX], float* out) {
+// out[r] = sum_c w[r][c] * v[c] for all r < R at once.  Wave k owns rows r = k, k + 4, ...; a lane owns 16-byte chunks of the
+// channel axis.  Every load of a row batch (RH rows x JU chunks per lane) is issued before the first FMA, so a [48][1152]
+// matrix is two memory round trips (it was one per 256 channels with 4-byte loads: five, plus an LDS hop across the waves).
+// C % 4 == 0; rows past R read row R - 1 (a legal dummy), chunks past C are weighted by zero.
+MDS_DEV f32x4 se_ld4(const float* p) { return *(const f32x4*)p; }
+MDS_DEV f32x4 se_ld4(const double* p) {
+  const f64x2 a = *(const f64x2*)p, b = *(const f64x2*)(p + 2);
+  return (f32x4){(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+}
+template <int RB, typename V>  // RB = R rounded up to 16; V: float or double vector
+MDS_DEV void se_matvec_rc(const float* w, const V* v, int R, int C, float* out) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float acc[RB];
+  constexpr int RW = RB / 4, RH = RW > 6 ? RW / 2 : RW, JU = 5;
+  const int C4 = C >> 2;
+  float acc[RW];
 #pragma unroll
-  for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-  for (int c = tid; c < C; c += 256) {
-    const float vc = (float)v[c];
-    float wv[RB];
+  for (int k = 0; k < RW; ++k) acc[k] = 0.f;
+  for (int fb = 0; fb < C4; fb += 64 * JU) {
+    f32x4 vv[JU];
+    int fo[JU];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) wv[r] = w[(long)(r < R ? r : R - 1) * C + c];  // rows past R: a legal dummy
+    for (int j = 0; j < JU; ++j) {
+      const int f = fb + lane + 64 * j;
+      fo[j] = f < C4 ? 4 * f : 0;
+      vv[j] = se_ld4(v + fo[j]);
+      if (f >= C4) vv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) acc[r] += wv[r] * vc;
+    for (int h = 0; h < RW; h += RH) {
+      f32x4 wv[RH][JU];
+#pragma unroll
+      for (int rr = 0; rr < RH; ++rr) {
+        const int r = wave + 4 * (h + rr);
+        const float* wr = w + (long)(r < R ? r : R - 1) * C;
+#pragma unroll
+        for (int j = 0; j < JU; ++j) wv[rr][j] = se_ld4(wr + fo[j]);
+      }
+#pragma unroll
+      for (int rr = 0; rr < RH; ++rr)
+#pragma unroll
+        for (int j = 0; j < JU; ++j) {
+          const f32x4 p = wv[rr][j] * vv[j];
+          acc[h + rr] += (p[0] + p[1]) + (p[2] + p[3]);
+        }
+    }
   }
 #pragma unroll
-  for (int r = 0; r < RB; ++r) {
-    const float s = wave_sum(acc[r]);
-    if (lane == 0) part[wave][r] = s;
+  for (int k = 0; k < RW; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) out[wave + 4 * k] = s;     // out: >= RB floats
   }
-  __syncthreads();
-  if (tid < R) out[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
   __syncthreads();
 }
 #define SE_DISPATCH_RB(R, ...)                                      \
@@ -259,7 +285,7 @@ MDS_DEV void se_matvec_rc(const float* w, const V* v, int R, int C, float (&part
 template <int RB>
 __global__ __launch_bounds__(256) void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
   MDS_CHAIN_PRIO();
-  __shared__ float part[4][SE_RMAX], hid[SE_RMAX], act[SE_RMAX];
+  __shared__ float hid[SE_RMAX], act[SE_RMAX];
   const int g = blockIdx.x, c = blockIdx.y * SE_CCH + threadIdx.x;
   const bool cok = c < a.C;
   // this thread's column of w2 and its bias do not depend on the hidden vector: requested first
@@ -268,7 +294,7 @@ __global__ __launch_bounds__(256) void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
 #pragma unroll
   for (int r = 0; r < RB; ++r)
     w2c[r] = (cok && r < a.R) ? (a.w2t ? a.w2t[(long)r * a.C + c] : a.w2[(long)c * a.R + r]) : 0.f;
-  se_matvec_rc<RB>(a.w1, a.pooled + (long)g * a.C, a.R, a.C, part, hid);
+  se_matvec_rc<RB>(a.w1, a.pooled + (long)g * a.C, a.R, a.C, hid);
   if (threadIdx.x < a.R) {
     const float h = hid[threadIdx.x] + a.b1[threadIdx.x];
     act[threadIdx.x] = siluf_(h);
@@ -281,7 +307,7 @@ __global__ __launch_bounds__(256) void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
   a.gate[(long)g * a.C + c] = sigmoidf_(s);
 }
 extern "C" int mds_se_fc_fwd(const mds_se_fc_fwd_args* a, mds_stream_t stream) {
-  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->R > 0 && a->R <= SE_RMAX, "se_fc_fwd: bad dims (R <= %d)", SE_RMAX);
+  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->C % 4 == 0 && a->R > 0 && a->R <= SE_RMAX, "se_fc_fwd: bad dims (C % 4 == 0, R <= %d)", SE_RMAX);
   MDS_REQUIRE(a->pooled && a->w1 && a->b1 && a->w2 && a->b2 && a->hidden && a->gate, "se_fc_fwd: null pointer");
   SE_DISPATCH_RB(a->R, MDS_LAUNCH(se_fc_fwd_kernel<RB>, dim3(a->groups, cdiv(a->C, SE_CCH)), dim3(256), 0, stream, *a));
   return mds_check_launch("se_fc_fwd");
@@ -318,13 +344,13 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(mds_se_fc_bwd_args a) {
     }
   }
   if (a.w2t) {  // de[c] staged once, then the block-wide [R][C] mat-vec
-    __shared__ float de_s[2048];
+    __shared__ __attribute__((aligned(16))) float de_s[2048];
     for (int cc = tid; cc < C; cc += 256) {
       const float gt = a.gate[(long)g * C + cc];
       de_s[cc] = a.dgate[(long)g * C + cc] * gt * (1.0f - gt);
     }
     __syncthreads();
-    se_matvec_rc<RB>(a.w2t, de_s, R, C, part, dh);
+    se_matvec_rc<RB>(a.w2t, de_s, R, C, dh);
     if (tid < R) {
       const float v = dh[tid] * silu_gradf_(a.hidden[g * R + tid]);
       dh[tid] = v;
@@ -394,7 +420,7 @@ __global__ __launch_bounds__(256) void se_bwd_b_kernel(mds_se_fc_bwd_args a) {
   if (r == 0) a.db2[c] += db2;
 }
 static int se_fc_bwd_check(const mds_se_fc_bwd_args* a) {
-  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->C <= 2048 && a->R > 0 && a->R <= SE_RMAX && a->rows_per_group > 0, "se_fc_bwd: bad dims (R <= %d, C <= 2048)", SE_RMAX);
+  MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= 2048 && a->R > 0 && a->R <= SE_RMAX && a->rows_per_group > 0, "se_fc_bwd: bad dims (R <= %d, C % 4 == 0, C <= 2048)", SE_RMAX);
   MDS_REQUIRE(a->scratch && a->dgate && a->gate && a->hidden && a->pooled && a->dpooled, "se_fc_bwd: null pointer");
   MDS_REQUIRE(!(a->bnsums && a->bn_stats) || a->bn_nblk > 0, "se_fc_bwd: bn_nblk");
   return 0;
