@@ -72,7 +72,8 @@ def test_bn_res(be, dt, M, C, act, use_mask, use_sc):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("packed,C,RD", [(True, 48, 12), (False, 48, 12), (True, 328, 28), (True, 1152, 48)])
+@pytest.mark.parametrize("packed,C,RD", [(True, 48, 12), (False, 48, 12), (True, 328, 28), (True, 1152, 48),
+                                         (True, 1536, 64), (True, 2048, 20)])   # > 1280 channels: two trips of the mat-vec; R = 64: 16 rows per wave
 def test_se_forward_backward(be, dt, packed, C, RD):
     """se_pool + se_fc_fwd + (gated consumer) and the SE backward chain vs autograd; with and without
     the packed [R][C] copy of w2 (made by pack_weights / MDS_PACK_IO_F32)."""
