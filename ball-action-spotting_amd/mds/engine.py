@@ -501,10 +501,16 @@ class Plan:
         bn2.finalize(self, fseg)
         R = blk.se.rd
         pooled, hidden, gate = self.zero_fwd64(groups * mid), self.f32(groups * R), self.f32(groups * mid)
-        a2 = self.act(Mout, mid)   # silu(bn2(y2)), written by the pooling pass it shares its reads with
+        # The projection and its weight gradient read y2 through the BN + SiLU + gate prologue; the pooling pass only reads.
+        # (Rounds 2-3 had the pooling pass also WRITE silu(bn2(y2)) for them - free while that pass was bound by its atomics'
+        # epilogue; with the per-channel epilogue the 2 x mid-width write + read costs more than the prologue's arithmetic:
+        # 12.84 -> 12.68 ms per step, MDS_SE_ACT=1 restores it.)
+        keep_act = os.environ.get("MDS_SE_ACT", "0") == "1"
+        a2 = self.act(Mout, mid) if keep_act else y2
         self.op(fseg, "se_pool", dtype=self.code, groups=groups, rows_per_group=rpg, C=mid, y=y2, scale=bn2.scale,
-                shift=bn2.shift, pooled=pooled, act=a2)
-        gate_pro = dict(mode=PRO_GATE, scale=None, shift=None, gate=gate, rows_per_group=rpg)
+                shift=bn2.shift, pooled=pooled, act=a2 if keep_act else None)
+        gate_pro = (dict(mode=PRO_GATE, scale=None, shift=None, gate=gate, rows_per_group=rpg) if keep_act else
+                    dict(mode=PRO_BN_GATE, scale=bn2.scale, shift=bn2.shift, gate=gate, rows_per_group=rpg))
         se = blk.se
         w2t = self.pack(se.conv_expand.weight, cabi.MDS_PACK_IO_F32, mid, R, 1)    # [R][mid], fp32
         self.op(fseg, "se_fc_fwd", groups=groups, C=mid, R=R, pooled=pooled, w1=P(se.conv_reduce.weight),
