@@ -15,6 +15,9 @@
 #include "gemm.h"
 
 #define PW_BM 128
+#ifndef MDS_PW_GPRE3
+#define MDS_PW_GPRE3 1   /* the gate row of a staged vector travels with it in the BN + SiLU + gate prologue too (64-row tiles) */
+#endif
 #define PW_BN 128
 #define PW_SP 72   /* output staging pitch (elements): 64 columns + 16 bytes */
 
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ?
     // loop it was one exposed L2 round trip per K chunk - 18 of them in the 1152 -> 192 projections
     // (the variants that would spill with 8 more registers per row keep the in-loop load: 128-row tiles, BN_SILU_GATE)
     constexpr bool GATED = PRO == MDS_PRO_BN_SILU_GATE || PRO == MDS_PRO_GATE;
-    constexpr bool GPRE = PRO == MDS_PRO_GATE && NL <= 2;
+    constexpr bool GPRE = (PRO == MDS_PRO_GATE || (PRO == MDS_PRO_BN_SILU_GATE && MDS_PW_GPRE3)) && NL <= 2;
     float rg[NS][GPRE ? NL : 1][8];
     const T* wrow[NLW];   // this thread's filter rows of the n-tile (row pointers hoisted out of the k-loop)
     bool wok[NLW];
@@ -129,8 +132,16 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ?
       wok[l] = n < N;
       wrow[l] = w + (long)(wok[l] ? n : 0) * K + 8 * svec;
     }
+    // the prologue's scale / shift of a chunk's 8 channels travel with the chunk's loads too (K-heavy projections with the BN + SiLU +
+    // gate prologue: they were an exposed round trip per K chunk after the barrier)
+    constexpr bool SPRE = PRO == MDS_PRO_BN_SILU_GATE && MDS_PW_GPRE3 && NL <= 2;
+    float psc[SPRE ? 8 : 1], psh[SPRE ? 8 : 1];
     auto issue = [&](int kc, RawV8<T> (&tx)[NL], RawV8<T> (&tw)[NLW], float (&tg)[GPRE ? NL : 1][8]) {  // all global loads of one K-chunk
       const bool kok = kc + 8 * svec < KE;
+      if (SPRE) {
+        const int kp = kok ? kc + 8 * svec : 0;
+        load8f(a.pro.scale + kp, (float (&)[8])psc); load8f(a.pro.shift + kp, (float (&)[8])psh);
+      }
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
         if (xok[l] && kok) tx[l].ld(xrow[l] + kc); else tx[l].zero();
@@ -152,7 +163,10 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ?
         }
       } else {
         float sc[8], sh[8];
-        if (PRO != MDS_PRO_GATE && kin) { load8f(a.pro.scale + kk, sc); load8f(a.pro.shift + kk, sh); }
+        if (SPRE) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { sc[j] = psc[SPRE ? j : 0]; sh[j] = psh[SPRE ? j : 0]; }
+        } else if (PRO != MDS_PRO_GATE && kin) { load8f(a.pro.scale + kk, sc); load8f(a.pro.shift + kk, sh); }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
           const int r = srow + RPP * l;
