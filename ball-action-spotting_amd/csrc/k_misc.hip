@@ -48,9 +48,30 @@ __global__ void pack_kernel(const mds_pack_job* jobs, int njobs) {
     return;
   }
   const int total = O * I * taps;
-  if (jb.kind == MDS_PACK_IO_F32) {
-    float* d32 = (float*)jb.dst;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < O * I; e += gridDim.x * blockDim.x) d32[e] = jb.src[(e % O) * I + e / O];
+  if (jb.kind == MDS_PACK_IO_F32 || (jb.kind == MDS_PACK_IO_FLIP && taps == 1)) {
+    // [O][I] -> [I][O] (the data-gradient pack of every 1x1 filter, the squeeze-excite w2 copy): 32 x 32 tiles through LDS so
+    // that both the fp32 rows read and the packed rows written are contiguous per wave half (a lane-per-destination gather read
+    // one 64-byte line per lane)
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tI = (I + 31) >> 5, nt = tI * ((O + 31) >> 5);
+    const bool f32 = jb.kind == MDS_PACK_IO_F32;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+      const int i0 = (t % tI) * 32, o0 = (t / tI) * 32;
+      for (int r = ty; r < 32; r += 8) {
+        const int o = o0 + r, i = i0 + tx;
+        tile[r][tx] = (o < O && i < I) ? jb.src[(size_t)o * I + i] : 0.0f;
+      }
+      __syncthreads();
+      for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, o = o0 + tx;
+        if (i < I && o < O) {
+          if (f32) ((float*)jb.dst)[(size_t)i * O + o] = tile[tx][r];
+          else Elem<T>::st(dst + (size_t)i * O + o, tile[tx][r]);
+        }
+      }
+      __syncthreads();
+    }
     return;
   }
   if (jb.kind == MDS_PACK_OI && taps == 1 && (total & 3) == 0) {

@@ -280,3 +280,24 @@ def test_pack_weights(be, dt):
     assert_close(dsts[2].view(24, 16), w1.view(24, 16), dt)
     ref = torch.zeros(32, 32); ref[:, :27] = ws.view(32, 27)
     assert_close(dsts[3].view(32, 32), ref, dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("O,I", [(24, 16), (70, 44), (192, 1152), (33, 5)])
+def test_pack_weights_transposed(be, dt, O, I):
+    """[O][I] -> [I][O] packs (MDS_PACK_IO_FLIP with one tap: the 1x1 data-gradient filters; MDS_PACK_IO_F32: the fp32
+    squeeze-excite w2 copy) go through 32 x 32 LDS tiles: ragged edges, several tiles per block."""
+    code, tdt = DT[dt]
+    w = torch.randn(O, I, generator=gen(43))
+    src = be.t(w)
+    d_flip = torch.empty(I * O, dtype=tdt, device=be.device)
+    d_f32 = torch.empty(I * O, dtype=torch.float32, device=be.device)
+    Job = cabi.STRUCTS["mds_pack_job"]
+    jobs = (Job * 2)()
+    for j, (d, k) in enumerate(((d_flip, cabi.MDS_PACK_IO_FLIP), (d_f32, cabi.MDS_PACK_IO_F32))):
+        jobs[j].src = src.data_ptr(); jobs[j].dst = d.data_ptr(); jobs[j].kind = k; jobs[j].O = O; jobs[j].I = I; jobs[j].taps = 1
+    raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(be.device)
+    be.lib.check(be.lib.fn["pack_weights"](raw.data_ptr(), 2, O * I, code, be.stream()), "pack_weights")
+    be.sync()
+    assert_close(d_flip.view(I, O), w.t(), dt)
+    assert torch.equal(d_f32.view(I, O).cpu(), w.t().contiguous())
