@@ -34,12 +34,17 @@ template <> struct PwCfg<float> { static const int KC = 32, LD = 40; };
 // TAIL: 0 = plain epilogue, 1 = POST (BatchNorm-backward sums of the NEXT layer over the output tile, mds_poststat_t),
 //       2 = EPI (mds_epi_t).
 // (Measured and removed, DESIGN 5: the x operand formed on load as dy = A*g + B*y + D, a second operand pair + bias row for the
-//  linear form of BatchNorm backward, two K chunks in flight for the K-heavy layers.)
+//  linear form of BatchNorm backward, two K chunks in flight for the K-heavy layers of the TRAINING step.)
+// DEEP (fp32 inference plans, 64-row tiles, NONE / GATE prologue): TWO K chunks in flight.  A one-image launch has fewer blocks than
+//   CUs, so nothing hides a chunk's load: the K loop ran at one memory round trip per 32-channel chunk (~1.4 us; 36 of them in a
+//   1152 -> 192 projection).  Two register sets, every load issued unconditionally from a clamped address (zeroed in registers
+//   when staged) so that no branch sits between a refill and its wait; an odd chunk count runs one all-zero phantom chunk.
 // SPLIT (inference plans, small M): grid.z blocks share an output tile, each over its own K range; partial tiles go to
 //   split_part[z][M][N] (fp32), the last block to finish the tile (ticket) adds them in z order and runs the epilogue.
-template <typename T, int PRO, int WN, int BM, int TAIL, bool SPLIT = false>
-__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
+template <typename T, int PRO, int WN, int BM, int TAIL, bool SPLIT = false, bool DEEP = false>
+__global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT || DEEP ? 2 : 3) void pw_fwd_kernel(mds_pw_fwd_args a) {
   MDS_CHAIN_PRIO();
+  static_assert(!DEEP || (TAIL != 1 && (PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && WN == 2 && BM == 64), "DEEP variants");
   static_assert(!SPLIT || (TAIL != 1 && (PRO == MDS_PRO_NONE || PRO == MDS_PRO_GATE) && WN == 2 && BM == 64), "SPLIT variants");
   constexpr bool POST = TAIL == 1, EPI = TAIL == 2;
   typedef typename Frag<T>::type frag_t;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ?
       }
     }
 
-    constexpr int NS = 1;
+    constexpr int NS = DEEP ? 2 : 1;
     RawV8<T> rx[NS][NL], rw[NS][NLW];
     // the squeeze-excite gate row of every staged x vector travels WITH it (same issue point): loaded inside the staging
     // loop it was one exposed L2 round trip per K chunk - 18 of them in the 1152 -> 192 projections
@@ -138,6 +143,17 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ?
     float psc[SPRE ? 8 : 1], psh[SPRE ? 8 : 1];
     auto issue = [&](int kc, RawV8<T> (&tx)[NL], RawV8<T> (&tw)[NLW], float (&tg)[GPRE ? NL : 1][8]) {  // all global loads of one K-chunk
       const bool kok = kc + 8 * svec < KE;
+      if (DEEP) {   // straight-line: rows are clamped in xrow / wrow, channels past the range read channel 0; zeroed when staged
+        const int ko = kok ? kc : -8 * svec;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          tx[l].ld(xrow[l] + ko);
+          if (GPRE) load8f(a.pro.gate + (long)grow[l] * K + (kok ? kc + 8 * svec : 0), tg[l]);
+        }
+#pragma unroll
+        for (int l = 0; l < NLW; ++l) tw[l].ld(wrow[l] + ko);
+        return;
+      }
       if (SPRE) {
         const int kp = kok ? kc + 8 * svec : 0;
         load8f(a.pro.scale + kp, (float (&)[8])psc); load8f(a.pro.shift + kp, (float (&)[8])psh);
@@ -159,6 +175,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ?
       if (PRO == MDS_PRO_NONE) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
+          if (DEEP && !(xok[l] && kin)) tx[l].zero();
           tx[l].st(xs + (srow + RPP * l) * LD + 8 * svec);
         }
       } else {
@@ -190,18 +207,25 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ?
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] *= g[j];
             }
+          } else if (DEEP) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
           }
           store8(xs + r * LD + 8 * svec, v);
         }
       }
 #pragma unroll
-      for (int l = 0; l < NLW; ++l) tw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
+      for (int l = 0; l < NLW; ++l) {
+        if (DEEP && !(wok[l] && kin)) tw[l].zero();
+        tw[l].st(ws + (srow + RPP * l) * LD + 8 * svec);
+      }
       __syncthreads();
-      if (kc + KC < KE) issue(kc + KC, tx, tw, tg);    // in flight while the MFMAs below run
+      if (DEEP) issue(kc + 2 * KC, tx, tw, tg);            // refill this set (past the range: clamped reads, never staged as data)
+      else if (kc + KC < KE) issue(kc + KC, tx, tw, tg);    // in flight while the MFMAs below run
       const int ksteps = (KE - kc >= KC) ? KC / 32 : ((KE - kc + 31) >> 5);
 #pragma unroll
       for (int ks = 0; ks < KC / 32; ++ks) {
-        if (ks < ksteps) {
+        if (DEEP || ks < ksteps) {   // DEEP: no branch between a refill and its wait (channels past the range are staged as zeros)
           typename MM::frag xf[MFW];
 #pragma unroll
           for (int mf = 0; mf < MFW; ++mf) xf[mf] = MM::prep(ld_frag(xs + (16 * MFW * wm + 16 * mf + i) * LD + 32 * ks + 8 * q));
@@ -215,7 +239,15 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT ?
       }
     };
     if (!SPLIT || KB < KE) issue(KB, rx[0], rw[0], rg[0]);
-    for (int kc = KB; kc < KE; kc += KC) chunk(kc, rx[0], rw[0], rg[0]);
+    if (DEEP) {
+      issue(KB + KC, rx[NS - 1], rw[NS - 1], rg[NS - 1]);
+      for (int kc = KB; kc < KE; kc += 2 * KC) {
+        chunk(kc, rx[0], rw[0], rg[0]);
+        chunk(kc + KC, rx[NS - 1], rw[NS - 1], rg[NS - 1]);
+      }
+    } else {
+      for (int kc = KB; kc < KE; kc += KC) chunk(kc, rx[0], rw[0], rg[0]);
+    }
     if (SPLIT) {
       // partial tile -> split_part[z]; ticket; the last block of the tile sums the partials in z order (its own included:
       // the order is fixed, so the result does not depend on which block came last) and goes on to the epilogue
@@ -434,9 +466,20 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   int gy = 1;
   if (nt > 1) { gy = cdiv(mds_knob(MDS_KNOB_PW_GY) > 0 ? mds_knob(MDS_KNOB_PW_GY) : 1536, mt); if (gy > nt) gy = nt; if (gy < 1) gy = 1; }
   dim3 grid(mt, gy, split ? a->split : 1), block(256);
+  // two K chunks in flight (DEEP) for the fp32 inference launches that leave CUs without a second block to hide a chunk's load:
+  // 64-row tiles, an output transform or split-K (inference plans only), >= 3 chunks in a block's K range, at most one block per
+  // CU (measured on one 736 x 1280 frame: the 120 ... 232-block split projections -0.6 ... -2.9 us per launch, the 348 / 360-block
+  // expansions +0.3 ... +0.9 us - two blocks on a CU already hide each other's loads).  MDS_KNOBS=17=1: off
+  const int kchunks = cdiv(split ? cdiv(a->K, a->split) : a->K, PwCfg<float>::KC);
+  const bool deep = a->dtype == MDS_F32 && (epi || split) && wn == 2 && bm == 64 && kchunks >= 3 &&
+                    (long)mt * gy * (split ? a->split : 1) <= 256 && mds_knob(MDS_KNOB_PW_DEEP) != 1;
 #define PW_GOSPLIT(T, PRO, TAIL_) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
-       MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_, true>), grid, block, smem, stream, *a); } while (0)
+       if (sizeof(T) == 4 && deep) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_, true, sizeof(T) == 4>), grid, block, smem, stream, *a); \
+       else MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_, true>), grid, block, smem, stream, *a); } while (0)
+#define PW_GODEEP(T, PRO) \
+  do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
+       MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, 2, false, sizeof(T) == 4>), grid, block, smem, stream, *a); } while (0)
 #define PW_GO2(T, PRO, TAIL_) \
   do { const size_t smem = (size_t)(bm + BN) * PwCfg<T>::LD * sizeof(T) + (sizeof(T) == 2 ? 4 * 16 * PW_SP * 2 : 0); \
        if (wn == 2 && bm == 64) MDS_LAUNCH((pw_fwd_kernel<T, PRO, 2, 64, TAIL_>), grid, block, smem, stream, *a); \
@@ -449,6 +492,9 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
       else { if (a->pro.mode == MDS_PRO_GATE) PW_GOSPLIT(T, MDS_PRO_GATE, 0); else PW_GOSPLIT(T, MDS_PRO_NONE, 0); }
     }
     else if (post) PW_GO2(T, MDS_PRO_NONE, 1);
+    else if (epi && deep && sizeof(T) == 4 && (a->pro.mode == MDS_PRO_GATE || a->pro.mode == MDS_PRO_NONE)) {
+      if (a->pro.mode == MDS_PRO_GATE) PW_GODEEP(T, MDS_PRO_GATE); else PW_GODEEP(T, MDS_PRO_NONE);
+    }
     else if (epi) { if (a->pro.mode == MDS_PRO_GATE) PW_GO2(T, MDS_PRO_GATE, 2); else if (a->pro.mode == MDS_PRO_BN_SILU) PW_GO2(T, MDS_PRO_BN_SILU, 2); else PW_GO2(T, MDS_PRO_NONE, 2); }
     else switch (a->pro.mode) {
       case MDS_PRO_NONE: PW_GO(T, MDS_PRO_NONE); break;
@@ -462,6 +508,7 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
 #undef PW_GO
 #undef PW_GO2
 #undef PW_GOSPLIT
+#undef PW_GODEEP
   return mds_check_launch("pw_fwd");
 }
 

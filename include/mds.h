@@ -62,7 +62,8 @@ const char* mds_last_error(void);
 #define MDS_KNOB_REDUCE_PASSES 14  /* rows passes per block of the grouped reduce kernels (0 = default 32) */
 #define MDS_KNOB_DW2_BLOCKS 15     /* block target of the 3x3 stride-1 strip rule (0 = default 640) */
 #define MDS_KNOB_REDUCE_BLOCKS 16  /* block cap of mds_bn_bwd_reduce (0 = default) */
-#define MDS_KNOB_COUNT 17
+#define MDS_KNOB_PW_DEEP 17        /* 1: the fp32 inference launches of mds_pw_fwd keep ONE K chunk in flight (A/B; default: two) */
+#define MDS_KNOB_COUNT 18
 int mds_dev_set(int knob, int value);
 /* Completion event of the NEXT launches of the calling thread (a hipEvent_t as void*; NULL disarms).  While armed, every kernel
  * this thread launches through the library is issued with the event as its STOP event (hipExtLaunchKernelGGL), i.e. the event is

@@ -1,0 +1,10 @@
+#!/bin/bash
+mkdir -p gpurun_out; export TMPDIR=/tmp
+OUT=gpurun_out/r04_ab_pw_deep2.txt
+echo "== predictor bench (DEEP only at <= 256 blocks): knobs, chunks-of-8 fp32 frames/s, frame-by-frame fp32 / fp32 TTA / bf16, chunks-of-8 TTA" > $OUT
+for rep in 1 2 3; do
+for k in "" "17=1"; do
+  r=$(MDS_KNOBS="$k" python bench.py --config predict --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); f=d['frame_by_frame_api']; print(d['value'], f['fp32_frames_per_s'], f['fp32_tta_frames_per_s'], f['bf16_frames_per_s'], d['fp32_tta_frames_per_s'])")
+  echo "KNOBS='$k' $r" >> $OUT
+done; done
+python -m pytest tests/test_k_pw.py tests/test_predictor.py -q -m gpu 2>&1 | tail -2 >> $OUT
