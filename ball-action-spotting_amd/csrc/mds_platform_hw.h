@@ -104,3 +104,44 @@ MDS_DEV float wave_sum(float v) {
   return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16))) +
          (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48)));
 }
+
+// ------------------------------------------------------------------ direct-to-LDS pipeline (k_pwk.hip)
+// A K-streaming GEMM keeps several stages of operands in flight as LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+// instruction, destination = wave-uniform LDS address + 16 * lane, no VGPRs).  hipcc drains such loads with s_waitcnt
+// vmcnt(0) in front of every LDS access it can see and in front of __syncthreads(); so inside the pipelined loop every LDS
+// access is issued through these helpers (inline asm, invisible to that bookkeeping), the barrier is the bare s_barrier,
+// and the waits are counted by hand: vmcnt(n) = "at most n of MY loads still in flight" (they retire in issue order).
+typedef uint32_t lds_t;   // byte address inside the workgroup's LDS allocation
+MDS_DEV lds_t lds_addr_of(const void* p) { return (lds_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+MDS_DEV void glds16(const void* gsrc, lds_t dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)dst_wave_uniform, 16, 0, 0);
+}
+MDS_DEV u16x8 lds_ld16(lds_t addr) {
+  u16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+MDS_DEV void lds_st16(lds_t addr, const u16x8& v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+// the value is usable below this point only (place after the s_waitcnt that covers its load)
+template <typename V> MDS_DEV void reg_pin(V& v) { asm volatile("" : "+v"(v)); }
+MDS_DEV void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int N> MDS_DEV void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> MDS_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wave-uniform n; values without a case wait for the next smaller one (stricter, never wrong)
+MDS_DEV void wait_vm_dyn(int n) {
+#define MDS_VM_CASE(k) case k: wait_vm<k>(); break;
+  switch (n < 0 ? 0 : (n > 40 ? 40 : n)) {
+    MDS_VM_CASE(0) MDS_VM_CASE(1) MDS_VM_CASE(2) MDS_VM_CASE(3) MDS_VM_CASE(4) MDS_VM_CASE(5) MDS_VM_CASE(6) MDS_VM_CASE(7)
+    MDS_VM_CASE(8) MDS_VM_CASE(9) MDS_VM_CASE(10) MDS_VM_CASE(11) MDS_VM_CASE(12) MDS_VM_CASE(13) MDS_VM_CASE(14) MDS_VM_CASE(15)
+    MDS_VM_CASE(16) MDS_VM_CASE(17) MDS_VM_CASE(18) MDS_VM_CASE(19) MDS_VM_CASE(20) MDS_VM_CASE(21) MDS_VM_CASE(22) MDS_VM_CASE(23)
+    MDS_VM_CASE(24) MDS_VM_CASE(25) MDS_VM_CASE(26) MDS_VM_CASE(27) MDS_VM_CASE(28) MDS_VM_CASE(29) MDS_VM_CASE(30) MDS_VM_CASE(31)
+    MDS_VM_CASE(32) MDS_VM_CASE(33) MDS_VM_CASE(34) MDS_VM_CASE(35) MDS_VM_CASE(36) MDS_VM_CASE(37) MDS_VM_CASE(38) MDS_VM_CASE(39)
+    MDS_VM_CASE(40)
+  }
+#undef MDS_VM_CASE
+}
+MDS_DEV void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+// p[idx] for a wave-uniform idx of a table no launch of the same stream is writing: through the scalar cache (s_load), i.e.
+// neither a vector register per lane nor an entry on vmcnt
+MDS_DEV float ld_uniform(const float* p, int idx) { return ((const __attribute__((address_space(4))) float*)(uintptr_t)p)[idx]; }

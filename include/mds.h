@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 129
+#define MDS_VERSION 130
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -63,7 +63,10 @@ const char* mds_last_error(void);
 #define MDS_KNOB_DW2_BLOCKS 15     /* block target of the 3x3 stride-1 strip rule (0 = default 640) */
 #define MDS_KNOB_REDUCE_BLOCKS 16  /* block cap of mds_bn_bwd_reduce (0 = default) */
 #define MDS_KNOB_PW_DEEP 17        /* 1: the fp32 inference launches of mds_pw_fwd keep ONE K chunk in flight (A/B; default: two) */
-#define MDS_KNOB_COUNT 18
+#define MDS_KNOB_PWK 18            /* K-streaming 1x1 GEMM (k_pwk.hip): 0 = rule, 1 = never (A/B), 2 = whenever the shape is legal (tests) */
+#define MDS_KNOB_PWK_DX 19         /* its x prefetch distance in 32-channel stages (0 = default) */
+#define MDS_KNOB_PWK_DW 20         /* its filter prefetch distance in stages (0 = default) */
+#define MDS_KNOB_COUNT 21
 int mds_dev_set(int knob, int value);
 /* Completion event of the NEXT launches of the calling thread (a hipEvent_t as void*; NULL disarms).  While armed, every kernel
  * this thread launches through the library is issued with the event as its STOP event (hipExtLaunchKernelGGL), i.e. the event is

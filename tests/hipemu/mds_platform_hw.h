@@ -78,3 +78,18 @@ MDS_DEV float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
   return v;
 }
+
+// direct-to-LDS pipeline touch-points (k_pwk.hip): the simulator copies at issue time and the waits are no-ops, so only the
+// addressing / slot arithmetic is exercised here - the counted waits themselves are checked on the MI355X
+typedef uint32_t lds_t;
+MDS_DEV lds_t lds_addr_of(const void* p) { return (lds_t)((const char*)p - hipemu::dyn_smem()); }
+MDS_DEV void glds16(const void* gsrc, lds_t dst_wave_uniform) { memcpy(hipemu::dyn_smem() + dst_wave_uniform + 16 * hipemu::lane_id(), gsrc, 16); }
+MDS_DEV u16x8 lds_ld16(lds_t addr) { u16x8 v; memcpy(&v, hipemu::dyn_smem() + addr, 16); return v; }
+MDS_DEV void lds_st16(lds_t addr, const u16x8& v) { memcpy(hipemu::dyn_smem() + addr, &v, 16); }
+template <typename V> MDS_DEV void reg_pin(V&) {}
+MDS_DEV void wait_lgkm0() {}
+template <int N> MDS_DEV void wait_lgkm() {}
+template <int N> MDS_DEV void wait_vm() {}
+MDS_DEV void wait_vm_dyn(int) {}
+MDS_DEV void raw_barrier() { hipemu::block_barrier(); }
+MDS_DEV float ld_uniform(const float* p, int idx) { return p[idx]; }

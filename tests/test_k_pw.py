@@ -369,6 +369,64 @@ def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken):
             assert_close(s[1], (v * v).sum(0), dt, scale=M ** 0.5, msg="sumsq")
 
 
+@pytest.fixture
+def force_kstream(be):
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK, 2), "dev_set")
+    yield
+    for k in (cabi.MDS_KNOB_PWK, cabi.MDS_KNOB_PWK_DX, cabi.MDS_KNOB_PWK_DW):
+        be.lib.fn["dev_set"](k, 0)
+
+
+@pytest.mark.parametrize("M,K,N,mode,stats,dx,dw", [
+    (300, 64, 192, 0, True, 0, 0),       # two stages only: the rings are longer than the stream
+    (333, 1152, 192, 3, True, 0, 0),     # the stage-5 projection: BN + SiLU + gate, 36 stages, ragged last row tile, a gate boundary inside a tile
+    (200, 672, 112, 3, True, 6, 2),      # 128-column tile with 16 padding columns, deep x ring / shallow filter ring
+    (260, 384, 96, 3, True, 2, 5),       # 96-column tile of 128 rows (two row blocks per wave column), minimum x distance
+    (150, 576, 192, 4, False, 3, 3),     # gate only, no statistics
+    (140, 192, 176, 2, True, 0, 0),      # BN + SiLU, N not a multiple of 48
+    (130, 128, 80, 1, True, 0, 0),       # affine prologue, 96-column tile with a padding fragment
+    (1000, 256, 128, 0, True, 10, 10),   # rings at their maximum length
+])
+def test_pw_fwd_kstream(be, force_kstream, M, K, N, mode, stats, dx, dw):
+    """k_pwk.hip: the K-streaming kernel (both operands as LDS-DMA rings with counted waits, prologue one stage ahead through
+    scalar tables, row-major epilogue).  On the simulator this checks addressing and slot arithmetic; the waits on MI355X."""
+    be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK_DX, dx)
+    be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK_DW, dw)
+    dt = "bf16"
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(M * 7 + K + N)
+    rpg = 150
+    groups = (M + rpg - 1) // rpg
+    x = torch.randn(M, K, generator=g).to(tdt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(tdt)
+    scale, shift, gate = _mk_pro(be, mode, K, groups, g)
+    y = torch.full((M, N), float("nan")).to(tdt).to(be.device)
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device, dtype=torch.float64)
+    be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=be.t(x), w=be.t(w), y=y,
+                                pro=cabi.pro(mode, scale, shift, gate, rpg), residual=None, stats=st if stats else None))
+    be.sync()
+    a = _apply_pro(x.float(), mode, scale, shift, gate, rpg).to(tdt).float()
+    ref = a @ w.float().t()
+    assert_close(y, ref, dt, msg="y")
+    if stats:
+        # this kernel adds one partial per 64- / 128-row block: at most ceil(M / 64) slots are touched
+        assert int((st.abs().sum((1, 2)) > 0).sum()) <= -(-M // 64), "the K-streaming kernel was not taken"
+        s = st.sum(0).cpu()
+        assert_close(s[0], ref.sum(0), dt, scale=M ** 0.5, msg="sum")
+        assert_close(s[1], (ref * ref).sum(0), dt, scale=M ** 0.5, msg="sumsq")
+
+
+@pytest.mark.parametrize("M,K,N,res,post", [
+    (300, 1152, 192, True, 2),     # the stage-5 expansion's data gradient: residual + MASK post statistics
+    (210, 672, 112, True, 1),      # PLAIN
+    (260, 384, 96, False, 3),      # SILU (g stored), 128-row tiles
+    (150, 576, 192, True, 0),      # residual only
+    (140, 192, 144, False, 1),     # N = 144: 18 octets per row
+])
+def test_pw_fwd_kstream_data_gradient(be, force_kstream, M, K, N, res, post):
+    _run_pw_plain(be, "bf16", M, K, N, res, False, post, False)
+
+
 # ------------------------------------------------------------------------------------------------ linear form of BatchNorm backward
 def _wcat(w0, w1):
     """[N][K0] and [N][K1] -> the packed [N][Kp + K1p] weight rows of a two-pair mds_pw_fwd (zero padded to multiples of 64)"""

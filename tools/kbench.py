@@ -87,6 +87,43 @@ def bench_pw(which):
             timeit(f"pw_wgrad {tag}", lambda: lib.call("pw_wgrad", a, stream()), (M * K + M * N) * 2, 2 * M * K * N)
 
 
+KH_SHAPES = [  # M, K, N, pro, tag: the K-streaming class (projections forward = data gradients of the expansions)
+    (20 * 23 * 40, 1152, 192, 3, "b5.x pwl 1152->192"), (20 * 23 * 40, 672, 192, 3, "b5.0 pwl 672->192"),
+    (20 * 46 * 80, 672, 112, 3, "b4.x pwl 672->112"), (20 * 46 * 80, 576, 112, 3, "b4.0 pwl 576->112"),
+    (20 * 46 * 80, 384, 96, 3, "b3.x pwl 384->96"), (20 * 46 * 80, 192, 96, 3, "b3.0 pwl 192->96"),
+    (4 * 5 * 23 * 40, 576, 192, 3, "3d pwl 576->192"), (20 * 23 * 40, 192, 192, 0, "proj2d 192->192"),
+]
+
+
+def bench_pwk():
+    """old general kernel (knob 18 = 1) against the K-streaming kernel at several prefetch distances; forward (BN + SiLU +
+    gate prologue, statistics) and data-gradient form (residual + MASK post statistics)"""
+    combos = [(int(a), int(b)) for a, b in (c.split(":") for c in os.environ.get("KB_PWK", "0:0,2:2,4:3,6:3,8:2,10:3").split(","))]
+    for (M, K, N, mode, tag) in KH_SHAPES:
+        x = rnd(M, K); w = rnd(N, K); y = torch.empty(M, N, device=dev, dtype=BF)
+        sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
+        rpg = M // 20
+        gate = torch.rand(20, K, device=dev)
+        st = torch.zeros(SLOTS, 2, N, device=dev, dtype=torch.float64)
+        nbytes, flops = (M * K + M * N + N * K) * 2, 2 * M * K * N
+        fwd = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=cabi.pro(mode, sc, sh, gate, rpg), residual=None, stats=st)
+        ys = rnd(M, N); res = rnd(M, N); bn = torch.rand(4, N, device=dev) + 0.5; mask = torch.ones(20, device=dev)
+        dg = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=cabi.pro(0), residual=res, stats=None,
+                       post=cabi.poststat(2, ys, bn, st, mask, rpg))
+        for name, a, nb in (("fwd", fwd, nbytes), ("dgrad", dg, nbytes + 2 * M * N * 2)):
+            lib.fn["dev_set"](18, 1)
+            timeit(f"{name:5s} {tag} general", lambda: lib.call("pw_fwd", a, stream()), nb, flops)
+            lib.fn["dev_set"](18, 2)
+            for (dx, dw) in combos:
+                lib.fn["dev_set"](19, dx); lib.fn["dev_set"](20, dw)
+                try:
+                    timeit(f"{name:5s} {tag} kstream dx={dx} dw={dw}", lambda: lib.call("pw_fwd", a, stream()), nb, flops)
+                except Exception as e:      # LDS budget exceeded for this combination
+                    print(f"{name:5s} {tag} kstream dx={dx} dw={dw}: {str(e)[:80]}")
+            for k in (18, 19, 20):
+                lib.fn["dev_set"](k, 0)
+
+
 CONV_SHAPES = [(20, 368, 640, 32, 16, 1, 2, "b0.0 32->16"), (20, 368, 640, 16, 64, 2, 2, "b1.0 16->64 s2"),
                (20, 184, 320, 32, 128, 1, 0, "b1.1 32->128"), (20, 184, 320, 32, 128, 2, 0, "b2.0 32->128 s2"),
                (20, 92, 160, 48, 192, 1, 0, "b2.1 48->192")]
@@ -222,6 +259,8 @@ if __name__ == "__main__":
             bench_se()
         elif t.startswith("dw"):
             bench_dw(t)
+        elif t == "pwk":
+            bench_pwk()
         elif t == "pw_as_conv":
             bench_pw_as_conv()
         elif t.startswith("pw"):
