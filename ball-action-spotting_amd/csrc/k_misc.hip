@@ -47,6 +47,23 @@ __global__ void pack_kernel(const mds_pack_job* jobs, int njobs) {
     }
     return;
   }
+  if (jb.kind == MDS_PACK_FRAG_OI || jb.kind == MDS_PACK_FRAG_IO) {
+    // thread = one lane slot (16 bytes) of one fragment: (ks, nf, lane) -> w[n = 16 nf + (lane & 15)][k = 32 ks + 8 (lane >> 4) .. + 7]
+    const bool io = jb.kind == MDS_PACK_FRAG_IO;
+    const int N = io ? I : O, K = io ? O : I, NFT = (N + 15) >> 4, slots = ((K + 31) >> 5) * NFT * 64;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < slots; e += gridDim.x * blockDim.x) {
+      const int lane = e & 63, f = e >> 6, nf = f % NFT, ks = f / NFT;
+      const int n = 16 * nf + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        v[j] = (n < N && k < K) ? (io ? jb.src[(size_t)k * I + n] : jb.src[(size_t)n * I + k]) : 0.0f;
+      }
+      store8(dst + (size_t)e * 8, v);
+    }
+    return;
+  }
   const int total = O * I * taps;
   if (jb.kind == MDS_PACK_IO_F32 || (jb.kind == MDS_PACK_IO_FLIP && taps == 1)) {
     // [O][I] -> [I][O] (the data-gradient pack of every 1x1 filter, the squeeze-excite w2 copy): 32 x 32 tiles through LDS so

@@ -117,6 +117,9 @@ MDS_DEV void glds16(const void* gsrc, lds_t dst_wave_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)(uintptr_t)dst_wave_uniform, 16, 0, 0);
 }
+// 16 bytes per lane from global memory into registers, invisible to hipcc's waitcnt bookkeeping (beside LDS-DMA it would wait for
+// vmcnt(0) at the first use, i.e. for everything issued since): usable only after the caller's own counted s_waitcnt + reg_pin.
+MDS_DEV void gld16(u16x8& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
 MDS_DEV u16x8 lds_ld16(lds_t addr) {
   u16x8 v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -142,6 +145,13 @@ MDS_DEV void wait_vm_dyn(int n) {
 #undef MDS_VM_CASE
 }
 MDS_DEV void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+// eight consecutive floats at a wave-uniform address into SGPRs (s_load_dwordx8); usable after the next lgkmcnt(0) + sreg_pin
+MDS_DEV f32x8 sld8(const float* p_uniform) {
+  f32x8 v;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p_uniform));
+  return v;
+}
+MDS_DEV void sreg_pin(f32x8& v) { asm volatile("" : "+s"(v)); }
 // p[idx] for a wave-uniform idx of a table no launch of the same stream is writing: through the scalar cache (s_load), i.e.
 // neither a vector register per lane nor an entry on vmcnt
 MDS_DEV float ld_uniform(const float* p, int idx) { return ((const __attribute__((address_space(4))) float*)(uintptr_t)p)[idx]; }

@@ -302,6 +302,9 @@ class Plan:
 
     def pack(self, param, kind, O, I, taps):
         n = O * 32 if kind == cabi.MDS_PACK_STEM else O * I * taps
+        if kind in (cabi.MDS_PACK_FRAG_OI, cabi.MDS_PACK_FRAG_IO):      # MFMA-fragment order of w[N][K], zero padded (include/mds.h)
+            N_, K = (O, I) if kind == cabi.MDS_PACK_FRAG_OI else (I, O)
+            n = -(-K // 32) * -(-N_ // 16) * 512
         dst = self._own(n, torch.float32 if kind == cabi.MDS_PACK_IO_F32 else self.tdt)
         self.pack_jobs.append((param, dst, kind, O, I, taps))
         return dst
@@ -372,6 +375,9 @@ class Plan:
         """epi_mode (inference plans only): the output is stored as act(bn(y)) (+ residual), mds_epi_t"""
         y = self.act(M, N_)
         w = wt if wt is not None else self.pack(wparam, cabi.MDS_PACK_OI, N_, K, 1)
+        # the K-heavy narrow-N launches read their filter in MFMA-fragment order, straight into registers (k_pwk.hip)
+        wfrag = (self.pack(wparam, cabi.MDS_PACK_FRAG_OI, N_, K, 1)
+                 if wt is None and epi_mode is None and self.lib.fn["pw_fwd_wants_frag"](int(M), int(K), int(N_), int(self.code)) else None)
         if epi_mode is not None:
             assert self.eval_epilogues and stats_bn is not None
             stats_bn.finalize(self, seg)      # eval table
@@ -379,7 +385,7 @@ class Plan:
                     stats=None, epi=dict(_struct="mds_epi_t", mode=epi_mode, scale=stats_bn.scale, shift=stats_bn.shift), **self._split(M, K, N_))
             return y
         self.op(seg, "pw_fwd", dtype=self.code, M=M, K=K, N=N_, x=x, w=w, y=y, pro=pro or dict(mode=0),
-                residual=residual, stats=stats_bn.stats if stats_bn is not None else None)
+                residual=residual, stats=stats_bn.stats if stats_bn is not None else None, w_frag=wfrag)
         if stats_bn is not None:
             stats_bn.finalize(self, seg)
         return y
@@ -443,6 +449,8 @@ class Plan:
         extra = {}
         if head is not None:
             extra["post"] = head["bn"].post(head)
+        if self.lib.fn["pw_fwd_wants_frag"](int(M), int(N_), int(K), int(self.code)):
+            extra["w_frag"] = self.pack(wparam, cabi.MDS_PACK_FRAG_IO, N_, K, 1)
         self.op(seg, "pw_fwd", dtype=self.code, M=M, K=N_, N=K, x=dy, w=wt, y=dx, pro=dict(mode=0), residual=residual, stats=None, **extra)
         return Grad(dx, head["bn"] if head is not None else None)
 

@@ -64,9 +64,7 @@ const char* mds_last_error(void);
 #define MDS_KNOB_REDUCE_BLOCKS 16  /* block cap of mds_bn_bwd_reduce (0 = default) */
 #define MDS_KNOB_PW_DEEP 17        /* 1: the fp32 inference launches of mds_pw_fwd keep ONE K chunk in flight (A/B; default: two) */
 #define MDS_KNOB_PWK 18            /* K-streaming 1x1 GEMM (k_pwk.hip): 0 = rule, 1 = never (A/B), 2 = whenever the shape is legal (tests) */
-#define MDS_KNOB_PWK_DX 19         /* its x prefetch distance in 32-channel stages (0 = default) */
-#define MDS_KNOB_PWK_DW 20         /* its filter prefetch distance in stages (0 = default) */
-#define MDS_KNOB_COUNT 21
+#define MDS_KNOB_COUNT 19
 int mds_dev_set(int knob, int value);
 /* Completion event of the NEXT launches of the calling thread (a hipEvent_t as void*; NULL disarms).  While armed, every kernel
  * this thread launches through the library is issued with the event as its STOP event (hipExtLaunchKernelGGL), i.e. the event is
@@ -170,6 +168,9 @@ typedef struct {
   double* stats;         /* optional [SLOTS][2][N]                                               */
   mds_poststat_t post;  /* data-gradient use: BN-backward sums of the NEXT layer in the epilogue */
   mds_epi_t epi;        /* eval-mode output transform (no statistics, no post with it) */
+  const void* w_frag;   /* optional second copy of w in MFMA-fragment order (MDS_PACK_FRAG_OI / _IO; bf16): with it the K-heavy
+                           narrow-N launches (mds_pw_fwd_wants_frag) take the K-streaming kernel, whose filter operand goes
+                           from memory straight to registers - one contiguous 1 KiB per (32-channel step, 16 columns)      */
   /* split-K for the small-M launches of inference plans (a 920-row layer is 15-30 blocks that each walk 36 K chunks
    * one memory round trip at a time): grid.z = split blocks share a tile, each stores its fp32 partial tile to
    * split_part[z][M][N]; the LAST block to finish a tile (split_ticket, self-resetting) adds the partials in z order -
@@ -180,6 +181,7 @@ typedef struct {
 } mds_pw_fwd_args;
 int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream);
 int mds_pw_fwd_split(long M, int K, int N, int dtype);   /* recommended split-K factor (1 = none); <= MDS_PW_MAX_SPLIT */
+int mds_pw_fwd_wants_frag(long M, int K, int N, int dtype);   /* 1: a launch of this shape uses w_frag when it is given one */
 #define MDS_PW_MAX_SPLIT 16
 #define MDS_PW_SPLIT_TILE_ROWS 64   /* tiles of a launch = ceil(M / 64) * ceil(N / 128) */
 #define MDS_PW_SPLIT_TICKET_STRIDE 32   /* ints between two tiles' tickets: one 128-byte line each (atomics on one line serialise, ~0.13 us apiece) */
@@ -711,6 +713,11 @@ int mds_frame_luma(const mds_frame_luma_args* a, mds_stream_t stream);
 #define MDS_PACK_IO_FLIP 1 /* [O][I][taps] -> [I][taps-1-t][O] (data-gradient pack)            */
 #define MDS_PACK_STEM 2    /* [O][3][3][3] -> [O][32] zero padded                              */
 #define MDS_PACK_IO_F32 3  /* [O][I] -> [I][O], kept in fp32 whatever `dtype` (squeeze-excite w2) */
+/* MFMA-fragment order of a 1x1 filter w[N][K] (mds_pw_fwd_args.w_frag): element (n, k) at
+ *   ((k / 32 * ceil(N / 16) + n / 16) * 64 + (n % 16) + 16 * (k % 32 / 8)) * 8 + k % 8, zero beyond N or K;
+ * ceil(K / 32) * ceil(N / 16) * 512 elements.                                                                  */
+#define MDS_PACK_FRAG_OI 4 /* [O][I] -> fragment order of w[N = O][K = I] (forward)                */
+#define MDS_PACK_FRAG_IO 5 /* [O][I] -> fragment order of w[N = I][K = O] (data gradient)          */
 typedef struct {
   const float* src;
   void* dst;

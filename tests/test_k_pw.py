@@ -326,7 +326,7 @@ def test_pw_fwd_filter_resident(be, force_filter_resident, dt, M, K, N, res, sta
     (200, 704, 192, True, False, 1),     # 11 chunks, two n-tiles, residual, PLAIN post statistics
     (130, 1096, 144, False, False, 3),   # K % 64 != 0, ragged n-tile, SILU post statistics
 ])
-def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken):
+def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken, frag=False):
     code, tdt = DT[dt]
     g_ = torch.Generator().manual_seed(M + 3 * K + post)
     rpg = 41
@@ -344,9 +344,13 @@ def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken):
         mask2 = (torch.rand(groups, generator=g_) < 0.6).float() / 0.6
         bn2 = _bn_setup(be, ys, gamma2, beta2)
         kw["post"] = cabi.poststat(post, be.t(ys), bn2, st, be.t(mask2), rpg)
+    if frag:
+        kw["w_frag"] = _frag_pack(be, w, io=True)
     be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=be.t(x), w=be.t(w), y=out, pro=cabi.pro(0),
                                 residual=be.t(r) if res else None, stats=st if stats else None, **kw))
     be.sync()
+    if frag and post:
+        assert int((st.abs().sum((1, 2)) > 0).sum()) <= -(-M // 64), "the K-streaming kernel was not taken"
     v = x.float() @ w.float().t() + (r.float() if res else 0.0)
     if check_taken and (stats or post) and M > 640:   # this kernel adds into 8 + 1 statistic slots (8 blocks per n-tile), the general one into M/64 + 1
         assert int((st.abs().sum((1, 2)) > 0).sum()) <= 9, "the filter-resident kernel was not taken"
@@ -369,29 +373,58 @@ def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken):
             assert_close(s[1], (v * v).sum(0), dt, scale=M ** 0.5, msg="sumsq")
 
 
+def _frag_pack(be, w, io=False):
+    """the fragment-major bf16 copy of a 1x1 filter through mds_pack_weights (w: [N][K]; io: packed from its transpose, as the
+    data-gradient launches do from the [K][N] parameter)"""
+    N, K = w.shape
+    src = be.t(w.float().t() if io else w.float())
+    dst = torch.empty(-(-K // 32) * -(-N // 16) * 512, dtype=torch.bfloat16, device=be.device)
+    Job = cabi.STRUCTS["mds_pack_job"]
+    job = Job()
+    job.src, job.dst = src.data_ptr(), dst.data_ptr()
+    job.kind = cabi.MDS_PACK_FRAG_IO if io else cabi.MDS_PACK_FRAG_OI
+    job.O, job.I, job.taps = (K, N, 1) if io else (N, K, 1)
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(be.device)
+    be.lib.check(be.lib.fn["pack_weights"](tab.data_ptr(), 1, dst.numel(), cabi.MDS_BF16, be.stream()), "pack_weights")
+    be.sync()
+    return dst
+
+
+def test_frag_pack_layout(be):
+    """MDS_PACK_FRAG_OI / _IO against the index formula of include/mds.h, with N and K padding"""
+    g = torch.Generator().manual_seed(5)
+    N, K = 40, 72
+    w = torch.randn(N, K, generator=g).to(torch.bfloat16)
+    NFT, KST = -(-N // 16), -(-K // 32)
+    want = torch.zeros(KST * NFT * 512)
+    n, k = torch.meshgrid(torch.arange(N), torch.arange(K), indexing="ij")
+    idx = ((k // 32 * NFT + n // 16) * 64 + (n % 16) + 16 * (k % 32 // 8)) * 8 + k % 8
+    want[idx.flatten()] = w.float().flatten()
+    for io in (False, True):
+        assert torch.equal(_frag_pack(be, w, io).float().cpu(), want), io
+
+
 @pytest.fixture
 def force_kstream(be):
     be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK, 2), "dev_set")
     yield
-    for k in (cabi.MDS_KNOB_PWK, cabi.MDS_KNOB_PWK_DX, cabi.MDS_KNOB_PWK_DW):
-        be.lib.fn["dev_set"](k, 0)
+    be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK, 0)
 
 
-@pytest.mark.parametrize("M,K,N,mode,stats,dx,dw", [
-    (300, 64, 192, 0, True, 0, 0),       # two stages only: the rings are longer than the stream
-    (333, 1152, 192, 3, True, 0, 0),     # the stage-5 projection: BN + SiLU + gate, 36 stages, ragged last row tile, a gate boundary inside a tile
-    (200, 672, 112, 3, True, 6, 2),      # 128-column tile with 16 padding columns, deep x ring / shallow filter ring
-    (260, 384, 96, 3, True, 2, 5),       # 96-column tile of 128 rows (two row blocks per wave column), minimum x distance
-    (150, 576, 192, 4, False, 3, 3),     # gate only, no statistics
-    (140, 192, 176, 2, True, 0, 0),      # BN + SiLU, N not a multiple of 48
-    (130, 128, 80, 1, True, 0, 0),       # affine prologue, 96-column tile with a padding fragment
-    (1000, 256, 128, 0, True, 10, 10),   # rings at their maximum length
+@pytest.mark.parametrize("M,K,N,mode,stats", [
+    (300, 64, 192, 0, True),       # one stage only: the rings are longer than the stream
+    (333, 1152, 192, 3, True),     # the stage-5 projection: BN + SiLU + gate, 18 stages, ragged last row tile, a gate boundary inside a tile
+    (200, 672, 112, 3, True),      # 128-column tile with 16 padding columns; K % 64 == 32: a half stage at the end
+    (260, 384, 96, 3, True),       # 96-column tile of 128 rows (two row blocks per wave column, two transform passes)
+    (150, 576, 192, 4, False),     # gate only, no statistics
+    (140, 192, 176, 2, True),      # BN + SiLU, N not a multiple of 48
+    (130, 160, 80, 1, True),       # affine prologue, 96-column tile with a padding fragment, half stage
+    (1000, 256, 128, 0, True),
+    (70, 96, 128, 2, True),        # a half stage right after the first
 ])
-def test_pw_fwd_kstream(be, force_kstream, M, K, N, mode, stats, dx, dw):
+def test_pw_fwd_kstream(be, force_kstream, M, K, N, mode, stats):
     """k_pwk.hip: the K-streaming kernel (both operands as LDS-DMA rings with counted waits, prologue one stage ahead through
     scalar tables, row-major epilogue).  On the simulator this checks addressing and slot arithmetic; the waits on MI355X."""
-    be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK_DX, dx)
-    be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK_DW, dw)
     dt = "bf16"
     code, tdt = DT[dt]
     g = torch.Generator().manual_seed(M * 7 + K + N)
@@ -403,7 +436,8 @@ def test_pw_fwd_kstream(be, force_kstream, M, K, N, mode, stats, dx, dw):
     y = torch.full((M, N), float("nan")).to(tdt).to(be.device)
     st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device, dtype=torch.float64)
     be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=be.t(x), w=be.t(w), y=y,
-                                pro=cabi.pro(mode, scale, shift, gate, rpg), residual=None, stats=st if stats else None))
+                                pro=cabi.pro(mode, scale, shift, gate, rpg), residual=None, stats=st if stats else None,
+                                w_frag=_frag_pack(be, w, io=(M % 2 == 1))))
     be.sync()
     a = _apply_pro(x.float(), mode, scale, shift, gate, rpg).to(tdt).float()
     ref = a @ w.float().t()
@@ -422,9 +456,10 @@ def test_pw_fwd_kstream(be, force_kstream, M, K, N, mode, stats, dx, dw):
     (260, 384, 96, False, 3),      # SILU (g stored), 128-row tiles
     (150, 576, 192, True, 0),      # residual only
     (140, 192, 144, False, 1),     # N = 144: 18 octets per row
+    (300, 96, 80, True, 2),        # one and a half stages
 ])
 def test_pw_fwd_kstream_data_gradient(be, force_kstream, M, K, N, res, post):
-    _run_pw_plain(be, "bf16", M, K, N, res, False, post, False)
+    _run_pw_plain(be, "bf16", M, K, N, res, False, post, False, frag=True)
 
 
 # ------------------------------------------------------------------------------------------------ linear form of BatchNorm backward

@@ -12,6 +12,20 @@ import torch
 from mds import cabi, geometry as geo
 
 dev = torch.device("cuda:0")
+
+
+def frag_pack(lib, w):
+    """fragment-major bf16 copy of a [N][K] filter (MDS_PACK_FRAG_OI) through mds_pack_weights"""
+    N, K = w.shape
+    src = w.float().contiguous()
+    dst = torch.empty(-(-K // 32) * -(-N // 16) * 512, dtype=torch.bfloat16, device=w.device)
+    job = cabi.STRUCTS["mds_pack_job"]()
+    job.src, job.dst, job.kind, job.O, job.I, job.taps = src.data_ptr(), dst.data_ptr(), cabi.MDS_PACK_FRAG_OI, N, K, 1
+    tab = torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8).to(w.device)
+    lib.check(lib.fn["pack_weights"](tab.data_ptr(), 1, dst.numel(), cabi.MDS_BF16, torch.cuda.current_stream().cuda_stream), "pack_weights")
+    torch.cuda.synchronize()
+    return dst
+
 lib = cabi.load()
 BF = torch.bfloat16
 SLOTS = cabi.MDS_STAT_SLOTS
@@ -98,7 +112,6 @@ KH_SHAPES = [  # M, K, N, pro, tag: the K-streaming class (projections forward =
 def bench_pwk():
     """old general kernel (knob 18 = 1) against the K-streaming kernel at several prefetch distances; forward (BN + SiLU +
     gate prologue, statistics) and data-gradient form (residual + MASK post statistics)"""
-    combos = [(int(a), int(b)) for a, b in (c.split(":") for c in os.environ.get("KB_PWK", "0:0,2:2,4:3,6:3,8:2,10:3").split(","))]
     for (M, K, N, mode, tag) in KH_SHAPES:
         x = rnd(M, K); w = rnd(N, K); y = torch.empty(M, N, device=dev, dtype=BF)
         sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
@@ -106,22 +119,17 @@ def bench_pwk():
         gate = torch.rand(20, K, device=dev)
         st = torch.zeros(SLOTS, 2, N, device=dev, dtype=torch.float64)
         nbytes, flops = (M * K + M * N + N * K) * 2, 2 * M * K * N
-        fwd = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=cabi.pro(mode, sc, sh, gate, rpg), residual=None, stats=st)
+        wfr = frag_pack(lib, w)
+        fwd = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=cabi.pro(mode, sc, sh, gate, rpg), residual=None, stats=st, w_frag=wfr)
         ys = rnd(M, N); res = rnd(M, N); bn = torch.rand(4, N, device=dev) + 0.5; mask = torch.ones(20, device=dev)
         dg = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=cabi.pro(0), residual=res, stats=None,
-                       post=cabi.poststat(2, ys, bn, st, mask, rpg))
+                       post=cabi.poststat(2, ys, bn, st, mask, rpg), w_frag=wfr)
         for name, a, nb in (("fwd", fwd, nbytes), ("dgrad", dg, nbytes + 2 * M * N * 2)):
             lib.fn["dev_set"](18, 1)
             timeit(f"{name:5s} {tag} general", lambda: lib.call("pw_fwd", a, stream()), nb, flops)
             lib.fn["dev_set"](18, 2)
-            for (dx, dw) in combos:
-                lib.fn["dev_set"](19, dx); lib.fn["dev_set"](20, dw)
-                try:
-                    timeit(f"{name:5s} {tag} kstream dx={dx} dw={dw}", lambda: lib.call("pw_fwd", a, stream()), nb, flops)
-                except Exception as e:      # LDS budget exceeded for this combination
-                    print(f"{name:5s} {tag} kstream dx={dx} dw={dw}: {str(e)[:80]}")
-            for k in (18, 19, 20):
-                lib.fn["dev_set"](k, 0)
+            timeit(f"{name:5s} {tag} kstream", lambda: lib.call("pw_fwd", a, stream()), nb, flops)
+            lib.fn["dev_set"](18, 0)
 
 
 CONV_SHAPES = [(20, 368, 640, 32, 16, 1, 2, "b0.0 32->16"), (20, 368, 640, 16, 64, 2, 2, "b1.0 16->64 s2"),
