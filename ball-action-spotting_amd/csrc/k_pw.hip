@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT |
 }
 
 int pw_fwd_wres_try(const mds_pw_fwd_args* a, mds_stream_t stream);   // k_pwr.hip: short-K wide-N layers; 1 = not taken
-int pw_fwd_k_try(const mds_pw_fwd_args* a, mds_stream_t stream);      // k_pwk.hip: K-streaming narrow-N layers (bf16); 1 = not taken
+int pw_fwd_k_try(const mds_pw_fwd_args* a, mds_stream_t stream);      // k_pwk8.hip: K-streaming narrow-N layers (bf16); 1 = not taken
 
 extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_fwd: bad dims");

@@ -105,7 +105,7 @@ MDS_DEV float wave_sum(float v) {
          (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48)));
 }
 
-// ------------------------------------------------------------------ direct-to-LDS pipeline (k_pwk.hip)
+// ------------------------------------------------------------------ direct-to-LDS pipeline (k_pwk8.hip)
 // A K-streaming GEMM keeps several stages of operands in flight as LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
 // instruction, destination = wave-uniform LDS address + 16 * lane, no VGPRs).  hipcc drains such loads with s_waitcnt
 // vmcnt(0) in front of every LDS access it can see and in front of __syncthreads(); so inside the pipelined loop every LDS

@@ -375,9 +375,9 @@ class Plan:
         """epi_mode (inference plans only): the output is stored as act(bn(y)) (+ residual), mds_epi_t"""
         y = self.act(M, N_)
         w = wt if wt is not None else self.pack(wparam, cabi.MDS_PACK_OI, N_, K, 1)
-        # the K-heavy narrow-N launches read their filter in MFMA-fragment order, straight into registers (k_pwk.hip)
+        # the K-heavy narrow-N launches read their filter in MFMA-fragment order, straight into registers (k_pwk8.hip)
         wfrag = (self.pack(wparam, cabi.MDS_PACK_FRAG_OI, N_, K, 1)
-                 if wt is None and epi_mode is None and self.lib.fn["pw_fwd_wants_frag"](int(M), int(K), int(N_), int(self.code)) else None)
+                 if wt is None and epi_mode is None and self.lib.fn["pw_fwd_wants_frag"](int(M), int(K), int(N_), int(self.code), 0) else None)
         if epi_mode is not None:
             assert self.eval_epilogues and stats_bn is not None
             stats_bn.finalize(self, seg)      # eval table
@@ -449,7 +449,7 @@ class Plan:
         extra = {}
         if head is not None:
             extra["post"] = head["bn"].post(head)
-        if self.lib.fn["pw_fwd_wants_frag"](int(M), int(N_), int(K), int(self.code)):
+        if self.lib.fn["pw_fwd_wants_frag"](int(M), int(N_), int(K), int(self.code), 1):
             extra["w_frag"] = self.pack(wparam, cabi.MDS_PACK_FRAG_IO, N_, K, 1)
         self.op(seg, "pw_fwd", dtype=self.code, M=M, K=N_, N=K, x=dy, w=wt, y=dx, pro=dict(mode=0), residual=residual, stats=None, **extra)
         return Grad(dx, head["bn"] if head is not None else None)

@@ -195,8 +195,11 @@ def trace_child(extra_args, steps=8, timeout=300):
         files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
         if not files:
             return None
-        if os.environ.get("MDS_KEEP_TRACE_STATS"):      # developer: keep the csv (copied to profiles/ by hand)
-            shutil.copy(files[0], os.path.join(ROOT, os.environ["MDS_KEEP_TRACE_STATS"]))     # (relative paths: from the repo root)
+        if os.environ.get("MDS_KEEP_TRACE_STATS"):      # developer: keep the csv.  The variable is a PREFIX (relative: from the repo
+            # root); the traced config names the file, so the child runs of configs 4 / 5 cannot overwrite the training step's
+            cfg = extra_args[extra_args.index("--config") + 1] if "--config" in extra_args else "train"
+            tag = {"train": "bench", "predict": "predict_fbf"}.get(cfg, cfg)
+            shutil.copy(files[0], os.path.join(ROOT, f'{os.environ["MDS_KEEP_TRACE_STATS"]}_{tag}_kernel_stats.csv'))
         out = {}
         for r in csv.DictReader(open(files[0])):
             fam = kernel_family(r["Name"])

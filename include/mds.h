@@ -63,8 +63,9 @@ const char* mds_last_error(void);
 #define MDS_KNOB_DW2_BLOCKS 15     /* block target of the 3x3 stride-1 strip rule (0 = default 640) */
 #define MDS_KNOB_REDUCE_BLOCKS 16  /* block cap of mds_bn_bwd_reduce (0 = default) */
 #define MDS_KNOB_PW_DEEP 17        /* 1: the fp32 inference launches of mds_pw_fwd keep ONE K chunk in flight (A/B; default: two) */
-#define MDS_KNOB_PWK 18            /* K-streaming 1x1 GEMM (k_pwk.hip): 0 = rule, 1 = never (A/B), 2 = whenever the shape is legal (tests) */
-#define MDS_KNOB_COUNT 19
+#define MDS_KNOB_PWK 18            /* K-streaming 1x1 GEMM (k_pwk8.hip): 0 = rule (forward launches), 1 = never, 2 = every legal shape (tests), 3 = rule + data gradients, 4 = data gradients only */
+#define MDS_KNOB_PWK_BM 19         /* rows per tile of the K-streaming kernel: 0 = rule, 64 / 80 / 96 / 128 (A/B) */
+#define MDS_KNOB_COUNT 20
 int mds_dev_set(int knob, int value);
 /* Completion event of the NEXT launches of the calling thread (a hipEvent_t as void*; NULL disarms).  While armed, every kernel
  * this thread launches through the library is issued with the event as its STOP event (hipExtLaunchKernelGGL), i.e. the event is
@@ -181,7 +182,7 @@ typedef struct {
 } mds_pw_fwd_args;
 int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream);
 int mds_pw_fwd_split(long M, int K, int N, int dtype);   /* recommended split-K factor (1 = none); <= MDS_PW_MAX_SPLIT */
-int mds_pw_fwd_wants_frag(long M, int K, int N, int dtype);   /* 1: a launch of this shape uses w_frag when it is given one */
+int mds_pw_fwd_wants_frag(long M, int K, int N, int dtype, int data_gradient);   /* 1: a launch of this shape (forward / data-gradient form) uses w_frag when it is given one */
 #define MDS_PW_MAX_SPLIT 16
 #define MDS_PW_SPLIT_TILE_ROWS 64   /* tiles of a launch = ceil(M / 64) * ceil(N / 128) */
 #define MDS_PW_SPLIT_TICKET_STRIDE 32   /* ints between two tiles' tickets: one 128-byte line each (atomics on one line serialise, ~0.13 us apiece) */

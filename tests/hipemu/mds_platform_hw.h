@@ -79,7 +79,7 @@ MDS_DEV float wave_sum(float v) {
   return v;
 }
 
-// direct-to-LDS pipeline touch-points (k_pwk.hip): the simulator copies at issue time and the waits are no-ops, so only the
+// direct-to-LDS pipeline touch-points (k_pwk8.hip): the simulator copies at issue time and the waits are no-ops, so only the
 // addressing / slot arithmetic is exercised here - the counted waits themselves are checked on the MI355X
 typedef uint32_t lds_t;
 MDS_DEV lds_t lds_addr_of(const void* p) { return (lds_t)((const char*)p - hipemu::dyn_smem()); }

@@ -423,8 +423,12 @@ def force_kstream(be):
     (70, 96, 128, 2, True),        # a half stage right after the first
 ])
 def test_pw_fwd_kstream(be, force_kstream, M, K, N, mode, stats):
-    """k_pwk.hip: the K-streaming kernel (both operands as LDS-DMA rings with counted waits, prologue one stage ahead through
-    scalar tables, row-major epilogue).  On the simulator this checks addressing and slot arithmetic; the waits on MI355X."""
+    """k_pwk8.hip: the K-streaming kernel (x as an LDS-DMA ring with counted waits, prologue two stages ahead through scalar
+    tables, row-major epilogue).  On the simulator this checks addressing and slot arithmetic; the waits on MI355X."""
+    _kstream_case(be, M, K, N, mode, stats)
+
+
+def _kstream_case(be, M, K, N, mode, stats):
     dt = "bf16"
     code, tdt = DT[dt]
     g = torch.Generator().manual_seed(M * 7 + K + N)
@@ -448,6 +452,23 @@ def test_pw_fwd_kstream(be, force_kstream, M, K, N, mode, stats):
         s = st.sum(0).cpu()
         assert_close(s[0], ref.sum(0), dt, scale=M ** 0.5, msg="sum")
         assert_close(s[1], (ref * ref).sum(0), dt, scale=M ** 0.5, msg="sumsq")
+
+
+@pytest.mark.parametrize("bm", [80, 96, 128])
+@pytest.mark.parametrize("M,K,N,mode", [
+    (333, 1152, 192, 3),           # rows_per_group 150: gate boundaries in the first and in the second 64-row transform pass
+    (290, 672, 112, 3),            # 128-column tile, half stage
+    (200, 576, 192, 0),            # no prologue: the producers only stream
+    (170, 96, 128, 2),
+])
+def test_pw_fwd_kstream_tile_rows(be, force_kstream, bm, M, K, N, mode):
+    """k_pwk8.hip: the other row counts of a tile (80 / 96 / 128: three or four DMA blocks per producer wave, a partial second
+    transform pass, 5 / 6 / 8 row fragments per consumer)"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK_BM, bm), "dev_set")
+    try:
+        _kstream_case(be, M, K, N, mode, True)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK_BM, 0)
 
 
 @pytest.mark.parametrize("M,K,N,res,post", [

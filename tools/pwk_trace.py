@@ -24,13 +24,12 @@ def frag_pack(lib, w):
 
 BF = torch.bfloat16
 def rnd(*s): return torch.randn(*s, device=dev).to(BF)
-PH = ["wait_vm+lgkm", "barrier", "issue", "transform", "frag reads", "mfma issue", "(next)"]
-for (M, K, N, mode, tag, dx, dw) in [(18400, 1152, 192, 3, "fwd 1152->192", 4, 3), (18400, 1152, 192, 0, "dgrad-like 1152->192 (no prologue)", 4, 3),
-                                     (73600, 672, 112, 3, "fwd 672->112", 2, 2)]:
+for (M, K, N, mode, tag) in [(18400, 1152, 192, 3, "fwd 1152->192"), (18400, 1152, 192, 0, "no prologue 1152->192"),
+                             (73600, 672, 112, 3, "fwd 672->112"), (73600, 672, 112, 0, "no prologue 672->112")]:
     x = rnd(M, K); w = rnd(N, K); y = torch.empty(M, N, device=dev, dtype=BF)
     sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
     gate = torch.rand(20, K, device=dev); st = torch.zeros(32, 2, N, device=dev, dtype=torch.float64)
-    trc = torch.zeros(4096, device=dev, dtype=torch.int64)
+    trc = torch.zeros(8192, device=dev, dtype=torch.int64)
     lib.fn["dev_set"](18, 2)
     a = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=cabi.pro(mode, sc, sh, gate, M // 20), residual=None, stats=st,
                   split_part=trc.view(torch.float32), w_frag=frag_pack(lib, w))
@@ -38,12 +37,18 @@ for (M, K, N, mode, tag, dx, dw) in [(18400, 1152, 192, 3, "fwd 1152->192", 4, 3
         lib.call("pw_fwd", a, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     S = (K + 63) // 64
-    t = trc[: (S + 1) * 32].view(S + 1, 4, 8).cpu().double()
-    print(f"== {tag} dx={dx} dw={dw}: block total {(t[S, :, 0] - t[0, :, 0]).mean():.0f} cycles for {S} stages = {(t[S, :, 0] - t[0, :, 0]).mean() / S:.0f} per stage")
-    lo, hi = 2, S - 2
+    NEED = 2 if mode else 1
+    T = S + NEED
+    t = trc[: (T + 1) * 64].view(T + 1, 8, 8).cpu().double()
+    t0 = t[0, 4, 0]
+    print(f"== {tag}: first producer step -> end of the K loop {(t[T, :4, 0].max() - t0):.0f} cycles, {S} stages = {(t[T, :4, 0].max() - t0) / S:.0f} per stage; "
+          f"loop end -> trace dump {(t[T + 0, 4, 0] - t0):.0f}")
+    lo, hi = NEED + 3, T - 3
+    for wv in range(4, 8):
+        seg = [(t[lo:hi, wv, ph + 1] - t[lo:hi, wv, ph]).mean().item() for ph in range(4)]
+        seg.append((t[lo + 1:hi + 1, wv, 0] - t[lo:hi, wv, 4]).mean().item())
+        print(f"  producer {wv - 4}: " + "  ".join(f"{n} {v:6.0f}" for n, v in zip(["wait_vm", "barrier", "issue", "transform", "loop"], seg)))
     for wv in range(4):
-        seg = []
-        for ph in range(6):
-            seg.append((t[lo:hi, wv, ph + 1] - t[lo:hi, wv, ph]).mean().item())
-        seg.append((t[lo + 1:hi + 1, wv, 0] - t[lo:hi, wv, 6]).mean().item())
-        print(f"  wave {wv}: " + "  ".join(f"{n} {v:6.0f}" for n, v in zip(["wait", "barrier", "issue", "reads+Wwait", "mfma", "transform", "loop"], seg)))
+        seg = [(t[lo:hi, wv, ph + 1] - t[lo:hi, wv, ph]).mean().item() for ph in range(5)]
+        seg.append((t[lo + 1:hi + 1, wv, 0] - t[lo:hi, wv, 5]).mean().item())
+        print(f"  consumer {wv}: " + "  ".join(f"{n} {v:6.0f}" for n, v in zip(["wait0", "mfma0", "barrier", "wait1", "mfma1", "loop"], seg)))
