@@ -71,8 +71,8 @@ MDS_DEV void block_reduce_rows(float (&acc)[NV][8], const RowMap& m, float* red)
 // one atomic instruction of a wave then touches 64 different 64-byte segments.  tools/probes/reduce_probe.hip: a 780-block
 // column reduction over 99 MB takes 44 us with 8 fp64 atomics per thread issued that way, 19.5 us with one per lane and
 // channel, 17.5 us without any epilogue.)  `red`: LDS of >= 256*8*NV floats.  ch is relative to the slice (rowmap().cbase).
-template <int NV, typename F>
-MDS_DEV void block_reduce_channels(const float (&acc)[NV][8], const RowMap& m, float* red, F&& emit) {
+template <int NV, typename A, typename F>
+MDS_DEV void block_reduce_channels(const A (&acc)[NV][8], const RowMap& m, A* red, F&& emit) {
   const int W = m.cpr * 8;
   __syncthreads();
   if (m.valid) {
@@ -84,7 +84,7 @@ MDS_DEV void block_reduce_channels(const float (&acc)[NV][8], const RowMap& m, f
   __syncthreads();
   for (int e = threadIdx.x; e < NV * W; e += 256) {
     const int v = e / W, ch = e - v * W;
-    float s = red[v * W + ch];
+    A s = red[v * W + ch];
     for (int r = 1; r < m.rpb; ++r) s += red[(r * NV + v) * W + ch];
     emit(v, ch, s);
   }

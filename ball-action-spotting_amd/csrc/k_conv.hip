@@ -582,7 +582,7 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
       return mds_check_launch("conv_fwd");
     }
   }
-  MDS_REQUIRE(ng == 1, "conv_fwd: tap groups are not available with MDS_CONV_OLD / a residual operand");
+  MDS_REQUIRE(ng == 1, "conv_fwd: tap groups need Cin % 32 == 0, K = 9 Cin < 1152 (the persistent kernel) and no residual operand");
   MDS_REQUIRE((long)a->IH * a->IW * a->Cin * (a->dtype == MDS_BF16 ? 2 : 4) < 4294967296L && (long)a->Cout * a->wtaps * a->Cin * 4 < 4294967296L,
               "conv_fwd: one image / the filter must stay below 4 GB (32-bit byte offsets)");
   dim3 grid(cdiv(a->B, CV_TB), cdiv(a->A, TA), a->N);

@@ -1,5 +1,6 @@
 // k_elem.hip — HBM-bound row-streaming kernels: 16-byte vector loads, per-channel parameters
 // in registers, LDS + wave reductions for the per-channel / per-group sums.
+#include <type_traits>
 #include "gemm.h"
 
 // ------------------------------------------------------------------ bn_res
@@ -197,13 +198,18 @@ extern "C" int mds_se_bwd_reduce(const mds_se_bwd_reduce_args* a, mds_stream_t s
 }
 
 // ------------------------------------------------------------------ BN backward reduce / apply
+// The fp32 instantiation (parity plans) accumulates in fp64 per thread and per block: the sums of the residual-stream BatchNorms
+// cancel to ~1e-3 of their absolute mass, and fp32 partials over a block's ~10^4 rows were the whole error of the worst batch-4
+// bias gradient (1.2 - 1.5e-3 of the float64 oracle, tests/test_fullsize_gpu.py).  bf16 plans keep fp32 partials (their inputs
+// carry 2^-9 already).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_args a) {
   MDS_CHAIN_PRIO();
-  __shared__ float red[256 * 8 * 2];
+  typedef typename std::conditional<std::is_same<T, float>::value, double, float>::type acc_t;
+  __shared__ acc_t red[256 * 8 * 2];
   const RowMap m = rowmap(a.C, gridDim.y, blockIdx.y);
   const int c0 = m.c0;
-  float acc[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+  acc_t acc[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
   if (m.valid) {
     float sc[8], sh[8], mu[8], rs[8];
     load8f(a.bn + 0 * a.C + c0, sc);
@@ -238,15 +244,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(mds_bn_bwd_reduce_ar
           eval_g_u(a.g, rr, c0, a.C, z, u, g);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            acc[0][j] += g[j];
-            acc[1][j] += g[j] * ((v[j] - mu[j]) * rs[j]);
+            acc[0][j] += (acc_t)g[j];
+            acc[1][j] += (acc_t)g[j] * (acc_t)((v[j] - mu[j]) * rs[j]);
           }
         }
       }
     }
   }
   double* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * a.C + m.cbase;     // fp64 slots (include/mds.h)
-  block_reduce_channels<2>(acc, m, red, [&](int v, int ch, float s) { atomicAdd(st + (long)v * a.C + ch, (double)s); });
+  block_reduce_channels<2>(acc, m, red, [&](int v, int ch, acc_t s) { atomicAdd(st + (long)v * a.C + ch, (double)s); });
 }
 extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M < 4294967295L, "bn_bwd_reduce: M must be below 2^32 rows");
@@ -257,6 +263,7 @@ extern "C" int mds_bn_bwd_reduce(const mds_bn_bwd_reduce_args* a, mds_stream_t s
   long nb = (a->M + rows_per_pass(a->C, ns) - 1) / rows_per_pass(a->C, ns);
   const long rcap = mds_knob(MDS_KNOB_REDUCE_BLOCKS) > 0 ? mds_knob(MDS_KNOB_REDUCE_BLOCKS) : 512;
   if (nb > rcap / ns) nb = rcap / ns;
+  if (nb < 1) nb = 1;                                     // (a developer knob below the slice count)
   MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_reduce_kernel<T>, dim3((unsigned)nb, ns), dim3(256), 0, stream, *a));
   return mds_check_launch("bn_bwd_reduce");
 }
@@ -280,6 +287,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(mds_bn_bwd_apply_args
   load8f(a.coef + 0 * a.C + c0, k0);
   load8f(a.coef + 1 * a.C + c0, k1);
   load8f(a.coef + 2 * a.C + c0, k2);
+  // fp32 plans: the three per-channel means in fp64 (mds_bn_bwd_finalize_args.coef64)
+  constexpr bool F64 = std::is_same<T, float>::value;
+  double d1[8], d2[8], dm[8];
+  const bool use64 = F64 && a.coef64 != nullptr;
+  if (use64) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { d1[j] = a.coef64[0 * a.C + c0 + j]; d2[j] = a.coef64[1 * a.C + c0 + j]; dm[j] = a.coef64[2 * a.C + c0 + j]; }
+  }
   const T* y = (const T*)a.y;
   T* dy = (T*)a.dy;
   // two rolling row slots (see se_pool_kernel): the next rows of both operands are requested before this row's arithmetic
@@ -306,8 +321,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(mds_bn_bwd_apply_args
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[j] = v[j] * sc[j] + sh[j];
         eval_g_u(a.g, rr, c0, a.C, z, u, g);
+        if (use64) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = k0[j] * (g[j] - k1[j] - (v[j] - mu[j]) * rs[j] * k2[j]);
+          for (int j = 0; j < 8; ++j) g[j] = (float)((double)k0[j] * (((double)g[j] - d1[j]) - ((double)v[j] - dm[j]) * (double)rs[j] * d2[j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[j] = k0[j] * (g[j] - k1[j] - (v[j] - mu[j]) * rs[j] * k2[j]);
+        }
         store8(dy + rr * a.C + c0, g);
       }
     }
@@ -321,6 +341,7 @@ extern "C" int mds_bn_bwd_apply(const mds_bn_bwd_apply_args* a, mds_stream_t str
   long nb = (a->M + rows_per_pass(a->C, ns) - 1) / rows_per_pass(a->C, ns);
   const long cap = (mds_knob(MDS_KNOB_STREAM_BLOCKS) ? mds_knob(MDS_KNOB_STREAM_BLOCKS) : 2048) / ns;
   if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
   MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(bn_bwd_apply_kernel<T>, dim3((unsigned)nb, ns), dim3(256), 0, stream, *a));
   return mds_check_launch("bn_bwd_apply");
 }

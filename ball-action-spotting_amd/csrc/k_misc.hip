@@ -24,7 +24,15 @@ int mds_check_launch(const char* what) {
 static std::atomic<int> g_knob[MDS_KNOB_COUNT];
 int mds_knob(int id) { return id >= 0 && id < MDS_KNOB_COUNT ? g_knob[id].load(std::memory_order_relaxed) : 0; }
 thread_local void* mds_tl_stop_event = nullptr;   // read by MDS_LAUNCH (mds_platform_hw.h)
-extern "C" int mds_launch_event(void* event) { mds_tl_stop_event = event; return 0; }
+thread_local int mds_tl_stop_uses = 0;
+// -> the number of launches that were issued with the PREVIOUSLY armed event (0: the armed op launched nothing, the event still
+// names an older kernel and must not be waited on)
+extern "C" int mds_launch_event(void* event) {
+  const int used = mds_tl_stop_uses;
+  mds_tl_stop_event = event;
+  mds_tl_stop_uses = 0;
+  return used;
+}
 extern "C" int mds_dev_set(int knob, int value) {
   MDS_REQUIRE(knob >= 0 && knob < MDS_KNOB_COUNT, "mds_dev_set: unknown knob %d", knob);
   g_knob[knob].store(value, std::memory_order_relaxed);
@@ -91,7 +99,7 @@ __global__ void pack_kernel(const mds_pack_job* jobs, int njobs) {
     }
     return;
   }
-  if (jb.kind == MDS_PACK_OI && taps == 1 && (total & 3) == 0) {
+  if (jb.kind == MDS_PACK_OI && taps == 1 && (total & 3) == 0 && (((uintptr_t)jb.src | (uintptr_t)dst) & 15) == 0) {   // (a parameter that is a view at an odd offset takes the scalar path)
     // 1x1 filters (3/4 of the parameters): the packed order IS the parameter's order - a vectorised cast, no index arithmetic
     for (int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += gridDim.x * blockDim.x * 4) {
       float v[4];
@@ -225,6 +233,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mds_bn_bwd_finaliz
     if (a.dgamma) dg = a.dgamma[c];
     if (a.dbeta) db = a.dbeta[c];
   }
+  double fmean = 0.0;                                   // the batch mean in fp64 (coef64), from the forward pass's own sums
+  if (a.coef64 && a.fwd_stats && a.batch_stats) {
+    fin_slot_sums(a.fwd_stats, a.C, c, sg, red, cl);
+    __syncthreads();
+    if (owner) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fmean += red[0][k][cl];
+      fmean /= (double)a.count;
+    }
+    __syncthreads();
+  } else if (owner) fmean = (double)mean;
   fin_slot_sums(a.stats, a.C, c, sg, red, cl);
   __syncthreads();
   if (!owner) return;
@@ -238,6 +257,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(mds_bn_bwd_finaliz
   const float k0 = gam * rstd, k1 = a.batch_stats ? (float)sg_ * inv : 0.0f, k2 = a.batch_stats ? (float)sgx * inv : 0.0f;
   a.coef[1 * a.C + c] = k1;
   a.coef[2 * a.C + c] = k2;
+  if (a.coef64) {
+    const double invd = 1.0 / (double)a.count;
+    a.coef64[0 * a.C + c] = a.batch_stats ? sg_ * invd : 0.0;
+    a.coef64[1 * a.C + c] = a.batch_stats ? sgx * invd : 0.0;
+    a.coef64[2 * a.C + c] = fmean;
+  }
   if (a.lin) {   // dy = k0*(g - k1 - (y - mean)*rstd*k2) = A*g + B*y + D
     a.lin[0 * a.C + c] = k0;
     a.lin[1 * a.C + c] = -k0 * k2 * rstd;
@@ -347,6 +372,7 @@ __global__ __launch_bounds__(256) void se_fc_fwd_kernel(mds_se_fc_fwd_args a) {
 extern "C" int mds_se_fc_fwd(const mds_se_fc_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->C % 4 == 0 && a->R > 0 && a->R <= SE_RMAX, "se_fc_fwd: bad dims (C % 4 == 0, R <= %d)", SE_RMAX);
   MDS_REQUIRE(a->pooled && a->w1 && a->b1 && a->w2 && a->b2 && a->hidden && a->gate, "se_fc_fwd: null pointer");
+  MDS_REQUIRE((((uintptr_t)a->pooled | (uintptr_t)a->w1 | (uintptr_t)a->w2t) & 15) == 0, "se_fc_fwd: pooled / w1 / w2t must be 16-byte aligned (16-byte vector loads)");
   SE_DISPATCH_RB(a->R, MDS_LAUNCH(se_fc_fwd_kernel<RB>, dim3(a->groups, cdiv(a->C, SE_CCH)), dim3(256), 0, stream, *a));
   return mds_check_launch("se_fc_fwd");
 }
@@ -461,6 +487,8 @@ static int se_fc_bwd_check(const mds_se_fc_bwd_args* a) {
   MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= 2048 && a->R > 0 && a->R <= SE_RMAX && a->rows_per_group > 0, "se_fc_bwd: bad dims (R <= %d, C % 4 == 0, C <= 2048)", SE_RMAX);
   MDS_REQUIRE(a->scratch && a->dgate && a->gate && a->hidden && a->pooled && a->dpooled, "se_fc_bwd: null pointer");
   MDS_REQUIRE(!(a->bnsums && a->bn_stats) || a->bn_nblk > 0, "se_fc_bwd: bn_nblk");
+  MDS_REQUIRE((((uintptr_t)a->pooled | (uintptr_t)a->w1 | (uintptr_t)a->w2 | (uintptr_t)a->w2t | (uintptr_t)a->dgate | (uintptr_t)a->gate) & 15) == 0,
+              "se_fc_bwd: pooled / w1 / w2 / w2t / dgate / gate must be 16-byte aligned (16-byte vector loads)");
   return 0;
 }
 extern "C" int mds_se_fc_bwd_data(const mds_se_fc_bwd_args* a, mds_stream_t stream) {

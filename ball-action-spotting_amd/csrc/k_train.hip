@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(mds_adamw_args a) {
   if (a.step_in) {                                          // device step counter: a skipped step does not count
     const float t = *a.step_in + (skip ? 0.f : 1.f);
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.step_out = t;
-    bias1 = 1.0f - powf(a.beta1, t); bias2 = 1.0f - powf(a.beta2, t);
+    // in double, as torch.optim.AdamW's host arithmetic: 1 - powf(0.999f, 1) is 0.00099998713, not 0.001 (1.3e-5 off at t = 1)
+    const double b1 = a.beta1_d != 0.0 ? a.beta1_d : (double)a.beta1, b2 = a.beta2_d != 0.0 ? a.beta2_d : (double)a.beta2;
+    bias1 = (float)(1.0 - pow(b1, (double)t)); bias2 = (float)(1.0 - pow(b2, (double)t));
   }
   if (skip) return;
   const int ti = a.chunks[2 * blockIdx.x], c0 = a.chunks[2 * blockIdx.x + 1];

@@ -46,6 +46,7 @@ MDS_DEV f32x4 ld_coherent4(const float* p) {
                  __builtin_bit_cast(float, (uint32_t)b), __builtin_bit_cast(float, (uint32_t)(b >> 32))};
 }
 extern thread_local void* mds_tl_stop_event;   // k_misc.hip (mds_launch_event)
+extern thread_local int mds_tl_stop_uses;      // launches issued with the armed event since it was armed
 // all of this lane's outstanding vector-memory operations (loads returned, stores acknowledged): s_waitcnt vmcnt(0)
 MDS_DEV void mds_wait_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // gfx9 encoding: vmcnt = 0, expcnt / lgkmcnt = max (no wait)
 // kernels of the DEPENDENT CHAIN raise their waves' issue priority (s_setprio): where they share a SIMD with a wave of the second
@@ -68,9 +69,10 @@ MDS_DEV void mds_wait_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // gfx9
         mds_cur_.store(mds_smem_, std::memory_order_relaxed);                                       \
       }                                                                                             \
     }                                                                                               \
-    if (mds_tl_stop_event) /* armed by mds_launch_event: the kernel's own completion signal is the event */ \
+    if (mds_tl_stop_event) { /* armed by mds_launch_event: the kernel's own completion signal is the event */ \
+      ++mds_tl_stop_uses;                                                                           \
       hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)mds_smem_, (hipStream_t)(stream), nullptr, (hipEvent_t)mds_tl_stop_event, 0, __VA_ARGS__); \
-    else                                                                                            \
+    } else                                                                                            \
       hipLaunchKernelGGL(kernel, grid, block, mds_smem_, (hipStream_t)(stream), __VA_ARGS__);      \
   } while (0)
 

@@ -69,12 +69,12 @@ def motion_kernel(ksize: int, angle: float, direction: float) -> np.ndarray:
 class TrainAugmentations(nn.Module):
     """``get_train_augmentations(size)`` with size = (width, height) like the reference's configs (image_size)."""
 
-    def __init__(self, size, seed: Optional[int] = None, compose_geometric: bool = True):
-        """compose_geometric=True (default): camera move, rotation, resized crop and flip are composed into ONE resampling of
-        the input - less interpolation blur and no intermediate zero borders than the reference, identical to it whenever at
-        most one of them fires (64 % of the samples at the reference's probabilities).  False: the REFERENCE ORDER - each
-        geometric stage resamples the previous stage's output as kornia's nn.Sequential does
-        (src/ball_action/augmentations.py:10-13); result-identical to the reference for every sample, up to two more passes."""
+    def __init__(self, size, seed: Optional[int] = None, compose_geometric: bool = False):
+        """compose_geometric=False (default): the REFERENCE ORDER - each geometric stage resamples the previous stage's output
+        as kornia's nn.Sequential does (src/ball_action/augmentations.py:10-13); result-identical to the reference for every
+        sample (0.46 ms per 4x15x736x1280 batch).  True: the opt-in fast path - camera move, rotation, resized crop and flip
+        composed into ONE resampling of the input (0.36 ms; less interpolation blur and no intermediate zero borders than the
+        reference, identical to it only when at most one of them fires: 64 % of the samples at the reference's probabilities)."""
         super().__init__()
         self.compose_geometric = bool(compose_geometric)
         self.width, self.height = int(size[0]), int(size[1])

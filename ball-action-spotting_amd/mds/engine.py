@@ -82,6 +82,8 @@ class BNL:
         self.bstats = pb.zero_bwd64(SLOTS * 2 * C_) if pb.need_grad else None      # fp64 slots (include/mds.h)
         self.coef = pb.f32(3 * C_) if pb.need_grad else None
         self.lin = pb.f32(3 * C_) if pb.need_grad else None     # A, B, D of dy = A*g + B*y + D (mds_dyp_t)
+        # fp32 plans: sum_g/M, sum_gx/M and the batch mean in fp64 for the apply pass (mds_bn_bwd_finalize_args.coef64)
+        self.coef64 = pb._own(3 * C_, torch.float64) if (pb.need_grad and pb.code == cabi.MDS_F32) else None
 
     scale = property(lambda s: s.buf.sub(0, s.C))
     shift = property(lambda s: s.buf.sub(s.C, s.C))
@@ -109,14 +111,16 @@ class BNL:
     def bwd_finalize(self, pb, seg, frozen=False):
         pb.op(seg, "bn_bwd_finalize", C=self.C, count=self.count, stats=self.bstats, gamma=P(self.mod.weight), bn=self.buf,
               dgamma=None if frozen else pb.grad(self.mod.weight), dbeta=None if frozen else pb.grad(self.mod.bias),
-              coef=self.coef, lin=self.lin, batch_stats=int(pb.batch_stats))
+              coef=self.coef, lin=self.lin, batch_stats=int(pb.batch_stats), fwd_stats=self.stats if self.coef64 is not None else None,
+              coef64=self.coef64)
 
     def backward(self, pb, seg, gsrc, y, dy, reduce=True, frozen=False):
         """emit reduce / finalize / apply (dy materialised); `gsrc` describes how g is derived (mds_gsrc_t)."""
         if reduce:
             self.bwd_reduce(pb, seg, gsrc, y)
         self.bwd_finalize(pb, seg, frozen)
-        pb.op(seg, "bn_bwd_apply", dtype=pb.code, M=self.count, C=self.C, g=gsrc, y=y, bn=self.buf, coef=self.coef, dy=dy)
+        pb.op(seg, "bn_bwd_apply", dtype=pb.code, M=self.count, C=self.C, g=gsrc, y=y, bn=self.buf, coef=self.coef, dy=dy,
+              coef64=self.coef64)
 
     def head(self, y, mode, mask=None, rpg=0):
         """what a producing data-gradient GEMM needs to take this layer's backward sums in its epilogue"""
@@ -209,7 +213,10 @@ class Plan:
         # BatchNorm backward that consumes it (mds_poststat_t): 22 bn_bwd_reduce launches less.  0: every reduce is its own launch.
         # (Forming dy on load inside the GEMMs - all layers / narrow layers only - and the linear form of BatchNorm backward were
         # measured slower in rounds 2 and 3 and are no longer part of the product: DESIGN 5.)
-        self.fuse_bn_bwd = os.environ.get("MDS_FUSE_BN_BWD", "1") != "0"
+        # fp32 plans (speed is not their point, the 1e-3 parity bar is): the sums of the residual-stream BatchNorms - sum g cancels
+        # to ~1e-3 of its absolute mass over 1.2 - 5.9 M rows - always go through mds_bn_bwd_reduce, whose fp32 instantiation
+        # accumulates per thread and per block in fp64 (fp32 block partials put the worst batch-4 bias at 1.2 - 1.5e-3).
+        self.fuse_bn_bwd = os.environ.get("MDS_FUSE_BN_BWD", "1") != "0" and code == cabi.MDS_BF16
         # inference plans (eval-mode BatchNorm, no gradient): producers store activated outputs (mds_epi_t)
         self.eval_epilogues = (not training) and (not need_grad) and os.environ.get("MDS_EVAL_EPI", "1") == "1"
         self.in_flight = False
@@ -924,8 +931,12 @@ class Plan:
             elif ext is not None and k + 1 < len(ops) and is_side[k + 1]:
                 armed = ext.get(seg, k)
                 self.lib.fn["launch_event"](armed)
-                rc = fn(ref, stream)
-                self.lib.fn["launch_event"](None)
+                try:
+                    rc = fn(ref, stream)
+                finally:          # the thread-local stop event never stays armed past this launch
+                    used = self.lib.fn["launch_event"](None)
+                if used == 0:     # the op took a path without a kernel launch: the event still names LAST step's kernel -
+                    armed = None  # fall back to a recorded event for the side launch that follows
             else:
                 rc = fn(ref, stream)
             if rc:

@@ -79,8 +79,15 @@ class RocDecFrameFetcher:
                          surface_stride=0, dst=out)
         stream = torch.cuda.current_stream(out.device).cuda_stream if out.is_cuda else 0
         lib.check(lib.fn["frame_luma"](C.byref(args), stream), "frame_luma")
-        self._pending.append((keep, out))       # the surface must outlive the copy
-        del self._pending[:-8]
+        # the surface must outlive the asynchronous copy: it is released only once an event recorded behind the copy has fired
+        # (a fixed "last 8" window let a 15- / 33-frame clip on a busy stream hand surfaces back to the decoder pool too early)
+        ev = None
+        if out.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(out.device))
+        self._pending.append((keep, out, ev))
+        while self._pending and (self._pending[0][2] is None or self._pending[0][2].query()) and len(self._pending) > 1:
+            self._pending.pop(0)
 
     def _produce(self, out: torch.Tensor, at: Optional[int]) -> None:
         """fill `out` with frame `at` (seek + decode) or, for at=None, with the decoder's next frame.  Contract of the reference

@@ -61,6 +61,36 @@ def broadcast_state(module: torch.nn.Module, src: int = 0, group=None):
                 off += n
 
 
+XGMI_LINK_GBS = 153.0       # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links per GPU, point-to-point)
+RING_HOP_US = 6.0           # per ring step: RCCL's own kernel hand-off on a link (latency term of a small slice)
+RCCL_CU_TAX = 0.25          # share of an all-reduce's duration its kernels take from the overlapped backward (measured for the
+                            # weight-gradient stream, which competes for CUs the same way: DESIGN 0e)
+
+
+def ring_allreduce_ms(nbytes: float, world: int) -> float:
+    """Ring all-reduce of `nbytes` over point-to-point xGMI: 2 (N - 1) steps, each moving nbytes / N over ONE link."""
+    if world <= 1:
+        return 0.0
+    steps = 2 * (world - 1)
+    return steps * (nbytes / world / (XGMI_LINK_GBS * 1e9) * 1e3 + RING_HOP_US * 1e-3)
+
+
+def predict_step_ms(local_ms: float, world: int, slice_bytes) -> dict:
+    """The stated scaling model, so that a measured N-GPU line judges itself: per-rank work is fixed (weak scaling), the
+    gradient arena goes out in `slice_bytes` slices in backward order from a communication stream; every slice but the LAST is
+    hidden behind the rest of the backward, the last one is exposed, and RCCL's kernels tax the overlapped backward by RCCL_CU_TAX
+    of their duration.  local_ms: the step without any exchange (the N = 1 time on the same device)."""
+    slice_bytes = list(slice_bytes)
+    total = ring_allreduce_ms(sum(slice_bytes), world) if slice_bytes else 0.0
+    exposed = ring_allreduce_ms(slice_bytes[-1], world) if slice_bytes else 0.0
+    hidden = max(sum(ring_allreduce_ms(b, world) for b in slice_bytes[:-1]), 0.0)
+    pred = local_ms + exposed + RCCL_CU_TAX * hidden
+    return {"predicted_ms": round(pred, 4), "predicted_exposed_ms": round(exposed, 4), "predicted_allreduce_total_ms": round(total, 4),
+            "predicted_efficiency": round(local_ms / pred, 4) if pred > 0 else None,
+            "model": f"ring all-reduce over xGMI at {XGMI_LINK_GBS:.0f} GB/s per link + {RING_HOP_US:.0f} us per ring step; last slice exposed, "
+                     f"{RCCL_CU_TAX:.2f} of the hidden slices' duration taxed on the backward"}
+
+
 class BucketedSync:
     """Gradient averaging overlapped with the backward pass.
 
@@ -74,12 +104,13 @@ class BucketedSync:
     def __init__(self, group=None, force: bool = False):
         self.group, self.force = group, force
         self.handles, self.comm, self.events = [], None, []
+        self.paused = False          # bench: steps without the exchange = the N = 1 time on this very device (local gradients only)
         self.timing = False          # bench: record an event pair around every slice's all-reduce on the communication stream
         self.last_timing = None      # [(lo, hi, microseconds)] of the last step when `timing` is on
         self.last_exposed_ms = None  # with `timing`: end of the last backward kernel -> end of the last all-reduce (what the step waits for)
 
     def active(self):
-        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
+        return (not self.paused) and dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
 
     def on_cut(self, plan, lo, hi):
         if not self.active():

@@ -247,7 +247,8 @@ class FusedAdamW(_FusedOptimizer):
         args = cabi.make("mds_adamw_args", table=cache["table"], chunks=cache["chunks"], nchunks=cache["nchunks"], gbase=base,
                          exp_avg=gs["exp_avg"], exp_avg_sq=gs["exp_avg_sq"], lr=float(group["lr"]), beta1=float(b1), beta2=float(b2),
                          eps=float(group["eps"]), weight_decay=float(group["weight_decay"]), bias1=0.0, bias2=0.0,
-                         found_inf=found_inf, grad_scale=grad_scale, step_in=gs["step_dev"][k:k + 1], step_out=gs["step_dev"][1 - k:2 - k])
+                         found_inf=found_inf, grad_scale=grad_scale, step_in=gs["step_dev"][k:k + 1], step_out=gs["step_dev"][1 - k:2 - k],
+                         beta1_d=float(b1), beta2_d=float(b2))
         lib.check(lib.fn["multi_adamw"](C.byref(args), _stream(active[0])), "multi_adamw")
 
 

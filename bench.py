@@ -136,7 +136,7 @@ def kernel_family(name):
     return fn.replace("dws_", "dw_")
 
 
-def pmc_child(counters, extra_args, timeout=120):
+def pmc_child(counters, extra_args, timeout=120, steps=2):
     """Run this script under `rocprofv3 --pmc <counters>` (counter collection only — never combined with trace
     domains) for 2 steps and return {kernel family: {counter: mean per launch, 'launches': n, 'us': mean duration}}."""
     exe = shutil.which("rocprofv3")
@@ -144,7 +144,7 @@ def pmc_child(counters, extra_args, timeout=120):
         return None
     tmp = tempfile.mkdtemp(prefix="mds_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", *counters, "-d", tmp, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
-           os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--profile-steps", "0", "--no-cpu-baseline", "--no-pmc",
+           os.path.abspath(__file__), "--steps", str(steps), "--warmup", "1", "--profile-steps", "0", "--no-cpu-baseline", "--no-pmc",
            "--no-other-configs", *extra_args]      # (the config 4 / 5 child runs inside a counter pass took it past its timeout)
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -381,6 +381,13 @@ def bench_predict(args, dev, rank, world):
                          "alg_flops_per_launch": int(avg_f), "share_of_kernel_time": round(fams[dom]["total_us"] / tot_us, 3),
                          "path": f"frame by frame (the reference's API), fp32, {fbf_fps:.0f} frames/s; durations: rocprofv3 --kernel-trace --stats child run",
                          "us_per_frame_by_family": {k: round(v["avg_us"] * cost[k][0], 1) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["total_us"])[:8]}}
+                # HBM traffic per launch of that kernel: FETCH_SIZE / WRITE_SIZE passes of the same path (separate runs, KiB units,
+                # FETCH_SIZE x2 on gfx950 - MI355X_MICROARCH.md HBM section)
+                pa = ["--config", "predict", "--predict-fbf-only"]
+                f = pmc_child(["FETCH_SIZE"], pa, timeout=400, steps=300) or pmc_child(["FETCH_SIZE"], pa, timeout=400, steps=300)
+                w = pmc_child(["WRITE_SIZE"], pa, timeout=400, steps=300) or pmc_child(["WRITE_SIZE"], pa, timeout=400, steps=300)
+                if f and w and dom in f and dom in w:
+                    kroof["traffic"] = int(f[dom]["FETCH_SIZE"] * 2048 + w[dom]["WRITE_SIZE"] * 1024)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import multidim_stacker_ref as orc
@@ -437,8 +444,12 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child runs that measure roofline.traffic and the in-step kernel durations")
+    ap.add_argument("--trace-only", action="store_true", help="with --no-pmc: still take the in-step kernel durations (rocprofv3 --kernel-trace "
+                    "child run) for the per-kernel roofline; only the counter passes are skipped (the config 4 child run)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the child runs of configs 4 and 5 (`other_configs` of the train line)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--n1-ms", type=float, default=None, help="--gpus N > 1: ms per step of an N = 1 run, for parallel.efficiency_vs_n1 "
+                    "(default: measured in the same run as steps without the exchange)")
     ap.add_argument("--chunk", type=int, default=8, help="--config predict: consecutive frames per predictor call")
     ap.add_argument("--torch-step", action="store_true", help="torch's focal loss + torch.optim.AdamW(fused=True) instead of mds.train")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
@@ -543,7 +554,25 @@ def main():
             fence()
             sync.timing = False
             sl = sync.last_timing or []
+            # the same steps WITHOUT the exchange on this very device = what an N = 1 run measures (weak scaling: per-rank work is
+            # fixed), so the line carries its own efficiency and the stated model's prediction next to the measurement
+            sync.paused = True
+            for _ in range(2):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            nloc = max(args.steps // 2, 3)
+            for _ in range(nloc):
+                step()
+            fence()
+            tl = torch.tensor([(time.perf_counter() - t0) / nloc * 1e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            local_ms = args.n1_ms if args.n1_ms else tl.item()
+            sync.paused = False
+            model_pred = parallel.predict_step_ms(local_ms, world, [(hi - lo) * 4 for lo, hi, _ in sl])
             par_info = {"rccl_ranks": world, "backend": dist.get_backend(), "devices_in_use": world,
+                        "local_step_ms_no_exchange": round(tl.item(), 4), "n1_ms_given": args.n1_ms,
+                        "efficiency_vs_n1": round(local_ms / ms_per_step, 4), **model_pred,
                         "allreduce_slices_in_backward_order":
                         [{"elems": hi - lo, "MB": round((hi - lo) * 4 / 1e6, 2), "us": us} for lo, hi, us in sl],
                         "allreduce_exposed_ms": sync.last_exposed_ms,
@@ -595,7 +624,7 @@ def main():
             roofline["whole_path"] = {"mfma_frac": round(work["flop"] * wps / world / (MFMA_PEAK_TFLOPS * 1e12), 4),
                                       "hbm_alg_frac_block_granular": round(work["bytes"] * wps / world / (HBM_PEAK_GBS * 1e9), 4),
                                       "definition": "SURVEY.md 8(d): max(F/2.5e15, B/8e12) / t_window"}
-        if world == 1 and not args.no_pmc:
+        if world == 1 and (not args.no_pmc or args.trace_only):
             extra = ["--config", args.config, "--batch", str(B), "--height", str(args.height), "--width", str(args.width),
                      "--dtype", args.dtype] + (["--torch-step"] if args.torch_step else [])
             # IN-STEP durations: the per-kernel pass above times each launch ALONE on one stream; inside the step the weight
@@ -629,7 +658,8 @@ def main():
                                      "isolated": {k: isolated.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_us", "share_of_kernel_time")},
                                      "in_step_ms_per_step": {k: round(v["total_us"] / nst / 1e3, 3) for k, v in
                                                              sorted(fams.items(), key=lambda kv: -kv[1]["total_us"])[:12]}})
-            roofline.update(pmc_for(dom, extra))
+            if not args.no_pmc:
+                roofline.update(pmc_for(dom, extra))
 
     if rank == 0 and roofline is None and work:       # no per-kernel pass (the config 4 child run): the whole-path fraction needs none
         t_window = elapsed / args.steps / B
@@ -646,7 +676,7 @@ def main():
     if rank == 0 and world == 1 and args.config == "train" and full and not args.no_other_configs:
         # BASELINE.json configs[3] and configs[4] beside the headline line (child runs of this script, 20 steps / 300 frames)
         torch.cuda.empty_cache()      # (the children are separate processes on the same 288 GB device)
-        others = {"long004": other_config("long004", ["--steps", "20", "--warmup", "5", "--cpu-seconds", "8"]),
+        others = {"long004": other_config("long004", ["--steps", "20", "--warmup", "5", "--cpu-seconds", "8", "--profile-steps", "2", "--trace-only"]),
                   "predict": other_config("predict", ["--steps", "300", "--predict-kernel-trace"])}
 
     if rank == 0:

@@ -71,7 +71,8 @@ int mds_dev_set(int knob, int value);
  * this thread launches through the library is issued with the event as its STOP event (hipExtLaunchKernelGGL), i.e. the event is
  * bound to the last such kernel's own completion signal - no marker packet on the stream.  The planner uses it to let the
  * weight-gradient stream wait for a kernel of the dependent chain: an event RECORDED on that chain costs it 4.4 us (measured,
- * tools/probes/event_cost.py; 71 of them per training step), a stop event nothing.                                            */
+ * tools/probes/event_cost.py; 71 of them per training step), a stop event nothing.  Returns the number of launches that were
+ * issued with the previously armed event (0 after an op that launched nothing: that event must not be waited on).            */
 int mds_launch_event(void* event);
 
 /* ---- output transform ("epilogue") for plans that KNOW the BatchNorm statistics before the producer runs (eval mode /
@@ -493,6 +494,10 @@ typedef struct {
   float* lin;       /* optional [3][C]: A, B, D of mds_dyp_t (dy = A*g + B*y + D)                          */
   int batch_stats;  /* 1: train-mode BN (batch statistics; the mean / xhat terms above).  0: eval-mode BN
                        (running statistics are constants): coef1 = coef2 = 0, i.e. dy = gamma*rstd*g        */
+  const double* fwd_stats; /* optional, with coef64: the forward pass's fp64 [SLOTS][2][C] sums (mean in fp64)       */
+  double* coef64;   /* optional [3][C]: sum_g/M, sum_gx/M and the batch mean in fp64, for mds_bn_bwd_apply's fp32
+                       form (fp32 plans: the fp32-rounded means are the SAME for every row, so their rounding
+                       error adds up M times in every sum over dy - the bias gradients upstream)            */
 } mds_bn_bwd_finalize_args;
 int mds_bn_bwd_finalize(const mds_bn_bwd_finalize_args* a, mds_stream_t stream);
 
@@ -506,6 +511,8 @@ typedef struct {
   const float* bn;
   const float* coef;
   void* dy;
+  const double* coef64;  /* optional (fp32 only): { sum_g/M, sum_gx/M, mean } in fp64 - the subtraction of the means is done
+                            in fp64 and rounded once per element                                              */
 } mds_bn_bwd_apply_args;
 int mds_bn_bwd_apply(const mds_bn_bwd_apply_args* a, mds_stream_t stream);
 
@@ -613,6 +620,8 @@ typedef struct {
    * torch's fused optimizers do not count a skipped step.  step_in != step_out (the host alternates two scalars).            */
   const float* step_in;
   float* step_out;
+  double beta1_d, beta2_d;       /* the betas in double: the in-kernel bias corrections are 1 - pow(beta_d, t) in double, as the host
+                                    arithmetic of torch.optim.AdamW (0 = take the fp32 betas)                                  */
 } mds_adamw_args;
 #define MDS_OPT_CHUNK 4096
 int mds_multi_adamw(const mds_adamw_args* a, mds_stream_t stream);

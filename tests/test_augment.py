@@ -103,7 +103,7 @@ def test_fused_pipeline_matches_the_single_resampling_oracle(be):
     every["camera"] = dict(every["camera"], center=[[(w - 1) / 2, (h - 1) / 2]] * 2)
     every["crop"] = (2, 1, 43, 29)
     params = [every, dict(crop=(1, 2, 44, 28), sharpness=0.8, posterize=5), dict(rotation=1.2, motion_blur=dict(ksize=11, angle=-7.0, direction=-1.0), contrast=1.15)]
-    mod = augment.TrainAugmentations((w, h))
+    mod = augment.TrainAugmentations((w, h), compose_geometric=True)
     mod._lib = be.lib if be.name == "emu" else None
     out = mod(be.t(x), params=params, noise=be.t(noise)).cpu()
     be.sync()
@@ -138,8 +138,8 @@ def test_reference_order_mode_is_result_identical_with_every_stage_firing(be):
     be.sync()
     ref = aug.apply_reference_order(x, [_oracle_params(s) for s in params], noise)
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
-    # the composed default is a different picture on these samples (that is why the switch exists) ...
-    comp = augment.TrainAugmentations((w, h))
+    # the composed (opt-in) form is a different picture on these samples (that is why the switch exists) ...
+    comp = augment.TrainAugmentations((w, h), compose_geometric=True)
     comp._lib = mod._lib
     oc = comp(be.t(x), params=params, noise=be.t(noise)).cpu()
     assert (oc[0] - ref[0]).abs().max().item() > 1e-2

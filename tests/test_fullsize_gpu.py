@@ -176,7 +176,8 @@ def test_fp32_full_window_vs_oracle_config2():
     big = sorted(gr, key=lambda n: -gr[n].norm().item())[:10]            # the ten largest gradient tensors, one by one
     gpb = {n: p.grad.float().cpu() for n, p in prod.named_parameters()}
     worst = max(((gpb[n] - gr[n]).norm() / gr[n].norm()).item() for n in big)
-    assert worst < 0.35, worst
+    print("bf16, ten largest gradient tensors: worst relative L2 error", worst)
+    assert worst < 0.32, worst      # 1.5 x the measured 0.208 (bf16 storage through 25 BatchNorm'd blocks; a mis-scaled layer is > 0.5)
 
 
 def _host_mem_available_gb():
@@ -219,15 +220,12 @@ def test_fp32_and_bf16_batch4_bench_shape_vs_oracle():
     orc.sigmoid_focal_loss(l32, tgt, alpha=-1.0, gamma=1.2).backward()
     errs32 = sorted(((_rel(p.grad, gr[n], floor), n) for n, p in ref32.named_parameters()), reverse=True)
     print("batch-4 bench shape, worst gradient errors vs float64: HIP fp32", errs[:4], "torch fp32", errs32[:4])
-    # bar: 1e-3 (north_star) for every parameter but at most two cancellation-dominated BatchNorm-bias sums (5.9 M rows cancelling
-    # to 1e-3 of their mass): those must be no worse than torch's OWN fp32 run of this step on the same parameter, and below 2e-3.
-    # Measured: 1.18e-3 (round 3) and 1.51e-3 (round 4: other launch geometry of the fp32 kernels, i.e. another grouping of the
-    # fp32 partial sums) against torch's 1.80e-3 - a realisation of fp32 rounding noise, the same on every run of one build.
-    t32 = {n: e for e, n in errs32}
-    over = [(e, n) for e, n in errs if e > 1e-3]
-    assert len(over) <= 2, errs[:6]
-    for e, n in over:
-        assert e < 2e-3 and e <= max(1.5e-3, t32[n]), (e, n, t32[n], errs32[:6])
+    # bar: 1e-3 (north_star) for EVERY parameter.  Rounds 3-4 needed an allowance for two cancellation-dominated BatchNorm-bias
+    # sums (1.2 - 1.5e-3, torch's own fp32 run: 1.8e-3).  Cause, found in round 5: the per-channel means of BatchNorm backward
+    # (sum g / M, sum g xhat / M, the batch mean) were fp32 - ONE rounding error shared by all M rows of a channel, so it adds up
+    # M times in every sum over dy (the bias gradients upstream).  The fp32 apply pass now subtracts them in fp64
+    # (mds_bn_bwd_finalize_args.coef64): measured 3.4e-4 worst.
+    assert errs[0][0] < 1e-3, (errs[:6], errs32[:6])
     for (n, b), (_, b2) in zip(ref.named_buffers(), prod.named_buffers()):
         assert _rel(b2, b, 1e-6) < 1e-3, n
     prod.zero_grad(set_to_none=True)

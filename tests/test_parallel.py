@@ -17,6 +17,23 @@ def test_shard_windows_partitions_everything():
         assert max(map(len, parts)) - min(map(len, parts)) <= 1
 
 
+def test_scaling_model_of_the_bench_line():
+    """bench.py --gpus N prints parallel.predicted_ms from this model next to the measurement"""
+    slices = [6.0e6, 6.2e6, 6.1e6, 6.4e6, 2.4e6]                # the five slices of the 27.1 MB arena, backward order
+    assert parallel.ring_allreduce_ms(27.1e6, 1) == 0.0
+    t8 = parallel.ring_allreduce_ms(27.1e6, 8)                  # 14 steps of 3.39 MB over one 153 GB/s link + 14 hops
+    assert abs(t8 - (14 * (27.1e6 / 8 / 153e9 * 1e3 + 0.006))) < 1e-9 and 0.3 < t8 < 0.45
+    for n, lo in ((2, 0.985), (4, 0.975), (8, 0.97)):
+        m = parallel.predict_step_ms(12.6, n, slices)
+        assert m["predicted_ms"] > 12.6 and m["predicted_efficiency"] >= lo, (n, m)
+        assert m["predicted_exposed_ms"] == round(parallel.ring_allreduce_ms(slices[-1], n), 4)
+    assert parallel.predict_step_ms(12.6, 1, slices)["predicted_ms"] == 12.6
+    # a paused sync (bench: the N = 1 time measured on the same device) exchanges nothing
+    s = parallel.BucketedSync(force=True)
+    s.paused = True
+    assert not s.active()
+
+
 def _worker(rank, world, port, tmp, frozen=False, gpu=False):
     for p in sys.path_extra:
         if p not in sys.path:

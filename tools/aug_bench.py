@@ -6,7 +6,7 @@ import torch
 from mds import augment
 dev = "cuda:0"
 x = torch.rand(4, 15, 736, 1280, device=dev)
-mod = augment.get_train_augmentations((1280, 736))
+mod = augment.get_train_augmentations((1280, 736), compose_geometric=True)       # the opt-in composed form
 nb = x.numel() * 4
 def t_ms(fn, reps=20):
     for _ in range(3): fn()
