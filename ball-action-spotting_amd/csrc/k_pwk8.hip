@@ -147,15 +147,34 @@ __global__ __launch_bounds__(512) void pwk8_kernel(mds_pw_fwd_args a) {
         if (HAS_GATE) sreg_pin(tga[o]);
       }
     };
-    auto piece = [&](const u16x8& rv, const f32x8& sc, const f32x8& sh, const f32x8& ga) {   // all lanes: one gate row
-      float v[8];
+    // One 8-channel piece, all lanes on one gate row, written stage by stage over the 8 elements (8 independent exps, then 8
+    // reciprocals).  Measured (profiles/r05_pwk8_trace.txt): the transform's pace is NOT set by the transcendentals, by packed
+    // fp32 ops or by the chains' latency - an affine-only prologue (28 plain VALU instructions per piece) already takes 1200 of
+    // the 2500 cycles per stage: beside a consumer wave that issues MFMAs this wave gets one VALU issue in ~11 cycles.
+    auto piece = [&](const u16x8& rv, const f32x8& sc, const f32x8& sh, const f32x8& ga) {
+      float v[8], e[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float z = bf2f(rv[j]);
-        if (HAS_BN) z = z * sc[j] + sh[j];
-        if (HAS_ACT) z = siluf_(z);
-        if (HAS_GATE) z *= ga[j];
-        v[j] = z;
+        v[j] = bf2f(rv[j]);
+        if (HAS_BN) v[j] = v[j] * sc[j] + sh[j];
+      }
+      if (HAS_ACT) {
+        // (the pins are what holds the stages apart: a scheduling fence alone does not stop the IR passes from sinking every
+        // element's arithmetic down to its use)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { e[j] = v[j] * -1.4426950408889634f; reg_pin(e[j]); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { e[j] = fast_exp2(e[j]); reg_pin(e[j]); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { e[j] = 1.0f + e[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { e[j] = fast_rcp(e[j]); reg_pin(e[j]); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= e[j];
+      }
+      if (HAS_GATE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= ga[j];
       }
       return pack8(v);
     };

@@ -24,7 +24,9 @@ def frag_pack(lib, w):
 
 BF = torch.bfloat16
 def rnd(*s): return torch.randn(*s, device=dev).to(BF)
-for (M, K, N, mode, tag) in [(18400, 1152, 192, 3, "fwd 1152->192"), (18400, 1152, 192, 0, "no prologue 1152->192"),
+for (M, K, N, mode, tag) in [(18400, 1152, 192, 3, "fwd 1152->192 BN+SiLU+gate"), (18400, 1152, 192, 2, "fwd 1152->192 BN+SiLU"),
+                             (18400, 1152, 192, 1, "fwd 1152->192 affine only"), (18400, 1152, 192, 4, "fwd 1152->192 gate only"),
+                             (18400, 1152, 192, 0, "no prologue 1152->192"),
                              (73600, 672, 112, 3, "fwd 672->112"), (73600, 672, 112, 0, "no prologue 672->112")]:
     x = rnd(M, K); w = rnd(N, K); y = torch.empty(M, N, device=dev, dtype=BF)
     sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
