@@ -14,7 +14,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(mds_stem_fwd_args a) {
   typedef typename Frag<T>::type frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int i = lane & 15, q = lane >> 4;
-  const int gw = blockIdx.x * 4 + (tid >> 6), nw = gridDim.x * 4;
+  // XCD-aware: consecutive block ids go to consecutive XCDs, each with its own L2.  A wave's 16-pixel group reads 33 input
+  // columns of 3 rows: the boundary line of a block's four groups and two of the three rows are shared with the neighbouring
+  // blocks - on eight different XCDs each of them fetched the shared lines from HBM again (PMC round 4: 416 MB fetched for a
+  // 226 MB input).  Every XCD now walks a contiguous range of the group sequence.
+  const int gw = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + (tid >> 6), nw = gridDim.x * 4;
   const T* w = (const T*)a.w;
   frag_t wf[2];
 #pragma unroll
@@ -107,12 +111,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(mds_stem_fwd_args a) {
   }
 }
 
+static int stem_fwd_tiled(const mds_stem_fwd_args* a, mds_stream_t stream);
 extern "C" int mds_stem_fwd(const mds_stem_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->N > 0 && a->H > 0 && a->W > 0 && a->OH > 0 && a->OW > 0, "stem_fwd: bad dims");
   MDS_REQUIRE(a->Cout % 16 == 0 && a->Cout <= 32, "stem_fwd: Cout=%d must be 16 or 32", a->Cout);
   MDS_REQUIRE((a->x || a->ingest.u8) && a->w && a->y, "stem_fwd: null pointer");
   MDS_REQUIRE(!a->ingest.u8 || (a->ingest.nsrc > 0 && a->ingest.src_h > 0 && a->ingest.src_w > 0 && a->N <= 2 * a->ingest.nsrc),
               "stem_fwd: ingest needs nsrc, src_h, src_w and N <= 2 * nsrc");
+  if (a->dtype == MDS_BF16 && a->x && !a->ingest.u8 && a->epi.mode == MDS_EPI_NONE && mds_knob(MDS_KNOB_STEM_FWD) != 1)
+    return stem_fwd_tiled(a, stream);                  // the training forward (k_stem.hip, below)
   const long ngroups = (long)a->N * a->OH * ((a->OW + 15) / 16);
   long nb = (ngroups + 3) / 4;
   if (nb > 4096) nb = 4096;
@@ -363,6 +370,139 @@ __global__ __launch_bounds__(256, DYP ? 2 : 3) void stem_wgrad_tiled_kernel(mds_
     const int oc = e >> 5, k = e & 31;
     if (k < 27 && oc < a.Cout) atomicAdd(a.dw + oc * 27 + k, (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]));
   }
+}
+
+// bf16 training forward, tiled through LDS (round 5).  The gather kernel at the top of this file issues 8 scalar 4-byte loads per
+// lane and 16-pixel group - 64 lanes x every second column of 4 (row, plane) pairs: ~20 cache lines per instruction, bound by the
+// texture-address path at 2.8 TB/s.  Here a block stages the fp32 input of an 8 x 32-pixel output tile ONCE with coalesced 8-byte
+// loads, as the three pre-shifted bf16 arrays A_kx[j] = x[2 (ox0 + j) + kx - pad_l] per (input row, plane) that the tiled weight
+// gradient uses, and a lane gathers its 8 taps of one pixel from LDS (2-byte reads; consecutive lanes = consecutive columns).
+// Persistent blocks, the next tile's loads in flight under this tile's MFMAs and stores.  Same arithmetic as the gather kernel:
+// the input is rounded to bf16 once (RNE), products on the bf16 matrix core, fp32 accumulation, statistics of the fp32 values.
+__global__ __launch_bounds__(256, 3) void stem_fwd_tiled_kernel(mds_stem_fwd_args a, int tiles_a, int tiles_b, int tiles_per_block) {
+  MDS_CHAIN_PRIO();
+  typedef bf16_t T;
+  constexpr int IR = 2 * SW_ROWS + 1;                  // input rows of a tile
+  constexpr int NX = IR * 3 * (SW_COLS / 8);           // x staging items: (input row, plane, 8-column group)
+  __shared__ __attribute__((aligned(16))) T xa[IR * 9 * SW_PITCH + SW_PITCH];   // [IR][3 planes][3 kx][SW_PITCH] + a row of zeros
+  T* zrow = xa + IR * 9 * SW_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const T* w = (const T*)a.w;
+  u16x8 wf[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    if (16 * f + i < a.Cout) wf[f] = ld_frag(w + (16 * f + i) * 32 + 8 * q);
+    else frag_zero(wf[f]);
+  }
+  if (tid < SW_PITCH) zrow[tid] = 0;
+  // this lane's eight taps k = 8q + j -> (plane, ky, kx): LDS element offset of the tap's array within the tile image (row 2r of
+  // the tile is added per output row r); k >= 27: the row of zeros
+  int toff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * q + j, pl = k / 9, ky = (k % 9) / 3, kx = k % 3;
+    toff[j] = k < 27 ? ((ky * 3 + pl) * 3 + kx) * SW_PITCH : -1;
+  }
+  const long total = (long)a.N * tiles_a * tiles_b;
+  long tl = (long)xcd_contiguous(blockIdx.x, gridDim.x) * tiles_per_block, tl_end = tl + tiles_per_block;
+  if (tl_end > total) tl_end = total;
+  float s_[8], ss_[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s_[e] = 0.f; ss_[e] = 0.f; }
+  T* y = (T*)a.y;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 rx[9];
+  auto origin = [&](long t, int& img, int& oy0, int& ox0) {
+    img = (int)(t / (tiles_a * tiles_b));
+    const int rem = (int)(t - (long)img * tiles_a * tiles_b);
+    oy0 = (rem / tiles_b) * SW_ROWS; ox0 = (rem % tiles_b) * SW_COLS;
+  };
+  auto issue = [&](long t) {
+    int img, oy0, ox0;
+    origin(t, img, oy0, ox0);
+    if (tid < NX) {
+      const int grp = tid & 3, pl = (tid >> 2) % 3, ir = tid / 12;
+      const int iy = oy0 * 2 - a.pad_t + ir;
+      const int iyc = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+      const float* row = a.x + (((long)img * 3 + pl) * a.H + iyc) * a.W;
+      const int ix0 = 2 * (ox0 + 8 * grp) - a.pad_l;
+      if (iy >= 0 && iy < a.H && ix0 >= 0 && ix0 + 17 < a.W) {   // interior: nine 8-byte loads
+#pragma unroll
+        for (int j = 0; j < 9; ++j) rx[j] = *(const f32x2*)(row + ix0 + 2 * j);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          const int ix = ix0 + 2 * j;
+          const bool ok0 = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W, ok1 = iy >= 0 && iy < a.H && ix + 1 >= 0 && ix + 1 < a.W;
+          const int c0 = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix), c1 = ix + 1 < 0 ? 0 : (ix + 1 >= a.W ? a.W - 1 : ix + 1);
+          const float v0 = row[c0], v1 = row[c1];
+          rx[j] = (f32x2){ok0 ? v0 : 0.f, ok1 ? v1 : 0.f};
+        }
+      }
+    }
+  };
+  if (tl < tl_end) issue(tl);
+  for (; tl < tl_end; ++tl) {
+    __syncthreads();                                   // the previous tile's fragments have been read
+    if (tid < NX) {
+      const int grp = tid & 3, pl = (tid >> 2) % 3, ir = tid / 12;
+      T* base = xa + ((ir * 3 + pl) * 3) * SW_PITCH + 8 * grp;
+      float v0[8], v1[8], v2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v0[j] = rx[j][0]; v1[j] = rx[j][1]; v2[j] = rx[j + 1][0]; }
+      store8(base, v0); store8(base + SW_PITCH, v1); store8(base + 2 * SW_PITCH, v2);
+    }
+    __syncthreads();
+    if (tl + 1 < tl_end) issue(tl + 1);
+    int img, oy0, ox0;
+    origin(tl, img, oy0, ox0);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = 2 * wave + rr, oy = oy0 + r;       // output row of the tile handled by this wave
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                    // its two 16-pixel groups
+        const int col = 16 * h + i, ox = ox0 + col;
+        const T* rowp = xa + (2 * r) * 9 * SW_PITCH + col;
+        u16x8 xf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = toff[j] >= 0 ? rowp[toff[j]] : zrow[0];
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        mma16(wf[0], xf, acc[0]);                      // acc[r] = y[pixel i][oc = 4q + r]
+        mma16(wf[1], xf, acc[1]);
+        if (oy < a.OH && ox < a.OW) {
+          const long row = ((long)img * a.OH + oy) * a.OW + ox;
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const int oc = 16 * f + 4 * q;
+            if (oc < a.Cout) {
+              float v[4] = {acc[f][0], acc[f][1], acc[f][2], acc[f][3]};
+              store4(y + row * a.Cout + oc, v);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { s_[f * 4 + e] += v[e]; ss_[f * 4 + e] += v[e] * v[e]; }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    double* st = a.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * a.Cout;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = sum_over_i16(s_[e]), ss = sum_over_i16(ss_[e]);
+      const int oc = 16 * (e >> 2) + 4 * q + (e & 3);
+      if (i == 0 && oc < a.Cout) { atomicAdd(st + oc, (double)s); atomicAdd(st + a.Cout + oc, (double)ss); }
+    }
+  }
+}
+
+static int stem_fwd_tiled(const mds_stem_fwd_args* a, mds_stream_t stream) {
+  const int tiles_a = cdiv(a->OH, SW_ROWS), tiles_b = cdiv(a->OW, SW_COLS);
+  const long total = (long)a->N * tiles_a * tiles_b;
+  const int tpb = (int)cdiv(total, total < 768 ? total : 768);   // three blocks per CU
+  MDS_LAUNCH(stem_fwd_tiled_kernel, dim3(cdiv(total, tpb)), dim3(256), 0, stream, *a, tiles_a, tiles_b, tpb);
+  return mds_check_launch("stem_fwd");
 }
 
 extern "C" int mds_stem_wgrad(const mds_stem_wgrad_args* a, mds_stream_t stream) {

@@ -159,7 +159,8 @@ def op_cost(name, kw, es):
         return g("N") * 3 * g("H") * g("W") * 4 + px * g("Cout") * es, 2 * 27 * g("Cout") * px
     if name == "stem_wgrad":
         px = g("N") * g("OH") * g("OW")
-        return g("N") * 3 * g("H") * g("W") * 4 + px * g("Cout") * es, 2 * 27 * g("Cout") * px
+        nwide = 2 if g("dyp") else 1      # dy formed on load (mds_dyp_t): the gradient source u AND the raw stem output y are read
+        return g("N") * 3 * g("H") * g("W") * 4 + nwide * px * g("Cout") * es, 2 * 27 * g("Cout") * px
     if name == "dw_fwd":
         nin = g("N") * g("T") * g("IH") * g("IW") * g("C")
         nout = g("N") * g("T") * g("OH") * g("OW") * g("C")

@@ -150,7 +150,7 @@ def test_dw_fwd_output_transform(be, dt, N, T, H, W, C, stride, kt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("N,H,W", [(2, 20, 36), (1, 17, 23), (3, 6, 70)])
+@pytest.mark.parametrize("N,H,W", [(2, 20, 36), (1, 17, 23), (3, 6, 70), (2, 40, 150)])      # (the last: 3 x 3 tiles of the tiled kernels per image)
 def test_stem_fwd_wgrad(be, dt, N, H, W):
     code, tdt = DT[dt]
     g = gen(H * W)
