@@ -148,9 +148,11 @@ __global__ __launch_bounds__(512) void pwk8_kernel(mds_pw_fwd_args a) {
       }
     };
     // One 8-channel piece, all lanes on one gate row, written stage by stage over the 8 elements (8 independent exps, then 8
-    // reciprocals).  Measured (profiles/r05_pwk8_trace.txt): the transform's pace is NOT set by the transcendentals, by packed
-    // fp32 ops or by the chains' latency - an affine-only prologue (28 plain VALU instructions per piece) already takes 1200 of
-    // the 2500 cycles per stage: beside a consumer wave that issues MFMAs this wave gets one VALU issue in ~11 cycles.
+    // reciprocals).  What it costs (profiles/r05_pwk8_trace_*.txt; the same numbers with the consumers' MFMAs compiled out, with
+    // two producers per SIMD they double): plain VALU 4 cycles, packed fp32 and 64-bit moves 8, v_exp_f32 / v_rcp_f32 16 per
+    // wave instruction - 8 unpack + 4 mov + 4 pk_fma + 8 mul + 8 exp + 8 add + 8 rcp + 8 pk_mul + 4 cvt = 496 cycles per piece,
+    // half of it the two transcendentals; four pieces per stage at 80 rows + ~500 cycles of LDS / table latency = the 2500
+    // cycles the trace shows.  The transform is bound by the SIMD's VALU throughput, not by scheduling.
     auto piece = [&](const u16x8& rv, const f32x8& sc, const f32x8& sh, const f32x8& ga) {
       float v[8], e[8];
 #pragma unroll

@@ -62,7 +62,7 @@ def bench_dw(which):
         mean = torch.randn(C, device=dev) * 0.1; rstd = torch.rand(C, device=dev) + 0.5
         y = torch.empty(N * T * OH * OW, C, device=dev, dtype=BF)
         st = torch.zeros(SLOTS, 2, C, device=dev, dtype=torch.float64)
-        pro = cabi.pro(2, sc, sh)
+        pro = cabi.pro(int(os.environ.get("KB_MODE", "2")), sc, sh)
         nin, nout = x.numel(), y.numel()
         if which == "dw_fwd":
             a = cabi.make("mds_dw_fwd_args", dtype=1, N=N, T=T, IH=H, IW=W, C=C, OH=OH, OW=OW, stride=s, pad_t=pt, pad_l=pl,
