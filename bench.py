@@ -472,18 +472,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but only {torch.cuda.device_count()} visible devices (one rank per GPU)"
+    # MDS_BENCH_SHARED_GPU=1 (developer, FUNCTIONAL test of the N > 1 code path on a one-GPU box): every rank on device 0, slices
+    # over gloo (RCCL refuses two ranks on one device); the line says so and is not a measurement of N GPUs
+    shared = os.environ.get("MDS_BENCH_SHARED_GPU", "0") == "1"
+    if shared:
+        local = 0
+    assert shared or torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but only {torch.cuda.device_count()} visible devices (one rank per GPU)"
     assert local < torch.cuda.device_count(), f"LOCAL_RANK {local} has no device of its own"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
         devs = [None] * world                       # every rank on its own device: N ranks sharing one GPU would not be an N-GPU line
         dist.all_gather_object(devs, (os.uname().nodename, torch.cuda.current_device()))
-        assert len(set(devs)) == world, f"ranks share devices: {devs}"
+        assert shared or len(set(devs)) == world, f"ranks share devices: {devs}"
 
     if args.config == "predict":
         return bench_predict(args, dev, rank, world)
@@ -574,7 +582,7 @@ def main():
             local_ms = args.n1_ms if args.n1_ms else tl.item()
             sync.paused = False
             model_pred = parallel.predict_step_ms(local_ms, world, [(hi - lo) * 4 for lo, hi, _ in sl])
-            par_info = {"rccl_ranks": world, "backend": dist.get_backend(), "devices_in_use": world,
+            par_info = {"rccl_ranks": world, "backend": dist.get_backend(), "devices_in_use": 1 if shared else world,
                         "local_step_ms_no_exchange": round(tl.item(), 4), "n1_ms_given": args.n1_ms,
                         "efficiency_vs_n1": round(local_ms / ms_per_step, 4), **model_pred,
                         "allreduce_slices_in_backward_order":
@@ -590,6 +598,9 @@ def main():
     roofline, breakdown, top_launches = None, None, None
     full = (args.height, args.width) == (736, 1280)
     work = WORK[args.config] if full else None
+    if world > 1 and getattr(model, "_grad_sync", None) is not None and hasattr(model._grad_sync, "paused"):
+        model._grad_sync.paused = True      # the per-kernel pass below runs on rank 0 ONLY: its steps must not enter a collective the
+                                            # other ranks never join (rank 0 would hang in the next synchronize)
     if rank == 0 and args.profile_steps > 0:
         plan = next(p for pool in model._cache.plans.values() for p in pool if p.kind == "full" and p.need_grad)
         plan.profile = []

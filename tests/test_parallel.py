@@ -147,3 +147,26 @@ def test_world2_sharing_one_gpu_gradients_match_mean_of_oracle(tmp_path, frozen)
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
+
+
+@pytest.mark.gpu
+def test_bench_line_of_two_ranks_runs_end_to_end(tmp_path):
+    """`python bench.py --gpus 2` end to end on the one-GPU box (MDS_BENCH_SHARED_GPU=1: both ranks on device 0, slices over gloo -
+    a FUNCTIONAL run of the N > 1 code path, not a measurement): the self-spawned torchrun, the timed steps with the bucketed
+    exchange, the steps without it, the rank-0-only per-kernel pass (which must not enter a collective) and the `parallel` block
+    with the scaling model's prediction."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDS_BENCH_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "1",
+                        "--no-cpu-baseline", "--no-pmc", "--no-other-configs"], env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    par = d["parallel"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and par["rccl_ranks"] == 2 and par["devices_in_use"] == 1
+    assert par["predicted_ms"] > par["local_step_ms_no_exchange"] > 0 and 0 < par["efficiency_vs_n1"] <= 1.05
+    assert len(par["allreduce_slices_in_backward_order"]) >= 3 and d["roofline"]["kernel"]
