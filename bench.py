@@ -386,10 +386,10 @@ def bench_predict(args, dev, rank, world):
                          "path": f"frame by frame (the reference's API), fp32, {fbf_fps:.0f} frames/s; durations: rocprofv3 --kernel-trace --stats child run",
                          "us_per_frame_by_family": {k: round(v["avg_us"] * cost[k][0], 1) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["total_us"])[:8]}}
                 # HBM traffic per launch of that kernel: FETCH_SIZE / WRITE_SIZE passes of the same path (separate runs, KiB units,
-                # FETCH_SIZE x2 on gfx950 - MI355X_MICROARCH.md HBM section)
+                # FETCH_SIZE x2 on gfx950 - MI355X_MICROARCH.md HBM section); 100 frames per pass: rocprofv3 7.2 segfaults in a 300-frame counter pass
                 pa = ["--config", "predict", "--predict-fbf-only"]
-                f = pmc_child(["FETCH_SIZE"], pa, timeout=400, steps=300) or pmc_child(["FETCH_SIZE"], pa, timeout=400, steps=300)
-                w = pmc_child(["WRITE_SIZE"], pa, timeout=400, steps=300) or pmc_child(["WRITE_SIZE"], pa, timeout=400, steps=300)
+                f = pmc_child(["FETCH_SIZE"], pa, timeout=200, steps=100) or pmc_child(["FETCH_SIZE"], pa, timeout=200, steps=100)
+                w = pmc_child(["WRITE_SIZE"], pa, timeout=200, steps=100) or pmc_child(["WRITE_SIZE"], pa, timeout=200, steps=100)
                 if f and w and dom in f and dom in w:
                     kroof["traffic"] = int(f[dom]["FETCH_SIZE"] * 2048 + w[dom]["WRITE_SIZE"] * 1024)
     cpu = None
