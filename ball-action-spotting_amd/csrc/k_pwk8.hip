@@ -435,9 +435,7 @@ bool pwk8_shape_ok(long M, int K, int N, int dtype) {
 
 // does a launch of this shape take the K-streaming kernel when it is given the fragment-major filter copy?  (the planner asks
 // before it schedules the extra MDS_PACK_FRAG_* job)
-int pwn_wants_frag(long M, int K, int N, int dtype, int data_gradient);      // k_pwn.hip
 extern "C" int mds_pw_fwd_wants_frag(long M, int K, int N, int dtype, int data_gradient) {
-  if (pwn_wants_frag(M, K, N, dtype, data_gradient)) return 1;
   const int knob = mds_knob(MDS_KNOB_PWK);
   if (knob == 1 || !pwk8_shape_ok(M, K, N, dtype)) return 0;
   if (knob == 2) return 1;

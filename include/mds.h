@@ -66,8 +66,7 @@ const char* mds_last_error(void);
 #define MDS_KNOB_PWK 18            /* K-streaming 1x1 GEMM (k_pwk8.hip): 0 = rule (forward launches), 1 = never, 2 = every legal shape (tests), 3 = rule + data gradients, 4 = data gradients only */
 #define MDS_KNOB_PWK_BM 19         /* rows per tile of the K-streaming kernel: 0 = rule, 64 / 80 / 96 / 128 (A/B) */
 #define MDS_KNOB_STEM_FWD 20       /* 1: the bf16 training stem forward takes the gather kernel instead of the LDS-tiled one (A/B) */
-#define MDS_KNOB_PWN 21            /* N-streaming 1x1 GEMM (k_pwn.hip): 0 = rule (forward launches), 1 = never, 2 = every legal shape (tests), 3 = rule + data gradients, 4 = data gradients only */
-#define MDS_KNOB_COUNT 22
+#define MDS_KNOB_COUNT 21
 int mds_dev_set(int knob, int value);
 /* Completion event of the NEXT launches of the calling thread (a hipEvent_t as void*; NULL disarms).  While armed, every kernel
  * this thread launches through the library is issued with the event as its STOP event (hipExtLaunchKernelGGL), i.e. the event is

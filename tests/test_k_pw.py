@@ -483,41 +483,6 @@ def test_pw_fwd_kstream_data_gradient(be, force_kstream, M, K, N, res, post):
     _run_pw_plain(be, "bf16", M, K, N, res, False, post, False, frag=True)
 
 
-@pytest.mark.parametrize("bm", [32, 48, 64, 80])
-@pytest.mark.parametrize("M,K,N,stats", [
-    (300, 192, 1152, True),        # the stage-5 expansion: 18 stages, ragged last row tile
-    (170, 96, 384, True),          # three k-steps
-    (200, 128, 256, False),        # four k-steps, no statistics (the projection's data gradient form)
-    (90, 192, 576, True),          # the 3D expansion; 80-row tiles: a second tile of 10 rows
-])
-def test_pw_fwd_nstream(be, bm, M, K, N, stats):
-    """k_pwn.hip: the N-streaming kernel (x rows resident in registers, filter fragments straight from the fragment-major copy,
-    output through a double-buffered LDS tile, column sums parked in LDS)"""
-    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PWN, 2), "dev_set")
-    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK_BM, bm), "dev_set")
-    try:
-        dt = "bf16"
-        code, tdt = DT[dt]
-        g = torch.Generator().manual_seed(M + K + N)
-        x = torch.randn(M, K, generator=g).to(tdt)
-        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(tdt)
-        y = torch.full((M, N), float("nan")).to(tdt).to(be.device)
-        st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, N, device=be.device, dtype=torch.float64)
-        be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=be.t(x), w=be.t(w), y=y, pro=cabi.pro(0),
-                                    residual=None, stats=st if stats else None, w_frag=_frag_pack(be, w, io=(M % 2 == 1))))
-        be.sync()
-        ref = x.float() @ w.float().t()
-        assert_close(y, ref, dt, msg="y")
-        if stats:
-            assert int((st.abs().sum((1, 2)) > 0).sum()) == -(-M // bm), "the N-streaming kernel was not taken (one statistics slot per row tile)"
-            s = st.sum(0).cpu()
-            assert_close(s[0], ref.sum(0), dt, scale=M ** 0.5, msg="sum")
-            assert_close(s[1], (ref * ref).sum(0), dt, scale=M ** 0.5, msg="sumsq")
-    finally:
-        be.lib.fn["dev_set"](cabi.MDS_KNOB_PWN, 0)
-        be.lib.fn["dev_set"](cabi.MDS_KNOB_PWK_BM, 0)
-
-
 # ------------------------------------------------------------------------------------------------ linear form of BatchNorm backward
 def _wcat(w0, w1):
     """[N][K0] and [N][K1] -> the packed [N][Kp + K1p] weight rows of a two-pair mds_pw_fwd (zero padded to multiples of 64)"""

@@ -132,26 +132,6 @@ def bench_pwk():
             lib.fn["dev_set"](18, 0)
 
 
-def bench_pwn():
-    """general kernel (knob 21 = 1) against the N-streaming kernel (k_pwn.hip): expansion forward (statistics) and the
-    projection's data-gradient form (no statistics)"""
-    for (M, K, N, tag) in [(18400, 192, 1152, "b5.x pw 192->1152"), (18400, 192, 576, "3d pw 192->576"), (18400, 96, 384, "96->384 @18400"),
-                           (36800, 192, 1152, "192->1152 @36800")]:
-        x = rnd(M, K); w = rnd(N, K); y = torch.empty(M, N, device=dev, dtype=BF)
-        st = torch.zeros(SLOTS, 2, N, device=dev, dtype=torch.float64)
-        nbytes, flops = (M * K + M * N + N * K) * 2, 2 * M * K * N
-        wfr = frag_pack(lib, w)
-        for name, stats in (("fwd", st), ("dgrad", None)):
-            a = cabi.make("mds_pw_fwd_args", dtype=1, M=M, K=K, N=N, x=x, w=w, y=y, pro=cabi.pro(0), residual=None, stats=stats, w_frag=wfr)
-            lib.fn["dev_set"](21, 1)
-            timeit(f"{name:5s} {tag} general", lambda: lib.call("pw_fwd", a, stream()), nbytes, flops)
-            lib.fn["dev_set"](21, 2)
-            for bm in (32, 48, 64, 80):
-                lib.fn["dev_set"](19, bm)
-                timeit(f"{name:5s} {tag} nstream bm={bm}", lambda: lib.call("pw_fwd", a, stream()), nbytes, flops)
-            lib.fn["dev_set"](19, 0); lib.fn["dev_set"](21, 0)
-
-
 CONV_SHAPES = [(20, 368, 640, 32, 16, 1, 2, "b0.0 32->16"), (20, 368, 640, 16, 64, 2, 2, "b1.0 16->64 s2"),
                (20, 184, 320, 32, 128, 1, 0, "b1.1 32->128"), (20, 184, 320, 32, 128, 2, 0, "b2.0 32->128 s2"),
                (20, 92, 160, 48, 192, 1, 0, "b2.1 48->192")]
@@ -289,8 +269,6 @@ if __name__ == "__main__":
             bench_dw(t)
         elif t == "pwk":
             bench_pwk()
-        elif t == "pwn":
-            bench_pwn()
         elif t == "pw_as_conv":
             bench_pw_as_conv()
         elif t.startswith("pw"):
