@@ -72,11 +72,13 @@ def cpu_baseline(max_seconds=20.0, frames=15, frozen=False):
     CPU work are spent (best pass reported).  If a single
     full-size pass exceeds the budget the sample falls back to a quarter of the pixels (15x368x640, same
     network and frame count) and the rate is scaled by 1/4 — the `sample` string says which was used.
-    A bf16-autocast pass of the quarter-size sample is timed beside it (SURVEY §8d asks for both)."""
+    A bf16-autocast pass of the same window is timed beside it (SURVEY §8d asks for both)."""
     import torch
     from oracle import multidim_stacker_ref as orc
     cores = os.cpu_count() or 1
-    threads = min(cores, 32)       # eager convolutions stop scaling (and oversubscribe) well before 256 threads
+    # eager convolutions stop scaling (and oversubscribe) well before 256 threads.  Measured on the GPU box's host (256 logical cores,
+    # profiles/r05_cpu_threads.txt): one fp32 fwd+bwd window takes 2.4 s at 32 threads, 5.1 s at 64, 10.8 s at 128 and 237 s at 256
+    threads = min(cores, 32)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0, num_frames=frames)
@@ -115,9 +117,9 @@ def cpu_baseline(max_seconds=20.0, frames=15, frozen=False):
     if frozen:
         return out
     try:
-        tb = run(368, 640, 6.0, amp=True, max_n=3)
-        out["bf16_autocast"] = {"value": round(1.0 / (min(tb) * 4), 5), "unit": "frame-windows/s",
-                                "sample": f"same oracle under torch.autocast('cpu', bfloat16), 15x368x640 sample scaled x1/4, "
+        tb = run(736, 1280, 6.0, amp=True, max_n=4)        # the full window (round 5: it is the faster of the two on this host)
+        out["bf16_autocast"] = {"value": round(1.0 / min(tb), 5), "unit": "frame-windows/s",
+                                "sample": f"same oracle under torch.autocast('cpu', bfloat16), 1 window of {shape}, "
                                           f"best of {len(tb)} passes ({sum(tb):.1f} s)"}
     except Exception as e:  # CPU bf16 convolutions may be unsupported on an old host
         out["bf16_autocast"] = {"error": str(e)[:120]}
