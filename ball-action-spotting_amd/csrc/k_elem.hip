@@ -89,14 +89,17 @@ __global__ __launch_bounds__(256) void se_pool_kernel(mds_se_pool_args a) {
 // blocks per group of a reduce kernel: every block ends with O(C) atomics / partial stores, so it
 // must own enough rows to amortise them (8 passes made the C = 1152 layers tail-bound: 1.2 TB/s)
 static int reduce_passes() { return mds_knob(MDS_KNOB_REDUCE_PASSES) > 0 ? mds_knob(MDS_KNOB_REDUCE_PASSES) : 32; }   // measured 8 / 16 / 32 / 64 / 128 at the four layer shapes
-static inline int group_blocks(long rows, int C) {
-  const long per = (long)rows_per_pass(C, row_slices(C)) * reduce_passes();
+// (fwd: the pooling pass of the FORWARD, which has nothing beside it and no second operand stream - swept alone in round 5 with
+// tools/fwd_time.py: 4 / 8 / 12 / 16 / 24 / 32 passes -> 4.131 / 4.122 / 4.118 / 4.108 / 4.140 / 4.172 ms of forward; the backward's
+// se_bwd_reduce keeps 32, swept inside the step)
+static inline int group_blocks(long rows, int C, bool fwd = false) {
+  const long per = (long)rows_per_pass(C, row_slices(C)) * ((fwd && mds_knob(MDS_KNOB_REDUCE_PASSES) == 0) ? 16 : reduce_passes());
   const long b = (rows + per - 1) / per;
   return (int)(b > 64 ? 64 : (b < 1 ? 1 : b));
 }
 extern "C" int mds_se_pool(const mds_se_pool_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->groups > 0 && a->rows_per_group > 0 && a->C % 8 == 0 && a->C <= 2048, "se_pool: bad dims");
-  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(se_pool_kernel<T>, dim3(group_blocks(a->rows_per_group, a->C), a->groups, row_slices(a->C)), dim3(256), 0, stream, *a));
+  MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH(se_pool_kernel<T>, dim3(group_blocks(a->rows_per_group, a->C, true), a->groups, row_slices(a->C)), dim3(256), 0, stream, *a));
   return mds_check_launch("se_pool");
 }
 
