@@ -683,6 +683,137 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
   if (POOL && a.pool) dw_pool_flush(red, sp, pimg, pok, a.pool, a.pool_inv, C, cbeg);
 }
 
+// ------------------------------------------------------------------------------------ 3x3x3, any T (time chunks)
+// The same register sliding window for stacks of any length (the 33-frame configuration: T = 11).  A strip is (image, TIME CHUNK of
+// TO output slices, output row, column segment): the thread keeps the activated window of the chunk's TO + 2 input slices (the
+// chunk and one halo slice on either side; slices outside the stack count as zeros), so the 27 taps need no boundary tests and
+// an input slice is read by at most two chunks.  TO = 4: 54 window registers pairs (T = 11 -> chunks of 4 / 4 / 3 outputs,
+// 6 + 6 + 4 input slices for 11: 1.45 x, the second reading from L2).  Replaces the LDS-tiled kernel at the top of this file for
+// these shapes: 166 us at 4 x 11 x 23 x 40 x 576 (0.56 TB/s; the T = 5 kernel's rate would be 72 us).
+#define DW3G_TO 4
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dw3g_fwd_kernel(mds_dw_fwd_args a, DwStrips g, int nchunks_t) {
+  MDS_CHAIN_PRIO();
+  constexpr int TO = DW3G_TO, TW = TO + 2;
+  typedef Pair<T> P;
+  typedef typename P::raw_t raw_t;
+  __shared__ f32x2 wl[27][32];
+  __shared__ float red[8][4][32];
+  const int tid = threadIdx.x, cp = tid & 31, sl = tid >> 5;
+  const DwBlock db = dw_block(g);   // (strip block, channel chunk) of this workgroup, XCD-aware
+  const int bx = db.bx;
+  const int C = a.C, cbeg = db.chunk * 64, c0 = cbeg + 2 * cp;
+  const bool cvalid = c0 < C;
+  const int mode = a.pro.mode;
+  for (int e = tid; e < 27 * 32; e += 256) {
+    const int t = e >> 5, c = cbeg + 2 * (e & 31);
+    wl[t][e & 31] = c < C ? (f32x2){a.w[(long)c * 27 + t], a.w[(long)(c + 1) * 27 + t]} : splat2(0.f);
+  }
+  __syncthreads();
+  f32x2 s1 = splat2(0.f), s2 = splat2(0.f), sc = splat2(1.f), sh = splat2(0.f);
+  if (cvalid && mode != MDS_PRO_NONE) { sc = *(const f32x2*)(a.pro.scale + c0); sh = *(const f32x2*)(a.pro.shift + c0); }
+  const int tstr = a.IH * a.IW * C;   // slice stride (elements)
+  for (int k = 0; k < g.spt; ++k) {
+    const long strip = ((long)bx * g.spt + k) * 8 + sl;
+    if (!cvalid || strip >= g.nstrips) continue;
+    const int seg = (int)(strip % g.nseg);
+    const long bt = strip / g.nseg;
+    const int oy = (int)(bt % g.nbands), nc = (int)(bt / g.nbands);   // "image" of the strip geometry = (stack, time chunk)
+    const int n = nc / nchunks_t, t0 = (nc - n * nchunks_t) * TO;
+    const int ox0 = seg * g.L;
+    const int nout = (a.OW - ox0 < g.L) ? a.OW - ox0 : g.L;
+    const T* xim = (const T*)a.x + (long)n * a.T * tstr + c0;
+    T* yim = (T*)a.y + (long)n * a.T * tstr + (long)oy * a.OW * C + c0;
+    int roff[3], rok = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int iy = oy - 1 + j;
+      rok |= (iy >= 0 && iy < a.IH) ? (1 << j) : 0;
+      roff[j] = clampi(iy, 0, a.IH - 1) * a.IW * C;
+    }
+    long toff[TW];                       // window slot s = input slice t0 - 1 + s (clamped; tok: inside the stack)
+    int tok = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < TW; ++s_) {
+      const int it = t0 - 1 + s_;
+      tok |= (it >= 0 && it < a.T) ? (1 << s_) : 0;
+      toff[s_] = (long)clampi(it, 0, a.T - 1) * tstr;
+    }
+    auto ldcol = [&](int ix, raw_t (&raw)[TW][3]) {
+      const int xo = clampi(ix, 0, a.IW - 1) * C;
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) raw[t][j] = P::ld(xim + toff[t] + roff[j] + xo);
+    };
+    f32x2 win[TW][3][3];
+    auto push = [&](int ix, const raw_t (&raw)[TW][3]) {
+      const bool cok = ix >= 0 && ix < a.IW;
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          f32x2 v = P::up(raw[t][j]);
+          if (mode != MDS_PRO_NONE) {
+            v = v * sc + sh;
+            if (mode != MDS_PRO_AFFINE) v = v * sigmoid2(v);
+          }
+          const bool ok = cok && ((rok >> j) & 1) && ((tok >> t) & 1);
+          win[t][j][0] = win[t][j][1]; win[t][j][1] = win[t][j][2];
+          win[t][j][2] = ok ? v : splat2(0.f);
+        }
+    };
+    raw_t raw[TW][3], cur[TW][3];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { win[t][j][1] = splat2(0.f); win[t][j][2] = splat2(0.f); }
+    ldcol(ox0 - 1, raw); push(ox0 - 1, raw);
+    ldcol(ox0, raw); push(ox0, raw);
+    ldcol(ox0 + 1, raw);
+#pragma unroll 1
+    for (int o = 0; o < nout; ++o) {
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cur[t][j] = raw[t][j];
+      ldcol(ox0 + o + 2, raw);
+      push(ox0 + o + 1, cur);
+      f32x2 acc[TO];
+#pragma unroll
+      for (int t = 0; t < TO; ++t) acc[t] = splat2(0.f);
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const f32x2 wv = wl[(dt * 3 + ky) * 3 + kx][cp];
+#pragma unroll
+            for (int ot = 0; ot < TO; ++ot) acc[ot] += win[ot + dt][ky][kx] * wv;   // output slice t0 + ot reads slices t0 + ot - 1 .. + 1 = slots ot .. ot + 2
+          }
+#pragma unroll
+      for (int ot = 0; ot < TO; ++ot) {
+        if (t0 + ot < a.T) {
+          P::str(yim + (long)(t0 + ot) * tstr + (long)(ox0 + o) * C, P::pk(acc[ot]));
+          s1 += acc[ot]; s2 += acc[ot] * acc[ot];
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    red[sl][0][cp] = s1[0]; red[sl][1][cp] = s1[1]; red[sl][2][cp] = s2[0]; red[sl][3][cp] = s2[1];
+    __syncthreads();
+    if (tid < 128) {
+      const int kk = tid >> 6, c = tid & 63;
+      float t = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) t += red[s][kk * 2 + (c & 1)][c >> 1];
+      if (cbeg + c < C) atomicAdd(a.stats + ((long)(bx % MDS_STAT_SLOTS) * 2 + kk) * C + cbeg + c, (double)t);
+    }
+  }
+}
+
 // backward: window of dy [5 slices][3 rows][3 cols] around the thread's input row; per input pixel
 //   da[it] = sum_{dt,ky,kx} dy[it+1-dt][iy+1-ky][ix+1-kx] * w[dt][ky][kx],   dw[tap] += act[it] * (same dy)
 #ifndef MDS_DW3B_OCC
@@ -1178,6 +1309,16 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
     dim3 grid = dw_grid(g), block(256);
     if (a->pool) MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw3_fwd_kernel<T, true>), grid, block, 0, stream, *a, g));
     else MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw3_fwd_kernel<T, false>), grid, block, 0, stream, *a, g));
+    return mds_check_launch("dw_fwd");
+  }
+  if (a->kt == 3 && a->stride == 1 && a->dtype == MDS_BF16 && a->epi.mode == MDS_EPI_NONE && !a->pool && mds_knob(MDS_KNOB_DW3G) != 1) {   // any other T: time chunks (fp32 would spill: it keeps the LDS-tiled kernel)
+    const int nct = cdiv(a->T, DW3G_TO);
+    // strips of ~10 columns (4 x 11 x 23 x 40 x 576: 112 / 94 / 84 / 94 / 96 us at 40 / 20 / 10 / 8 / 5 columns - two to three rounds
+    // of blocks suit this kernel better than one round of long strips)
+    const int want = mds_knob(MDS_KNOB_DW3_L) > 1 ? mds_knob(MDS_KNOB_DW3_L) : cdiv(a->OW, (a->OW + 5) / 10 > 0 ? (a->OW + 5) / 10 : 1);
+    DwStrips g = dw_strips(a->N * nct, a->OH, a->OW, a->C, 1, want);
+    dim3 grid = dw_grid(g), block(256);
+    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw3g_fwd_kernel<T>), grid, block, 0, stream, *a, g, nct));
     return mds_check_launch("dw_fwd");
   }
   MDS_DISPATCH_DTYPE(a->dtype, T, {

@@ -35,6 +35,10 @@ DW_CASES = [  # N,T,H,W,C,stride,kt
     (1, 1, 11, 38, 72, 2, 1),     # mixed: pad_t 1, pad_l 0; several segments
     (2, 3, 5, 7, 24, 1, 3),
     (1, 5, 6, 9, 576, 1, 3),
+    (2, 11, 6, 13, 72, 1, 3),     # the 33-frame configuration's stack length: time chunks of 4 / 4 / 3 slices (dw3g_*)
+    (1, 4, 5, 9, 24, 1, 3),       # exactly one chunk
+    (1, 9, 7, 8, 136, 1, 3),      # 4 / 4 / 1
+    (3, 2, 5, 6, 16, 1, 3),
 ]
 
 

@@ -55,7 +55,7 @@ def rnd(*shape, dtype=BF):
 
 def bench_dw(which):
     for (N, T, H, W, C, s, kt, tag) in [(20, 1, 46, 80, 384, 1, 1, "s3 46x80x384"), (20, 1, 46, 80, 576, 1, 1, "s4.0 46x80x576"), (20, 1, 46, 80, 672, 1, 1, "s4 46x80x672"), (20, 1, 23, 40, 1152, 1, 1, "s5 23x40x1152"),
-                                        (20, 1, 92, 160, 192, 2, 1, "s3.0 92x160x192 s2"), (4, 5, 23, 40, 576, 1, 3, "3d 5x23x40x576")]:
+                                        (20, 1, 92, 160, 192, 2, 1, "s3.0 92x160x192 s2"), (4, 5, 23, 40, 576, 1, 3, "3d 5x23x40x576"), (4, 11, 23, 40, 576, 1, 3, "3d 11x23x40x576 (config 4)")]:
         OH, OW, pt, pl = geo.conv_geometry(H, W, s)
         x = rnd(N * T * H * W, C); w = torch.randn(C, kt * 9, device=dev) * 0.3
         sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev) * 0.1

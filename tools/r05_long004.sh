@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_k_dw_stem.py -q -m gpu -k "dw_fwd_bwd or strip_lengths" 2>&1 | tail -1
+python tools/kbench.py dw_fwd 2>&1 | grep "3d"
+run() { python bench.py --config long004 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-other-configs --profile-steps 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'])"; }
+for rep in 1 2 3; do echo "LDS-tiled dw3 (21=1) $(MDS_KNOBS=21=1 run)"; echo "time-chunked dw3g      $(run)"; done | tee gpurun_out/r05_ab_long004_dw3g.txt
