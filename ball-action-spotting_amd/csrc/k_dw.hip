@@ -689,7 +689,9 @@ __global__ __launch_bounds__(256, 2) void dw3_fwd_kernel(mds_dw_fwd_args a, DwSt
 // chunk and one halo slice on either side; slices outside the stack count as zeros), so the 27 taps need no boundary tests and
 // an input slice is read by at most two chunks.  TO = 4: 54 window registers pairs (T = 11 -> chunks of 4 / 4 / 3 outputs,
 // 6 + 6 + 4 input slices for 11: 1.45 x, the second reading from L2).  Replaces the LDS-tiled kernel at the top of this file for
-// these shapes: 166 us at 4 x 11 x 23 x 40 x 576 (0.56 TB/s; the T = 5 kernel's rate would be 72 us).
+// these shapes: 166 -> 84 us at 4 x 11 x 23 x 40 x 576.  (The BACKWARD counterpart - chunks of three input slices under a five-slice
+// dy window - measured 238 us against the LDS-tiled kernel's 183: four times the blocks, each ending in its 64 x 27 filter-gradient
+// atomics, and 42 spilled registers; not adopted, profiles/LOG.md.)
 #define DW3G_TO 4
 template <typename T>
 __global__ __launch_bounds__(256, 2) void dw3g_fwd_kernel(mds_dw_fwd_args a, DwStrips g, int nchunks_t) {

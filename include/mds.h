@@ -66,7 +66,7 @@ const char* mds_last_error(void);
 #define MDS_KNOB_PWK 18            /* K-streaming 1x1 GEMM (k_pwk8.hip): 0 = rule (forward launches), 1 = never, 2 = every legal shape (tests), 3 = rule + data gradients, 4 = data gradients only */
 #define MDS_KNOB_PWK_BM 19         /* rows per tile of the K-streaming kernel: 0 = rule, 64 / 80 / 96 / 128 (A/B) */
 #define MDS_KNOB_STEM_FWD 20       /* 1: the bf16 training stem forward takes the gather kernel instead of the LDS-tiled one (A/B) */
-#define MDS_KNOB_DW3G 21           /* 1: the 3x3x3 depthwise kernels at T != 5 take the LDS-tiled kernels instead of the time-chunked sliding window (A/B) */
+#define MDS_KNOB_DW3G 21           /* 1: the 3x3x3 depthwise forward at T != 5 takes the LDS-tiled kernel instead of the time-chunked sliding window (A/B) */
 #define MDS_KNOB_COUNT 22
 int mds_dev_set(int knob, int value);
 /* Completion event of the NEXT launches of the calling thread (a hipEvent_t as void*; NULL disarms).  While armed, every kernel
