@@ -106,6 +106,8 @@ KH_SHAPES = [  # M, K, N, pro, tag: the K-streaming class (projections forward =
     (20 * 46 * 80, 672, 112, 3, "b4.x pwl 672->112"), (20 * 46 * 80, 576, 112, 3, "b4.0 pwl 576->112"),
     (20 * 46 * 80, 384, 96, 3, "b3.x pwl 384->96"), (20 * 46 * 80, 192, 96, 3, "b3.0 pwl 192->96"),
     (4 * 5 * 23 * 40, 576, 192, 3, "3d pwl 576->192"), (20 * 23 * 40, 192, 192, 0, "proj2d 192->192"),
+    (44 * 23 * 40, 1152, 192, 3, "config 4: b5.x pwl 1152->192 @40480"), (44 * 23 * 40, 576, 192, 3, "config 4: 3d pwl 576->192 @40480"),
+    (44 * 23 * 40, 192, 192, 0, "config 4: proj2d 192->192 @40480"),
 ]
 
 
