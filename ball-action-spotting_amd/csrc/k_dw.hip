@@ -1320,7 +1320,7 @@ extern "C" int mds_dw_fwd(const mds_dw_fwd_args* a, mds_stream_t stream) {
     const int want = mds_knob(MDS_KNOB_DW3_L) > 1 ? mds_knob(MDS_KNOB_DW3_L) : cdiv(a->OW, (a->OW + 5) / 10 > 0 ? (a->OW + 5) / 10 : 1);
     DwStrips g = dw_strips(a->N * nct, a->OH, a->OW, a->C, 1, want);
     dim3 grid = dw_grid(g), block(256);
-    MDS_DISPATCH_DTYPE(a->dtype, T, MDS_LAUNCH((dw3g_fwd_kernel<T>), grid, block, 0, stream, *a, g, nct));
+    MDS_LAUNCH((dw3g_fwd_kernel<bf16_t>), grid, block, 0, stream, *a, g, nct);      // (bf16 only: no fp32 instantiation exists)
     return mds_check_launch("dw_fwd");
   }
   MDS_DISPATCH_DTYPE(a->dtype, T, {
