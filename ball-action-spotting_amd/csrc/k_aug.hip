@@ -219,3 +219,24 @@ extern "C" int mds_frame_luma(const mds_frame_luma_args* a, mds_stream_t stream)
   MDS_LAUNCH(frame_luma_kernel, dim3(cdiv(a->width, 16 * 256) > 0 ? cdiv(a->width, 16 * 256) : 1, a->height, a->count), dim3(256), 0, stream, *a);
   return mds_check_launch("frame_luma");
 }
+
+// ------------------------------------------------------------------ predictor glue, slot-addressed row copies
+// One launch moves the rows a predictor step needs between its device rings and a plan's buffers; the slot numbers are kernel
+// arguments (an index tensor would be a host-to-device copy per frame).  grid = (pieces of a row, rows).
+__global__ __launch_bounds__(256) void copy_rows_kernel(mds_copy_rows_args a) {
+  const int r = blockIdx.y;
+  const unsigned char* s = (const unsigned char*)a.src + (long)a.src_slot[r] * a.src_pitch;
+  unsigned char* d = (unsigned char*)a.dst + (long)a.dst_slot[r] * a.dst_pitch;
+  const bool vec = ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0;
+  const long nv = vec ? a.row_bytes >> 4 : 0;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) ((u32x4*)d)[v] = ((const u32x4*)s)[v];
+  for (long x = 16 * nv + (long)blockIdx.x * 256 + threadIdx.x; x < a.row_bytes; x += (long)gridDim.x * 256) d[x] = s[x];
+}
+extern "C" int mds_copy_rows(const mds_copy_rows_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->src && a->dst && a->row_bytes > 0 && a->nrows > 0 && a->nrows <= MDS_COPY_ROWS_MAX, "copy_rows: bad args (at most %d rows)", MDS_COPY_ROWS_MAX);
+  for (int r = 0; r < a->nrows; ++r) MDS_REQUIRE(a->dst_slot[r] >= 0 && a->src_slot[r] >= 0, "copy_rows: negative slot");
+  long bx = cdiv(a->row_bytes, 16L * 256 * 4);      // four 16-byte vectors per lane
+  bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+  MDS_LAUNCH(copy_rows_kernel, dim3((unsigned)bx, a->nrows), dim3(256), 0, stream, *a);
+  return mds_check_launch("copy_rows");
+}

@@ -15,9 +15,19 @@ otherwise ``(None, predict_index)``.  What differs is where the work happens:
   stack; 3D tail + head of five) are captured once into hipGraphs: at batch 1-2 the reference's path is bound by
   ~330 kernel launches per frame, a graph replay is one.
 
+* ``predict_stream`` (offline prediction of a whole half - config 5 is throughput-only): the same per-frame (or per-chunk)
+  passes, software-pipelined over ``lanes`` internal HIP streams: step j (ring update, encoder pass, tail pass) runs on lane
+  j % lanes with that lane's own launch plans and buffers; only the rings are shared, ordered by events.  At batch 1 every
+  launch of a pass is a few hundred workgroups at most on 256 CUs and a step is a chain of ~100 dependent launches, so a
+  second chain beside the first costs a third of its own time (measured frame by frame, fp32: 1 / 2 / 3 / 4 lanes = 670 /
+  1113 / 1426 / 1587 frames/s; a separate stream for the tail passes loses - profiles/LOG.md).  Results reach the caller's
+  stream ``lanes`` steps late, behind an event: what the generator yields is safe to use on the current stream.
+
 The module's weights are read in place (the same ``mds.MultiDimStacker`` instance, e.g. the EMA copy argus loads).
 """
 from __future__ import annotations
+
+import os
 
 import torch
 
@@ -37,6 +47,9 @@ class StackIndexes:
 
 
 class StreamPredictor:
+    MAX_LANES = 4
+    MAX_IN_FLIGHT = 128          # frames of predict_stream steps in flight (lanes x chunk)
+
     def __init__(self, nn_module, frame_size=(1280, 736), frame_stack_size: int = 15, frame_stack_step: int = 2,
                  tta: bool = False, use_graphs: bool = True, compute_dtype: str = None):
         self.m = nn_module
@@ -52,18 +65,25 @@ class StreamPredictor:
         self._predict_offset = self.idx.make_stack_indexes(0)[-1]
         self.span = self.ss * self.step                  # frames between the ends of consecutive stacks of one window
         self.max_chunk = 32
-        self.nframes = 2 * self._predict_offset + 1 + self.max_chunk + 3     # raw-frame ring: a window behind every frame of a chunk
-        self.nfeat = (self.S - 1) * self.span + self.max_chunk + 8          # feature store: one slot per stack END index (mod)
+        # raw-frame ring: a window behind every frame of a chunk - and, for predict_stream, room for the steps in flight: the
+        # ring update of step j must not reach a slot an encoder pass of steps j - lanes + 1 .. j - 1 still reads (those read
+        # back to 28 frames behind their first frame): ring > lanes * chunk + 27, lanes * chunk <= MAX_IN_FLIGHT.  Same for the
+        # feature store (one slot per stack END index, modulo): a lane's encoder pass runs at most lanes + 1 steps ahead of
+        # another lane's tail pass, which reads 24 frames back.
+        self.nframes = 2 * self._predict_offset + 1 + self.MAX_IN_FLIGHT + 8
+        self.nfeat = (self.S - 1) * self.span + self.MAX_IN_FLIGHT + 2 * self.max_chunk + 8
         self.use_graphs = use_graphs
         self._built = None
         self.encoder_passes = 0          # 2D-encoder passes issued so far (steady state: one per chunk)
+        self._pipe = None                # predict_stream: the streams / lane of the step being issued
         self.reset_buffers()
 
     def close(self):
         """hand the launch plans back to the module's cache (they stay pinned while the predictor lives)"""
         for c in getattr(self, "plans", {}).values():
-            c["g2d"] = c["gtail"] = None
-            c["p2d"].in_flight = c["ptail"].in_flight = False
+            c["graphs"] = {}
+            for plan in c["p2d"] + c["ptail"]:
+                plan.in_flight = False
         self.plans = {}
         self.store = None
         self._built = None
@@ -89,11 +109,11 @@ class StreamPredictor:
         self.store = None
         self._built = (h, w, dev)
 
-    def _chunk(self, n: int):
-        """plans / graphs for chunks of n consecutive frames: one 2D-encoder pass over n (x2 with TTA) new stacks,
-        one tail pass over n (x2) windows"""
+    def _chunk(self, n: int, lanes: int = 1, tails: int = 1):
+        """plans / graphs for chunks of n consecutive frames: one 2D-encoder pass over n (x2 with TTA) new stacks - one plan
+        per encoder lane of predict_stream -, one tail pass over n (x2) windows"""
         c = self.plans.get(n)
-        if c is not None:
+        if c is not None and len(c["p2d"]) >= lanes and len(c["ptail"]) >= tails:
             return c
         h, w, dev = self._built
         m, b = self.m, (2 if self.tta else 1)
@@ -103,30 +123,40 @@ class StreamPredictor:
         try:
             with torch.no_grad():
                 probe = self.frames[0]
-                p2d = m._plan(probe, "2d", n * b, self.ss, self.H, self.W, False, ingest=(h, w, n))
-                ptail = m._plan(probe, "tail", n * b, self.S * self.ss, p2d.h, p2d.w, False)
+                if c is None:
+                    c = self.plans[n] = dict(p2d=[], ptail=[], graphs={}, warm={}, ver={}, cache={}, w={})
+                while len(c["p2d"]) < lanes:       # a plan that is in flight is never handed out again: every call builds (or finds) another
+                    p2d = m._plan(probe, "2d", n * b, self.ss, self.H, self.W, False, ingest=(h, w, n))
+                    p2d.in_flight = True           # owned by this predictor
+                    c["w"]["2d", len(c["p2d"])] = p2d.weight_tensors()
+                    c["p2d"].append(p2d)
+                while len(c["ptail"]) < (tails or 1):
+                    p2d = c["p2d"][0]
+                    pt = m._plan(probe, "tail", n * b, self.S * self.ss, p2d.h, p2d.w, False)
+                    pt.in_flight = True
+                    c["w"]["tail", len(c["ptail"])] = pt.weight_tensors()
+                    c["ptail"].append(pt)
         finally:
             m.compute_dtype = saved
-        p2d.in_flight = ptail.in_flight = True      # owned by this predictor: never handed out to another caller
+        p2d = c["p2d"][0]
         f = p2d.h * p2d.w * m.num_3d_features
         if self.store is None:
             self.f, self.tdt = f, p2d.tdt
             self.store = torch.zeros(self.nfeat, b, f, dtype=p2d.tdt, device=dev)      # [slot][orig | flipped][h*w*c]
-        c = self.plans[n] = dict(p2d=p2d, ptail=ptail, g2d=None, gtail=None, warm=0, cache={})
-        c["2d_w"], c["tail_w"] = p2d.weight_tensors(), ptail.weight_tensors()
         return c
 
-    def _replay(self, c, which):
+    def _replay(self, c, which, lane=0):
         """eager for the first calls (kernel attribute opt-ins, allocator warm-up), then one hipGraph replay"""
-        plan = c["p2d"] if which == "2d" else c["ptail"]
+        plan = c["p2d"][lane] if which == "2d" else c["ptail"][lane]
+        key = (which, lane)
 
         # packed weights / eval BatchNorm table: rebuilt only when a parameter or buffer was written since the last pass
         # (tensor version counters - the module's weights are still read in place, a load_state_dict / optimizer step between
         # two frames is picked up by the next one); kept OUT of the replayed graph
-        ver = sum(t._version for t in c[which + "_w"])
-        if c.get(which + "_ver") != ver:
+        ver = sum(t._version for t in c["w"][key])
+        if c["ver"].get(key) != ver:
             plan.refresh_weights()
-            c[which + "_ver"] = ver
+            c["ver"][key] = ver
 
         def fn():
             plan.begin_forward(None, refresh=False)
@@ -134,28 +164,35 @@ class StreamPredictor:
                 plan.run("f2d")
             else:
                 plan.run("f3d"); plan.run("fhead")
-        key = "g2d" if which == "2d" else "gtail"
         if not self.use_graphs or plan.device.type != "cuda":
             return fn()
-        if c[key] is None:
-            if c["warm"] < 4:
-                c["warm"] += 1
+        if c["graphs"].get(key) is None:
+            if c["warm"].get(key, 0) < 4:
+                c["warm"][key] = c["warm"].get(key, 0) + 1
                 return fn()
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(plan.device)
             with torch.cuda.graph(g):
                 fn()
-            c[key] = g
-        c[key].replay()
+            c["graphs"][key] = g
+        c["graphs"][key].replay()
 
     def _window_ready(self, index):
         return all(self.frame_tag[i % self.nframes] == i for i in self.idx.make_stack_indexes(index - self._predict_offset))
 
-    def _idx(self, c, key, rows, dev):
-        t = c["cache"].get(key)
-        if t is None:
-            t = c["cache"][key] = torch.tensor(rows, device=dev)
-        return t
+    def _rows(self, c, key, dst, dst_pitch, dst_slots, src, src_pitch, src_slots, row_bytes):
+        """one mds_copy_rows launch on the current stream: dst row dst_slots[r] <- src row src_slots[r] (pitches in BYTES).  The
+        slot numbers are kernel arguments - no index tensor, so nothing is copied from the host; the argument blocks are cached
+        per slot pattern (they repeat with the rings' periods)"""
+        st = c["cache"].get(key)
+        if st is None:
+            assert len(dst_slots) == len(src_slots) <= cabi.MDS_COPY_ROWS_MAX
+            st = c["cache"][key] = cabi.make("mds_copy_rows_args", dst=dst, src=src, dst_pitch=dst_pitch, src_pitch=src_pitch,
+                                              row_bytes=row_bytes, nrows=len(dst_slots), dst_slot=list(dst_slots), src_slot=list(src_slots))
+            if len(c["cache"]) > 4096:            # (bounded: a stream restarted at arbitrary indexes makes new patterns)
+                c["cache"].pop(next(iter(c["cache"])))
+        dev = dst.device
+        c["ptail"][0].lib.call("copy_rows", st, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
 
     # ------------------------------------------------------------------ the reference's API
     @torch.no_grad()
@@ -185,10 +222,16 @@ class StreamPredictor:
                 results.append((None, index - self._predict_offset))
             # ring update (n <= ring length; the frames of one chunk land in distinct slots)
             assert n <= self.max_chunk, "chunk longer than the frame ring allows"
-            if n == 1:
-                self.frames[first_index % self.nframes].copy_(frames[0])
-            else:
-                self.frames[torch.arange(first_index, first_index + n, device=dev) % self.nframes] = frames
+            with self._on("enc", frames):
+                a = first_index % self.nframes       # consecutive indexes are consecutive ring slots: one copy (two at the wrap)
+                if a + n <= self.nframes:
+                    self.frames[a:a + n].copy_(frames)
+                else:
+                    self.frames[a:].copy_(frames[:self.nframes - a])
+                    self.frames[:a + n - self.nframes].copy_(frames[self.nframes - a:])
+                if self._pipe is not None:       # (the lane waited for the previous step's ring event first: this one covers all earlier frames too)
+                    self._pipe["ring"] = torch.cuda.Event()
+                    self._pipe["ring"].record()
             for j in range(n):
                 if self._window_ready(first_index + j):
                     ready.append(j)
@@ -204,10 +247,23 @@ class StreamPredictor:
                 results[j] = r
             return results
 
+    # ------------------------------------------------------------------ two-stream software pipeline (predict_stream)
+    def _on(self, which, *inputs):
+        """stream context of a step: the caller's stream, or - inside predict_stream - the stream of the step's lane"""
+        if self._pipe is None:
+            return _Null()
+        st = self._pipe[which]
+        for t in inputs:
+            if t.is_cuda:
+                t.record_stream(st)         # the caller's tensor is read on the internal stream: its memory must outlive that
+        return torch.cuda.stream(st)
+
     def _run_chunk(self, indexes):
         n = len(indexes)
-        c = self._chunk(n)
-        p2d, ptail = c["p2d"], c["ptail"]
+        pipe = self._pipe
+        lane = pipe["lane"] if pipe is not None else 0
+        c = self._chunk(n, lane + 1, lane + 1)
+        p2d, ptail = c["p2d"][lane], c["ptail"][lane]
         dev, b = p2d.device, (2 if self.tta else 1)
         wins = [self.idx.make_stack_indexes(i - self._predict_offset) for i in indexes]
         stacks = [[tuple(w_[s * self.ss:(s + 1) * self.ss]) for s in range(self.S)] for w_ in wins]
@@ -220,32 +276,128 @@ class StreamPredictor:
                 if self.feat_tag[st[-1] % self.nfeat] != st:
                     uniq.setdefault(st, None)
         pending = list(uniq)
-        for r0 in range(0, len(pending), n):           # > 1 pass only right after a (re)start of the stream
-            todo = pending[r0:r0 + n]
-            todo = todo + [todo[-1]] * (n - len(todo))   # a short last pass repeats its last stack (same features, same slot)
-            sel = self._idx(c, ("sel", tuple(st[0] % self.nframes for st in todo)), [i % self.nframes for st in todo for i in st], dev)
-            torch.index_select(self.frames, 0, sel, out=p2d.x_u8.tensor.view(n * self.ss, *self.frames.shape[1:]))
-            self._replay(c, "2d")
-            self.encoder_passes += 1
-            fslots = [st[-1] % self.nfeat for st in todo]
-            si = self._idx(c, ("fs", tuple(fslots)), fslots, dev)
-            if n == 1:
-                self.store[fslots[0]].copy_(p2d.feat.tensor.view(b, self.f))
-            else:
-                self.store[si] = p2d.feat.tensor.view(b, n, self.f).transpose(0, 1)      # images: n originals, then their n mirrored copies
-            for st, fs in zip(todo, fslots):
-                self.feat_tag[fs] = st
+        with self._on("enc"):
+            for r0 in range(0, len(pending), n):           # > 1 pass only right after a (re)start of the stream
+                todo = pending[r0:r0 + n]
+                todo = todo + [todo[-1]] * (n - len(todo))   # a short last pass repeats its last stack (same features, same slot)
+                fb = self.frames.shape[1] * self.frames.shape[2]                     # bytes of a raw frame
+                src = [i % self.nframes for st in todo for i in st]
+                self._rows(c, ("sel", lane, tuple(src)), p2d.x_u8.tensor, fb, range(n * self.ss), self.frames, fb, src, fb)
+                self._replay(c, "2d", lane)
+                self.encoder_passes += 1
+                fslots = [st[-1] % self.nfeat for st in todo]
+                eb = self.store.element_size() * self.f                            # bytes of one image's features
+                # the pass's images: n originals, then (TTA) their n mirrored copies -> store[slot][orig | flipped]
+                self._rows(c, ("fs", lane, b, tuple(fslots)), self.store, eb, [fs * b + bb for bb in range(b) for fs in fslots],
+                           p2d.feat.tensor, eb, range(n * b), eb)
+                for st, fs in zip(todo, fslots):
+                    self.feat_tag[fs] = st
+            if pipe is not None:
+                enc_done = torch.cuda.Event()
+                enc_done.record()
+                for st in pending:
+                    pipe["stack_ev"][st] = (enc_done, pipe["enc"])
         slots = [[st[-1] % self.nfeat for st in sts] for sts in stacks]
-        gi = self._idx(c, ("g", tuple(s_[-1] for s_ in slots)), slots, dev)              # [n][S]
-        if b == 1:      # no TTA: [n][S][1][f] is already the tail's [n][1][S][f] - one gather straight into its input
-            torch.index_select(self.store.view(self.nfeat, self.f), 0, gi.view(-1), out=ptail.feat.tensor.view(n * self.S, self.f))
-        else:
-            gathered = self.store[gi]                                                          # [n][S][b][f]
-            ptail.feat.tensor.view(n, b, self.S, self.f).copy_(gathered.permute(0, 2, 1, 3))
-        self._replay(c, "tail")
-        probs = torch.sigmoid(ptail.logits.tensor.view(n, b, -1))                          # nn.Sigmoid, then the TTA mean
-        probs = probs[:, 0] if b == 1 else probs.mean(dim=1)
+        with self._on("tail"):
+            if pipe is not None:       # the features of the window's stacks: encoder passes of this and of earlier steps, on any lane
+                me, seen = torch.cuda.current_stream(), set()
+                for sts in stacks:
+                    for st in sts:
+                        ev = pipe["stack_ev"].get(st)
+                        if ev is not None and ev[1] != me and id(ev[0]) not in seen:
+                            seen.add(id(ev[0]))
+                            me.wait_event(ev[0])
+            eb = self.store.element_size() * self.f
+            # the tail's input [n][b][S][f] <- store[slot of (window j, stack s)][bb]
+            self._rows(c, ("g", b, tuple(tuple(s_) for s_ in slots)), ptail.feat.tensor, eb, range(n * b * self.S), self.store, eb,
+                       [slots[j][s_] * b + bb for j in range(n) for bb in range(b) for s_ in range(self.S)], eb)
+            self._replay(c, "tail", lane)
+            probs = torch.sigmoid(ptail.logits.tensor.view(n, b, -1))                          # nn.Sigmoid, then the TTA mean
+            probs = probs[:, 0] if b == 1 else probs.mean(dim=1)
+            if pipe is not None:
+                pipe["tail_done"] = torch.cuda.Event()
+                pipe["tail_done"].record()
+                pipe["outs"].append(probs)
         return [(probs[j], indexes[j] - self._predict_offset) for j in range(n)]
+
+    @torch.no_grad()
+    def predict_stream(self, frames, first_index: int = 0, chunk: int = 1, lanes: int = 4):
+        """Generator over an iterable of raw (h, w) uint8 frames with consecutive indexes from ``first_index``: yields, frame by
+        frame and in order, exactly what ``predict(frame, index)`` returns - from the same passes (``chunk`` consecutive frames
+        per pass, 1 = the reference's pattern: one new stack through the 2D encoder, one window through the tail).  Step j runs
+        on lane j % lanes - a HIP stream with its own encoder and tail plans; the rings (raw frames, stack features) are shared:
+        a lane's ring update waits for the previous step's, its tail pass for the encoder passes (on other lanes, 6 .. 24 frames
+        earlier) that produced the window's older stacks.  The caller's stream is made to wait for step j only after step
+        j + lanes has been issued: ``lanes`` steps of look-ahead into ``frames``; everything yielded is ordered behind an event
+        on the current stream."""
+        dev = next(self.m.parameters()).device
+        lanes = max(1, min(int(lanes), self.MAX_LANES, self.MAX_IN_FLIGHT // max(1, int(chunk))))
+        if dev.type != "cuda":                    # no streams to overlap: plain calls
+            idx = first_index
+            for fr in _batched(frames, chunk):
+                yield from self.predict_batch(torch.stack(list(fr)), idx)
+                idx += len(fr)
+            return
+        with torch.cuda.device(dev):
+            if getattr(self, "_streams", None) is None:
+                self._streams = [torch.cuda.Stream(dev) for _ in range(self.MAX_LANES)]
+            enc = self._streams
+            cur = torch.cuda.current_stream(dev)
+            for st in self._streams:              # whatever the caller queued so far (weights, earlier predict calls) comes first
+                st.wait_stream(cur)
+            pending, idx, step, last_ring, stack_ev = [], first_index, 0, None, {}
+
+            def finish(item):
+                res, done, outs = item
+                if done is not None:
+                    cur.wait_event(done)
+                    for out in outs:
+                        out.record_stream(cur)    # allocated on the tail stream, consumed on the caller's
+                return res
+
+            try:
+                for fr in _batched(frames, chunk):
+                    fr = [f.to(dev, non_blocking=True) for f in fr]
+                    batch = fr[0][None] if len(fr) == 1 else torch.stack(fr)
+                    ready = torch.cuda.Event()
+                    ready.record(cur)             # the frames are complete on the caller's stream here ...
+                    lane = enc[step % lanes]
+                    lane.wait_event(ready)        # ... and the lane's ring update starts behind that
+                    if last_ring is not None:     # ... and behind the ring updates of all earlier steps (made on other lanes)
+                        lane.wait_event(last_ring)
+                    pipe = self._pipe = dict(enc=lane, tail=lane, lane=step % lanes, ring=None, tail_done=None, outs=[], stack_ev=stack_ev)
+                    try:
+                        res = self.predict_batch(batch, idx)
+                    finally:
+                        self._pipe = None
+                    last_ring = pipe["ring"]
+                    if len(stack_ev) > 64 * chunk + 256:      # events of stacks no window needs any more
+                        for st in list(stack_ev)[:len(stack_ev) // 2]:
+                            del stack_ev[st]
+                    pending.append((res, pipe["tail_done"], pipe["outs"]))
+                    idx += len(fr)
+                    step += 1
+                    while len(pending) > lanes:
+                        yield from finish(pending.pop(0))
+                while pending:
+                    yield from finish(pending.pop(0))
+            finally:
+                for st in self._streams:          # an abandoned generator leaves nothing running behind the caller's back
+                    cur.wait_stream(st)
+
+
+def _batched(iterable, size):
+    it = iter(iterable)
+    while True:
+        out = []
+        for _ in range(size):
+            try:
+                out.append(next(it))
+            except StopIteration:
+                break
+        if not out:
+            return
+        yield out
 
 
 class _Null:

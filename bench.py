@@ -285,8 +285,9 @@ def bench_predict(args, dev, rank, world):
 
     last = {}
 
-    def run(tta, cdt, graphs=True, chunk=CH):
-        """K frames through the predictor, `chunk` consecutive frames per call (1 = the reference's frame-by-frame API)"""
+    def run(tta, cdt, graphs=True, chunk=CH, pipelined=0):
+        """K frames through the predictor, `chunk` consecutive frames per call (1 = the reference's frame-by-frame API);
+        pipelined: through StreamPredictor.predict_stream (the same passes, encoder of step j + 1 beside the tail of step j)"""
         sp = StreamPredictor(model, frame_size=(1280, 736), tta=tta, compute_dtype=cdt, use_graphs=graphs)
         last["sp"] = sp
         idx = 0
@@ -295,6 +296,12 @@ def bench_predict(args, dev, rank, world):
             nonlocal idx
             out = None
             done = 0
+            if pipelined:
+                first = idx
+                for out, _ in sp.predict_stream((pool[(first + j) % 64] for j in range(nfr)), first, chunk=chunk, lanes=pipelined):
+                    pass
+                idx += nfr
+                return out
             while done < nfr:
                 c = min(chunk, nfr - done)
                 a = idx % 64            # the caller's frames: a VIEW of the pool (no arange / remainder / gather launches of the
@@ -336,12 +343,22 @@ def bench_predict(args, dev, rank, world):
         torch.cuda.synchronize()
         return 50 / (time.perf_counter() - t0)
 
+    if args.predict_pipe_only:       # developer: the pipelined rates alone
+        if rank == 0:
+            out = {"fbf": round(K / run(False, None, chunk=1), 1), f"chunk{CH}": round(K / run(False, None), 1)}
+            for L in (1, 2, 3, 4):
+                out[f"fbf_lanes{L}"] = round(K / run(False, None, chunk=1, pipelined=L), 1)
+                out[f"chunk{CH}_lanes{L}"] = round(K / run(False, None, pipelined=L), 1)
+            out["fbf_tta_lanes3"] = round(K / run(True, None, chunk=1, pipelined=3), 1)
+            print(json.dumps(out))
+        return
     if args.predict_fbf_only:        # the kernel-trace child: only the reference's frame-by-frame API, fp32
         el = run(False, None, chunk=1)
         if rank == 0:
             print(json.dumps({"metric": "frames/sec, frame-by-frame API (trace child)", "value": round(K / el, 2), "unit": "frames/s"}))
         return
-    el = run(False, None)
+    LN = args.lanes
+    el = run(False, None, pipelined=LN)
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -349,9 +366,18 @@ def bench_predict(args, dev, rank, world):
     fps = K * world / el
     extra = {}
     if rank == 0 and world == 1:
-        extra = {"fp32_tta_frames_per_s": round(K / run(True, None), 1), "bf16_frames_per_s": round(K / run(False, "bf16"), 1),
-                 "bf16_tta_frames_per_s": round(K / run(True, "bf16"), 1),
-                 "frame_by_frame_api": {"fp32_frames_per_s": round(K / run(False, None, chunk=1), 1),
+        extra = {"fp32_tta_frames_per_s": round(K / run(True, None, pipelined=LN), 1), "bf16_frames_per_s": round(K / run(False, "bf16", pipelined=LN), 1),
+                 "bf16_tta_frames_per_s": round(K / run(True, "bf16", pipelined=LN), 1),
+                 "one_stream_no_lanes": {"note": f"predict_batch calls on the caller's stream, {CH} frames per call (rounds 2-4's headline path)",
+                                         "fp32_frames_per_s": round(K / run(False, None), 1), "fp32_tta_frames_per_s": round(K / run(True, None), 1),
+                                         "bf16_frames_per_s": round(K / run(False, "bf16"), 1)},
+                 "one_frame_per_pass": {"note": "the reference's pattern (one new stack through the 2D encoder, one window through the tail per frame) "
+                                                f"through predict_stream, {LN} lanes",
+                                        "fp32_frames_per_s": round(K / run(False, None, chunk=1, pipelined=LN), 1),
+                                        "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1, pipelined=LN), 1),
+                                        "fp32_frames_per_s_by_lanes": {str(L): round(K / run(False, None, chunk=1, pipelined=L), 1) for L in (1, 2, 3)}},
+                 "frame_by_frame_api": {"note": "predict(frame, index) calls, each result consumed in order on the caller's stream (no look-ahead)",
+                                        "fp32_frames_per_s": round(K / run(False, None, chunk=1), 1),
                                         "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1), 1),
                                         "bf16_frames_per_s": round(K / run(False, "bf16", chunk=1), 1),
                                         "fp32_no_graph_frames_per_s": round(K / run(False, None, graphs=False, chunk=1), 1)},
@@ -364,7 +390,7 @@ def bench_predict(args, dev, rank, world):
         sp = last["sp"]
         cost = {}
         for c in sp.plans.values():
-            for plan in (c["p2d"], c["ptail"]):
+            for plan in (c["p2d"][0], c["ptail"][0]):
                 for seg, ops in plan.bound.items():
                     for (name, *_), (nb, fl) in zip(ops, plan.costs[seg]):
                         e = cost.setdefault(kernel_family(name + "_kernel"), [0, 0.0, 0.0])
@@ -416,7 +442,8 @@ def bench_predict(args, dev, rank, world):
                "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(t_frame * 1e3, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32 (1x1 / 3x3 products as split-bf16: three bf16 MFMAs, >= 16 significant bits)", "data": "synthetic",
                "config": {"workload": f"sliding-window predictor over a stream of raw uint8 frames, 15-frame window stride 2, no TTA, fp32, {CH} consecutive "
-                                      "frames per call (offline prediction of a half; a step = one frame); one independent stream per GPU",
+                                      f"frames per pass, {LN} lanes (StreamPredictor.predict_stream: offline prediction of a half, throughput-only; "
+                                      "a step = one frame); one independent stream of frames per GPU",
                           "parallelism": f"replicas x{world}"},
                "roofline": {"bound": "mfma", "frac_whole_path": round(max(35.9e9 / (MFMA_PEAK_TFLOPS * 1e12), 0.12e9 / (HBM_PEAK_GBS * 1e9)) / t_frame, 5),
                             "definition": "SURVEY.md 8(d) config 5: 35.9 GFLOP, 0.12 GB per frame; launch-latency bound in practice",
@@ -456,6 +483,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--n1-ms", type=float, default=None, help="--gpus N > 1: ms per step of an N = 1 run, for parallel.efficiency_vs_n1 "
                     "(default: measured in the same run as steps without the exchange)")
+    ap.add_argument("--predict-pipe-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--lanes", type=int, default=4, help="--config predict: lanes of StreamPredictor.predict_stream (steps in flight on their own HIP streams)")
     ap.add_argument("--chunk", type=int, default=8, help="--config predict: consecutive frames per predictor call")
     ap.add_argument("--torch-step", action="store_true", help="torch's focal loss + torch.optim.AdamW(fused=True) instead of mds.train")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")

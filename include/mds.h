@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 130
+#define MDS_VERSION 131
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -703,6 +703,23 @@ typedef struct {
   const float* noise;         /* optional device (B, T, H, W) standard-normal draws; NULL = generate */
 } mds_aug_args;
 int mds_aug_pass(const mds_aug_args* a, mds_stream_t stream);
+
+/* ---- SURVEY 8(f) N1 (predictor glue): row gather / scatter between the predictor's device rings and the plans' buffers -
+ * raw frames ring -> the stem's uint8 input, 2D features -> the feature store, the store's five stacks -> the tail's
+ * input.  The reference does this with a Python dict of tensors + torch.stack / torch.cat per frame
+ * (src/predictors.py:58-68); index tensors on the device would cost a host-to-device copy per frame, so the slot
+ * numbers travel in the kernel arguments.  dst row r = dst + dst_slot[r] * dst_pitch  <-  src + src_slot[r] * src_pitch. */
+#define MDS_COPY_ROWS_MAX 320
+typedef struct {
+  void* dst;
+  const void* src;
+  long dst_pitch, src_pitch;   /* bytes between consecutive slots */
+  long row_bytes;              /* bytes copied per row (16-byte vectors when bases, pitches and row_bytes allow) */
+  int nrows;                   /* <= MDS_COPY_ROWS_MAX */
+  int dst_slot[MDS_COPY_ROWS_MAX];
+  int src_slot[MDS_COPY_ROWS_MAX];
+} mds_copy_rows_args;
+int mds_copy_rows(const mds_copy_rows_args* a, mds_stream_t stream);
 
 /* ---- SURVEY 8(f) N4 (device side): the luma plane of a decoded NV12 surface -> a contiguous (H, W) uint8 frame.
  * What `NvDecFrameFetcher._convert` does with PySurfaceConverter(NV12 -> Y) + makefromDevicePtrUint8 + resize_

@@ -110,6 +110,16 @@ def test_stream_predictor_matches_reference_logic(be, tta):
             if pp is not None:
                 got.append(pp.float().cpu())
     check(got, "chunks of 3")
+    # predict_stream: the same passes, the encoder of step j + 1 issued beside the tail of step j on two internal HIP streams
+    # (plain calls on the CPU simulator) - what it yields is what predict() returned, in order, nothing lost at the end
+    for chunk in (1, 3):
+        ss = StreamPredictor(prod, frame_size=size, tta=tta)
+        res = list(ss.predict_stream(iter(all_frames), 0, chunk=chunk))
+        assert [ip for _, ip in res] == [i - 14 for i in range(n)]
+        for (pp, _), o in zip(res, outs):
+            assert (pp is None) == (o is None)
+            if pp is not None:
+                assert (pp.float().cpu() - o).abs().max().item() < 1e-5, chunk
     # a gap in the stream: the window is incomplete again until 15 fresh frames (stride 2) are there
     sp2 = StreamPredictor(prod, frame_size=size, tta=tta)
     for index in list(range(0, 30)) + [40]:
