@@ -339,9 +339,9 @@ class StreamPredictor:
                 idx += len(fr)
             return
         with torch.cuda.device(dev):
-            if getattr(self, "_streams", None) is None:
-                self._streams = [torch.cuda.Stream(dev) for _ in range(self.MAX_LANES)]
+            self._streams = _lane_streams(dev, self.m._library(next(self.m.parameters())), self.MAX_LANES)
             enc = self._streams
+            lanes = min(lanes, len(enc))
             cur = torch.cuda.current_stream(dev)
             for st in self._streams:              # whatever the caller queued so far (weights, earlier predict calls) comes first
                 st.wait_stream(cur)
@@ -384,6 +384,63 @@ class StreamPredictor:
             finally:
                 for st in self._streams:          # an abandoned generator leaves nothing running behind the caller's back
                     cur.wait_stream(st)
+
+
+_LANE_STREAMS = {}       # device -> the lane streams of predict_stream
+
+
+def _lane_streams(dev, lib, want):
+    """The lane streams are chosen ONCE per process and device, by measurement.  A HIP stream is bound to one of the runtime's
+    hardware queues (GPU_MAX_HW_QUEUES, 4 by default) when it is first used - the least referenced queue at that moment - and
+    two lanes on one hardware queue run one after the other (measured at 4 lanes: 1 / 2 / 4 hardware queues -> 695 / 1110 /
+    1591 frames/s; 8 queues: 685 - the device serves four at a time; the same 3 lanes drawn afresh: 1398 or 898 frames/s
+    depending on what the process's earlier streams had left).  So: a dozen candidate streams, a copy that keeps a quarter of
+    the chip busy for ~0.1 ms issued on two of them at a time - side by side it takes about as long as one, on a shared queue
+    twice as long -, and the largest set of candidates that all overlap each other becomes the lanes (fewer than ``want`` if
+    the runtime has fewer queues: predict_stream then runs that many lanes)."""
+    got = _LANE_STREAMS.get(dev)
+    if got is not None:
+        return got
+    import time
+    cand = [torch.cuda.Stream(dev) for _ in range(12)]
+    nb = 48 << 20
+    src, dst = torch.empty(2, nb, dtype=torch.uint8, device=dev), torch.empty(2, nb, dtype=torch.uint8, device=dev)
+    jobs = [cabi.make("mds_copy_rows_args", dst=dst[k], src=src[k], dst_pitch=nb, src_pitch=nb, row_bytes=nb, nrows=1, dst_slot=[0], src_slot=[0])
+            for k in (0, 1)]
+
+    def timed(streams):
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for k, st in enumerate(streams):
+                lib.call("copy_rows", jobs[k], st.cuda_stream)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter() - t0
+            best = t if best is None or t < best else best
+        return best
+    for st in cand:
+        timed([st])                       # first use binds the hardware queue
+    one = min(timed([st]) for st in cand[:4])
+    n = len(cand)
+    ok = [[False] * n for _ in range(n)]
+    for i in range(n):
+        for j in range(i + 1, n):
+            ok[i][j] = ok[j][i] = timed([cand[i], cand[j]]) < 1.5 * one
+    best = []
+
+    def grow(chosen, start):              # largest set of mutually overlapping candidates (12 candidates: a handful of steps)
+        nonlocal best
+        if len(chosen) > len(best):
+            best = list(chosen)
+        if len(best) >= want:
+            return
+        for k in range(start, n):
+            if all(ok[k][c] for c in chosen):
+                grow(chosen + [k], k + 1)
+    grow([], 0)
+    got = _LANE_STREAMS[dev] = [cand[k] for k in (best or [0])]
+    return got
 
 
 def _batched(iterable, size):

@@ -367,20 +367,16 @@ def bench_predict(args, dev, rank, world):
     extra = {}
     if rank == 0 and world == 1:
         extra = {"fp32_tta_frames_per_s": round(K / run(True, None, pipelined=LN), 1), "bf16_frames_per_s": round(K / run(False, "bf16", pipelined=LN), 1),
-                 "bf16_tta_frames_per_s": round(K / run(True, "bf16", pipelined=LN), 1),
                  "one_stream_no_lanes": {"note": f"predict_batch calls on the caller's stream, {CH} frames per call (rounds 2-4's headline path)",
-                                         "fp32_frames_per_s": round(K / run(False, None), 1), "fp32_tta_frames_per_s": round(K / run(True, None), 1),
-                                         "bf16_frames_per_s": round(K / run(False, "bf16"), 1)},
+                                         "fp32_frames_per_s": round(K / run(False, None), 1)},
                  "one_frame_per_pass": {"note": "the reference's pattern (one new stack through the 2D encoder, one window through the tail per frame) "
                                                 f"through predict_stream, {LN} lanes",
                                         "fp32_frames_per_s": round(K / run(False, None, chunk=1, pipelined=LN), 1),
-                                        "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1, pipelined=LN), 1),
-                                        "fp32_frames_per_s_by_lanes": {str(L): round(K / run(False, None, chunk=1, pipelined=L), 1) for L in (1, 2, 3)}},
+                                        "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1, pipelined=LN), 1)},
                  "frame_by_frame_api": {"note": "predict(frame, index) calls, each result consumed in order on the caller's stream (no look-ahead)",
                                         "fp32_frames_per_s": round(K / run(False, None, chunk=1), 1),
                                         "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1), 1),
-                                        "bf16_frames_per_s": round(K / run(False, "bf16", chunk=1), 1),
-                                        "fp32_no_graph_frames_per_s": round(K / run(False, None, graphs=False, chunk=1), 1)},
+                                        "bf16_frames_per_s": round(K / run(False, "bf16", chunk=1), 1)},
                  "round1_module_call_path_frames_per_s": round(module_path(False), 1)}
     kroof = None
     if rank == 0 and world == 1 and args.predict_kernel_trace:
