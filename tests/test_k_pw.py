@@ -191,7 +191,9 @@ def test_pw_fwd_split_rule(be):
     (333, 48, 144, 2),
     (700, 112, 32, 3),
     (64, 192, 16, 1),
-    (300, 200, 192, 4),     # 128 < N <= 256: one 256-wide tile (bf16), gate prologue, K tail
+    (300, 200, 192, 4),     # 128 < N <= 256: a full and a half-empty 128-column tile, gate prologue, K tail
+    (900, 136, 192, 3),     # the stage-6 projection's form: BN + SiLU + gate on the wide operand, K tail
+    (450, 64, 160, 0),      # ragged second tile
 ])
 def test_pw_wgrad(be, dt, M, K, N, mode):
     code, tdt = DT[dt]
