@@ -955,13 +955,18 @@ class Plan:
             self.hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
             self.hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
             self.device, self.ev = device, {}
+            # hipEventDisableTiming | hipEventDisableSystemFence: these events only order the second stream behind a kernel of
+            # the chain - nobody on the host inspects them, so the system-scope fence (cache write-back for the host's benefit)
+            # a default event adds when it completes is dropped; the kernel's own device-scope release and the waiting stream's
+            # acquire stay.  12.67 -> 12.56 ms per step same-box (profiles/r05_ab_event_flags.txt; MDS_EVENT_FLAGS=0 = default events).
+            self.flags = int(os.environ.get("MDS_EVENT_FLAGS", "0x20000002"), 0)
 
         def get(self, seg, k):
             h = self.ev.get((seg, k))
             if h is None:
                 v = self.ct.c_void_p()
                 with torch.cuda.device(self.device):
-                    rc = self.hip.hipEventCreateWithFlags(self.ct.byref(v), 0)
+                    rc = self.hip.hipEventCreateWithFlags(self.ct.byref(v), self.flags)
                 if rc != 0 or not v.value:
                     raise RuntimeError(f"hipEventCreateWithFlags failed: {rc}")
                 h = self.ev[(seg, k)] = v.value
