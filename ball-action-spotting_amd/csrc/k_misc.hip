@@ -510,21 +510,33 @@ extern "C" int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
 // ------------------------------------------------------------------ head (dropout mask + Linear)
 __global__ __launch_bounds__(256) void head_fwd_kernel(mds_head_fwd_args a) {
   // one block per (sample, class): 256 threads walk the F = 1280 features (it was one wave: 20 dependent trips, 15 us on the chain)
+  // with `probs`: the first block of each group of `tta` samples does the whole group and writes the mean of their sigmoids
   __shared__ float part[4];
-  int b = blockIdx.x / a.NC, k = blockIdx.x % a.NC;
-  float s = 0.f;
-  for (int f = threadIdx.x; f < a.F; f += 256) {
-    float v = a.pooled[(long)b * a.F + f];
-    if (a.mask) v *= a.mask[(long)b * a.F + f];
-    s += v * a.w[(long)k * a.F + f];
+  const int b0 = blockIdx.x / a.NC, k = blockIdx.x % a.NC;
+  const int tta = (a.probs && a.tta > 1) ? a.tta : 1;
+  if (b0 % tta) return;
+  float psum = 0.f;
+  for (int t = 0; t < tta && b0 + t < a.B; ++t) {
+    const int b = b0 + t;
+    float s = 0.f;
+    for (int f = threadIdx.x; f < a.F; f += 256) {
+      float v = a.pooled[(long)b * a.F + f];
+      if (a.mask) v *= a.mask[(long)b * a.F + f];
+      s += v * a.w[(long)k * a.F + f];
+    }
+    s = wave_sum(s);
+    __syncthreads();          // (the previous sample's partials have been read)
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float logit = ((part[0] + part[1]) + (part[2] + part[3])) + a.b[k];
+    if (threadIdx.x == 0) a.logits[b * a.NC + k] = logit;
+    psum += sigmoidf_(logit);
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) a.logits[b * a.NC + k] = ((part[0] + part[1]) + (part[2] + part[3])) + a.b[k];
+  if (a.probs && threadIdx.x == 0) a.probs[(b0 / tta) * a.NC + k] = psum / (float)tta;
 }
 extern "C" int mds_head_fwd(const mds_head_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->B > 0 && a->F > 0 && a->NC > 0, "head_fwd: bad dims");
+  MDS_REQUIRE(!a->probs || (a->tta >= 1 && a->B % a->tta == 0), "head_fwd: probs needs tta >= 1 dividing B");
   MDS_LAUNCH(head_fwd_kernel, dim3(a->B * a->NC), dim3(256), 0, stream, *a);
   return mds_check_launch("head_fwd");
 }

@@ -200,7 +200,8 @@ class Plan:
 
     def __init__(self, module, lib, device, kind, B, T, H, W, code, training, need_grad, enc_grad, ingest=None):
         self.lib, self.device, self.kind = lib, device, kind
-        self.ingest = ingest        # (src_h, src_w): the 2D encoder reads raw uint8 frames (pad + /255 + TTA flip fused in the stem)
+        self.ingest = ingest        # 2D plans: (src_h, src_w, nsrc) - the encoder reads raw uint8 frames (pad + /255 + TTA flip fused in the stem);
+                                    # tail plans: ("probs", tta) - the head also writes the TTA-mean of the sigmoids (mds.predict)
         self.eval_bn = []           # the BNL of every BatchNorm of an eval-mode plan
         self.code = code
         self.tdt = torch.bfloat16 if code == cabi.MDS_BF16 else torch.float32
@@ -760,8 +761,11 @@ class Plan:
         dmask = self.mask(B * F_, m.drop_rate) if m.drop_rate > 0 else None
         ncls = m.classifier.out_features
         self.logits = self.f32(B * ncls)
+        # the predictor's tail plans (ingest = ("probs", tta)): nn.Sigmoid + the mean over the TTA pair in the head's launch
+        tta = self.ingest[1] if (self.kind == "tail" and self.ingest is not None and self.ingest[0] == "probs") else 0
+        self.probs = self.f32(B // tta * ncls) if tta else None
         self.op("fhead", "head_fwd", B=B, F=F_, NC=ncls, pooled=pooled, mask=dmask, w=P(m.classifier.weight),
-                b=P(m.classifier.bias), logits=self.logits)
+                b=P(m.classifier.bias), logits=self.logits, probs=self.probs, tta=max(tta, 1))
         self.dlogits = self.f32(B * ncls) if self.need_grad else None
 
         def bwd(seg, _, nxt_head):

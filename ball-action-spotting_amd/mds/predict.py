@@ -132,7 +132,7 @@ class StreamPredictor:
                     c["p2d"].append(p2d)
                 while len(c["ptail"]) < (tails or 1):
                     p2d = c["p2d"][0]
-                    pt = m._plan(probe, "tail", n * b, self.S * self.ss, p2d.h, p2d.w, False)
+                    pt = m._plan(probe, "tail", n * b, self.S * self.ss, p2d.h, p2d.w, False, ingest=("probs", b))
                     pt.in_flight = True
                     c["w"]["tail", len(c["ptail"])] = pt.weight_tensors()
                     c["ptail"].append(pt)
@@ -312,8 +312,7 @@ class StreamPredictor:
             self._rows(c, ("g", b, tuple(tuple(s_) for s_ in slots)), ptail.feat.tensor, eb, range(n * b * self.S), self.store, eb,
                        [slots[j][s_] * b + bb for j in range(n) for bb in range(b) for s_ in range(self.S)], eb)
             self._replay(c, "tail", lane)
-            probs = torch.sigmoid(ptail.logits.tensor.view(n, b, -1))                          # nn.Sigmoid, then the TTA mean
-            probs = probs[:, 0] if b == 1 else probs.mean(dim=1)
+            probs = ptail.probs.tensor.view(n, -1).clone()          # nn.Sigmoid + the TTA mean came out of the head's launch; the plan's buffer is reused by the next pass
             if pipe is not None:
                 pipe["tail_done"] = torch.cuda.Event()
                 pipe["tail_done"].record()
@@ -321,16 +320,18 @@ class StreamPredictor:
         return [(probs[j], indexes[j] - self._predict_offset) for j in range(n)]
 
     @torch.no_grad()
-    def predict_stream(self, frames, first_index: int = 0, chunk: int = 1, lanes: int = 4):
+    def predict_stream(self, frames, first_index: int = 0, chunk: int = 1, lanes: int = None):
         """Generator over an iterable of raw (h, w) uint8 frames with consecutive indexes from ``first_index``: yields, frame by
         frame and in order, exactly what ``predict(frame, index)`` returns - from the same passes (``chunk`` consecutive frames
         per pass, 1 = the reference's pattern: one new stack through the 2D encoder, one window through the tail).  Step j runs
         on lane j % lanes - a HIP stream with its own encoder and tail plans; the rings (raw frames, stack features) are shared:
         a lane's ring update waits for the previous step's, its tail pass for the encoder passes (on other lanes, 6 .. 24 frames
         earlier) that produced the window's older stacks.  The caller's stream is made to wait for step j only after step
-        j + lanes has been issued: ``lanes`` steps of look-ahead into ``frames``; everything yielded is ordered behind an event
-        on the current stream."""
+        j + lanes has been issued: ``lanes`` steps of look-ahead into ``frames`` (default: 4 lanes for chunks of up to 4 frames,
+        3 up to 8, 2 beyond); everything yielded is ordered behind an event on the current stream."""
         dev = next(self.m.parameters()).device
+        if not lanes:        # measured (profiles/r05_predict_lanes.txt): bigger passes fill more of the chip themselves
+            lanes = 4 if chunk <= 4 else (3 if chunk <= 8 else 2)
         lanes = max(1, min(int(lanes), self.MAX_LANES, self.MAX_IN_FLIGHT // max(1, int(chunk))))
         if dev.type != "cuda":                    # no streams to overlap: plain calls
             idx = first_index

@@ -357,7 +357,8 @@ def bench_predict(args, dev, rank, world):
         if rank == 0:
             print(json.dumps({"metric": "frames/sec, frame-by-frame API (trace child)", "value": round(K / el, 2), "unit": "frames/s"}))
         return
-    LN = args.lanes
+    LN = args.lanes or (4 if CH <= 4 else (3 if CH <= 8 else 2))
+    L1 = args.lanes or 4          # lanes of the one-frame-per-pass runs
     el = run(False, None, pipelined=LN)
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -370,9 +371,9 @@ def bench_predict(args, dev, rank, world):
                  "one_stream_no_lanes": {"note": f"predict_batch calls on the caller's stream, {CH} frames per call (rounds 2-4's headline path)",
                                          "fp32_frames_per_s": round(K / run(False, None), 1)},
                  "one_frame_per_pass": {"note": "the reference's pattern (one new stack through the 2D encoder, one window through the tail per frame) "
-                                                f"through predict_stream, {LN} lanes",
-                                        "fp32_frames_per_s": round(K / run(False, None, chunk=1, pipelined=LN), 1),
-                                        "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1, pipelined=LN), 1)},
+                                                f"through predict_stream, {L1} lanes",
+                                        "fp32_frames_per_s": round(K / run(False, None, chunk=1, pipelined=L1), 1),
+                                        "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1, pipelined=L1), 1)},
                  "frame_by_frame_api": {"note": "predict(frame, index) calls, each result consumed in order on the caller's stream (no look-ahead)",
                                         "fp32_frames_per_s": round(K / run(False, None, chunk=1), 1),
                                         "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1), 1),
@@ -480,7 +481,7 @@ def main():
     ap.add_argument("--n1-ms", type=float, default=None, help="--gpus N > 1: ms per step of an N = 1 run, for parallel.efficiency_vs_n1 "
                     "(default: measured in the same run as steps without the exchange)")
     ap.add_argument("--predict-pipe-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--lanes", type=int, default=4, help="--config predict: lanes of StreamPredictor.predict_stream (steps in flight on their own HIP streams)")
+    ap.add_argument("--lanes", type=int, default=0, help="--config predict: lanes of StreamPredictor.predict_stream (steps in flight on their own HIP streams; 0 = its own rule)")
     ap.add_argument("--chunk", type=int, default=8, help="--config predict: consecutive frames per predictor call")
     ap.add_argument("--torch-step", action="store_true", help="torch's focal loss + torch.optim.AdamW(fused=True) instead of mds.train")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 131
+#define MDS_VERSION 132
 #define MDS_F32 0
 #define MDS_BF16 1
 #define MDS_STAT_SLOTS 32
@@ -562,6 +562,9 @@ typedef struct {
   const float* w;      /* [NC][F] */
   const float* b;      /* [NC]    */
   float* logits;       /* [B][NC] */
+  float* probs;        /* optional [B / tta][NC]: mean over each group of `tta` consecutive samples of sigmoid(logits) - the
+                          predictor's nn.Sigmoid + torch.mean over the TTA pair (src/predictors.py:69-70) in the same launch */
+  int tta;             /* samples per group (>= 1; used with probs only) */
 } mds_head_fwd_args;
 int mds_head_fwd(const mds_head_fwd_args* a, mds_stream_t stream);
 

@@ -257,6 +257,21 @@ def test_head_fwd_bwd(be):
     assert_close(dw, wf.grad, "f32"); assert_close(db, bf.grad, "f32")
 
 
+@pytest.mark.parametrize("tta", [1, 2, 3])
+def test_head_fwd_probs(be, tta):
+    """the predictor's nn.Sigmoid + mean over the TTA group (src/predictors.py:69-70) from the head's own launch"""
+    B, Fdim, NC = 6, 333, 2
+    g = gen(32 + tta)
+    pooled = torch.randn(B, Fdim, generator=g); w = torch.randn(NC, Fdim, generator=g) * 0.1; b = torch.randn(NC, generator=g)
+    ref = F.linear(pooled, w, b)
+    logits = torch.empty(B, NC, device=be.device); probs = torch.empty(B // tta, NC, device=be.device)
+    be.call("head_fwd", cabi.make("mds_head_fwd_args", B=B, F=Fdim, NC=NC, pooled=be.t(pooled), mask=None, w=be.t(w), b=be.t(b),
+                                  logits=logits, probs=probs, tta=tta))
+    be.sync()
+    assert_close(logits, ref, "f32")
+    assert_close(probs, torch.sigmoid(ref).view(B // tta, tta, NC).mean(1), "f32")
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_pack_weights(be, dt):
     import ctypes as C_
