@@ -288,7 +288,7 @@ def bench_predict(args, dev, rank, world):
     def run(tta, cdt, graphs=True, chunk=CH, pipelined=0):
         """K frames through the predictor, `chunk` consecutive frames per call (1 = the reference's frame-by-frame API);
         pipelined: through StreamPredictor.predict_stream (the same passes, encoder of step j + 1 beside the tail of step j)"""
-        sp = StreamPredictor(model, frame_size=(1280, 736), tta=tta, compute_dtype=cdt, use_graphs=graphs)
+        sp = StreamPredictor(model, frame_size=(1280, 736), tta=tta, compute_dtype=cdt, use_graphs=graphs and os.environ.get("MDS_BENCH_NO_GRAPH", "0") != "1")
         last["sp"] = sp
         idx = 0
 
@@ -411,10 +411,11 @@ def bench_predict(args, dev, rank, world):
                          "path": f"frame by frame (the reference's API), fp32, {fbf_fps:.0f} frames/s; durations: rocprofv3 --kernel-trace --stats child run",
                          "us_per_frame_by_family": {k: round(v["avg_us"] * cost[k][0], 1) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["total_us"])[:8]}}
                 # HBM traffic per launch of that kernel: FETCH_SIZE / WRITE_SIZE passes of the same path (separate runs, KiB units,
-                # FETCH_SIZE x2 on gfx950 - MI355X_MICROARCH.md HBM section); 100 frames per pass: rocprofv3 7.2 segfaults in a 300-frame counter pass
+                # FETCH_SIZE x2 on gfx950 - MI355X_MICROARCH.md HBM section); 40 frames per pass: rocprofv3 7.2 segfaults in a 300-frame
+                # counter pass and (round 5) did not come back from a 100-frame one within 15 minutes
                 pa = ["--config", "predict", "--predict-fbf-only"]
-                f = pmc_child(["FETCH_SIZE"], pa, timeout=200, steps=100) or pmc_child(["FETCH_SIZE"], pa, timeout=200, steps=100)
-                w = pmc_child(["WRITE_SIZE"], pa, timeout=200, steps=100) or pmc_child(["WRITE_SIZE"], pa, timeout=200, steps=100)
+                f = pmc_child(["FETCH_SIZE"], pa, timeout=120, steps=40) or pmc_child(["FETCH_SIZE"], pa, timeout=120, steps=40)
+                w = pmc_child(["WRITE_SIZE"], pa, timeout=120, steps=40) or pmc_child(["WRITE_SIZE"], pa, timeout=120, steps=40)
                 if f and w and dom in f and dom in w:
                     kroof["traffic"] = int(f[dom]["FETCH_SIZE"] * 2048 + w[dom]["WRITE_SIZE"] * 1024)
     cpu = None
