@@ -1059,7 +1059,7 @@ class Plan:
     def begin_forward(self, mask_override=None, refresh=True):
         """refresh=False (the stream predictor): the caller runs refresh_weights() itself, and only when a parameter changed"""
         if self.zf_arena.numel or self.zf64_arena.numel:
-            self._zero_fwd.zero_()
+            self._memset(self._zero_fwd)
         if self.masks:
             if mask_override is not None:
                 self.mask_arena.tensor.copy_(mask_override.to(self.device, torch.float32).view(-1))
@@ -1072,8 +1072,23 @@ class Plan:
             # autograd's saved-tensor checks and version-keyed caches (mds.predict) see the write
             torch.autograd.graph.increment_version(self._bn_buffers)
 
+    _hip = None
+
+    def _memset(self, t):
+        """zero a uint8 arena on the current stream: hipMemsetAsync (one runtime fill, also a node of a captured hipGraph)"""
+        if t.device.type != "cuda" or os.environ.get("MDS_MEMSET", "hip") != "hip":
+            t.zero_()
+            return
+        if Plan._hip is None:
+            import ctypes
+            Plan._hip = ctypes.CDLL(_hip_path())
+            Plan._hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+        rc = Plan._hip.hipMemsetAsync(t.data_ptr(), 0, t.numel() * t.element_size(), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"hipMemsetAsync failed: {rc}")
+
     def begin_backward(self):
-        self._zero_bwd.zero_()
+        self._memset(self._zero_bwd)
 
     def stale(self):
         cur = tuple(p.data_ptr() for p, *_ in self.pack_jobs)

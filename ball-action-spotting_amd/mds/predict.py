@@ -143,7 +143,18 @@ class StreamPredictor:
         if self.store is None:
             self.f, self.tdt = f, p2d.tdt
             self.store = torch.zeros(self.nfeat, b, f, dtype=p2d.tdt, device=dev)      # [slot][orig | flipped][h*w*c]
+        self._order_lanes_behind_caller()
         return c
+
+    def _order_lanes_behind_caller(self):
+        """Buffers made on the caller's stream (rings, a plan's zero-initialised arenas and tickets) are first used on a lane's
+        stream: inside predict_stream the lanes wait for the caller's stream here, so that a zero-fill still queued there cannot
+        land on top of a lane's first writes (plans for a new chunk size / a new lane are built while other lanes are running)."""
+        if self._pipe is not None:
+            ev = torch.cuda.Event()
+            ev.record()                  # the current stream here is the caller's (no lane context is open)
+            for st in self._streams:
+                st.wait_event(ev)
 
     def _replay(self, c, which, lane=0):
         """eager for the first calls (kernel attribute opt-ins, allocator warm-up), then one hipGraph replay"""
@@ -212,6 +223,7 @@ class StreamPredictor:
         if self._built is None or self._built != (frames.shape[-2], frames.shape[-1], dev):
             self._build(frames[0])
             self.reset_buffers()
+            self._order_lanes_behind_caller()
         n = frames.shape[0]
         with torch.cuda.device(dev) if dev.type == "cuda" else _Null():
             results, ready = [], []

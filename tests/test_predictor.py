@@ -279,3 +279,37 @@ def test_predict_stream_lanes_over_several_ring_periods(tta, chunk):
     # distinct frames give distinct predictions: the comparison is not vacuous
     vals = torch.stack([p for p, _ in want if p is not None])
     assert (vals[1:] - vals[:-1]).abs().max().item() > 1e-6
+
+
+@pytest.mark.gpu
+def test_predict_stream_orders_lanes_behind_buffers_made_on_the_callers_stream():
+    """plans for a new chunk size / a new lane are built (zero-filled arenas, tickets, the feature store) on the CALLER's stream
+    while lanes are already running.  Here the caller's stream is kept busy (a 125 ms device-side sleep in front of every plan
+    build, every plan built inside the run): the results must still be those of the one-stream run."""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    src = fill_deterministic(orc.MultiDimStacker(**kw), 5, scale=0.02)
+    prod = mds.MultiDimStacker(**kw)
+    prod.load_state_dict(src.state_dict())
+    prod = prod.to("cuda:0").eval()
+    n, chunk, size = 90, 5, (96, 64)
+    frames = torch.randint(0, 256, (n, 58, 90), generator=torch.Generator().manual_seed(4)).to(torch.uint8).cuda()
+    seq = StreamPredictor(prod, frame_size=size)
+    want = []
+    for first in range(0, n, chunk):
+        want.extend(seq.predict_batch(frames[first:first + chunk], first))
+    seq.close()
+    torch.cuda.synchronize()
+    prod.clear_plans()                      # every plan of the pipelined run is built fresh, inside the run
+    sp = StreamPredictor(prod, frame_size=size)
+    build = sp._chunk
+
+    def slow_build(*a, **k):
+        torch.cuda._sleep(300_000_000)      # ~125 ms of the caller's stream: what is queued on it next runs late
+        return build(*a, **k)
+    sp._chunk = slow_build
+    got = list(sp.predict_stream(iter(frames), 0, chunk=chunk, lanes=4))
+    torch.cuda.synchronize()
+    for j, ((pg, ig), (pw, iw)) in enumerate(zip(got, want)):
+        assert ig == iw and (pg is None) == (pw is None), j
+        if pg is not None:
+            assert (pg - pw).abs().max().item() < 1e-5, (j, pg, pw)
