@@ -321,7 +321,7 @@ class StreamPredictor:
                             me.wait_event(ev[0])
             eb = self.store.element_size() * self.f
             # the tail's input [n][b][S][f] <- store[slot of (window j, stack s)][bb]
-            self._rows(c, ("g", b, tuple(tuple(s_) for s_ in slots)), ptail.feat.tensor, eb, range(n * b * self.S), self.store, eb,
+            self._rows(c, ("g", lane, b, tuple(tuple(s_) for s_ in slots)), ptail.feat.tensor, eb, range(n * b * self.S), self.store, eb,
                        [slots[j][s_] * b + bb for j in range(n) for bb in range(b) for s_ in range(self.S)], eb)
             self._replay(c, "tail", lane)
             probs = ptail.probs.tensor.view(n, -1).clone()          # nn.Sigmoid + the TTA mean came out of the head's launch; the plan's buffer is reused by the next pass

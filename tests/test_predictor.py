@@ -245,9 +245,10 @@ def test_stream_predictor_at_the_real_frame_size():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tta,chunk", [(False, 1), (True, 1), (False, 5)])
-def test_predict_stream_lanes_over_several_ring_periods(tta, chunk):
-    """predict_stream with 4 lanes in flight over a stream long enough to wrap the raw-frame ring (165 slots) and the feature
+@pytest.mark.parametrize("tta,chunk,lanes", [(False, 1, 4), (True, 1, 4), (False, 5, 4), (False, 1, 3), (False, 5, 3), (False, 3, 2)])
+def test_predict_stream_lanes_over_several_ring_periods(tta, chunk, lanes):
+    """predict_stream with 2 - 4 lanes in flight (the ring periods are multiples of 4, not of 3: a slot pattern then comes back
+    on ANOTHER lane) over a stream long enough to wrap the raw-frame ring (165 slots) and the feature
     store (216 slots) more than twice, every frame distinct: a ring update or an encoder pass of a later step overtaking a
     reader on another lane, or a tail pass that did not wait for an encoder pass on another lane, shows up as a mismatch
     against the same frames through plain predict_batch calls on one stream (identical kernels: the bar is 1e-5)."""
@@ -266,7 +267,7 @@ def test_predict_stream_lanes_over_several_ring_periods(tta, chunk):
         want.extend(seq.predict_batch(frames[first:first + chunk], first))
     seq.close()
     sp = StreamPredictor(prod, frame_size=size, tta=tta)
-    got = list(sp.predict_stream(iter(frames), 0, chunk=chunk, lanes=4))
+    got = list(sp.predict_stream(iter(frames), 0, chunk=chunk, lanes=lanes))
     torch.cuda.synchronize()
     assert len(got) == len(want) == n and sp.encoder_passes <= -(-n // chunk) + 8
     live = 0
