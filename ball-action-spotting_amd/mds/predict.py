@@ -259,7 +259,7 @@ class StreamPredictor:
                 results[j] = r
             return results
 
-    # ------------------------------------------------------------------ two-stream software pipeline (predict_stream)
+    # ------------------------------------------------------------------ lanes (predict_stream)
     def _on(self, which, *inputs):
         """stream context of a step: the caller's stream, or - inside predict_stream - the stream of the step's lane"""
         if self._pipe is None:
