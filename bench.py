@@ -312,7 +312,8 @@ def bench_predict(args, dev, rank, world):
                 out = sp.predict_batch(fr, idx)[-1][0]
                 idx += c; done += c
             return out
-        feed(max(Wm, 28 + 6 * chunk, 6 * chunk * max(pipelined, 1) + 28))      # (every lane past its eager passes and its hipGraph capture)
+        W = max(Wm, 28 + 6 * chunk, 6 * chunk * max(pipelined, 1) + 28)       # every lane past its eager passes and its hipGraph capture
+        feed(-(-W // chunk) * chunk + K % chunk)                               # + one chunk of the size the K timed frames end with (its plans exist)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
