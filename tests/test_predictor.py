@@ -314,3 +314,36 @@ def test_predict_stream_orders_lanes_behind_buffers_made_on_the_callers_stream()
         assert ig == iw and (pg is None) == (pw is None), j
         if pg is not None:
             assert (pg - pw).abs().max().item() < 1e-5, (j, pg, pw)
+
+
+@pytest.mark.gpu
+def test_predict_stream_closed_early_joins_the_lanes_and_the_predictor_goes_on():
+    """the reference's loop breaks out at max_frame_index (scripts/ball_action/predict.py:52-53): closing the generator with
+    steps still in flight must leave nothing running behind the caller's stream, and plain predict() calls continue the SAME
+    stream of frames afterwards with the results a one-stream run gives"""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    src = fill_deterministic(orc.MultiDimStacker(**kw), 5, scale=0.02)
+    prod = mds.MultiDimStacker(**kw)
+    prod.load_state_dict(src.state_dict())
+    prod = prod.to("cuda:0").eval()
+    n, size = 80, (96, 64)
+    frames = torch.randint(0, 256, (n, 58, 90), generator=torch.Generator().manual_seed(6)).to(torch.uint8).cuda()
+    seq = StreamPredictor(prod, frame_size=size)
+    want = [seq.predict(frames[j], j) for j in range(n)]
+    seq.close()
+    sp = StreamPredictor(prod, frame_size=size)
+    got = []
+    gen = sp.predict_stream(iter(frames[:60]), 0, chunk=1, lanes=4)
+    for res in gen:
+        got.append(res)
+        if len(got) == 40:
+            break
+    gen.close()
+    # frames 40 .. 43 were already issued (look-ahead); feed the stream on from 44 through the plain API: the rings hold 0 .. 43
+    for j in range(44, n):
+        r = sp.predict(frames[j], j)
+        assert r[1] == want[j][1] and (r[0] - want[j][0]).abs().max().item() < 1e-5, j
+    for j in range(40):
+        assert got[j][1] == want[j][1] and (got[j][0] is None) == (want[j][0] is None)
+        if got[j][0] is not None:
+            assert (got[j][0] - want[j][0]).abs().max().item() < 1e-5, j
