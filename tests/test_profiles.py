@@ -51,3 +51,23 @@ def test_the_other_configs_traces_are_their_own(kind, absent):
         assert any(k.startswith("pw_fwd") for k in fams), os.path.basename(p)
         for k in absent:
             assert not any(f.startswith(k) for f in fams), (os.path.basename(p), k)
+
+
+def test_a_steady_state_predictor_frame_has_no_torch_kernel():
+    """the frame-by-frame predictor's glue (index_select x2, index_put, arange, remainder, sigmoid, fills) is
+    gone from the steady state - ring / store addressing by mds_copy_rows, sigmoid + TTA mean in head_fwd, zero arenas by
+    hipMemsetAsync.  What is left of at::native in the committed trace are one-off set-up launches (a handful of calls)."""
+    files = [p for p in _rounds("predict_fbf") if int(re.match(r"r(\d+)", os.path.basename(p)).group(1)) >= 5]
+    assert files
+    p = files[-1]
+    frames = 0
+    with open(p) as f:
+        rows = list(csv.DictReader(f))
+    for r in rows:
+        if r["Name"].startswith("stem_fwd") or "stem_fwd_kernel" in r["Name"]:
+            frames = max(frames, int(r["Calls"]))
+    assert frames >= 100, frames
+    assert any("copy_rows_kernel" in r["Name"] and int(r["Calls"]) >= 2 * frames for r in rows)
+    for r in rows:
+        if "at::native" in r["Name"]:
+            assert int(r["Calls"]) < 0.1 * frames, (r["Name"][:80], r["Calls"], frames)
