@@ -100,6 +100,33 @@ def test_frame_luma_kernel(be, w, h, pitch, count):
     assert torch.equal(dst.cpu(), surf[:, :h, :w])
 
 
+@pytest.mark.parametrize("row_bytes,src_pitch,dst_pitch,nrows", [(5220, 5220, 5220, 3), (4096, 8192, 4096, 5), (1000, 1024, 2048, 7),
+                                                                 (921600, 921600, 921600, 2), (48, 64, 48, 320)])
+def test_copy_rows_kernel(be, row_bytes, src_pitch, dst_pitch, nrows):
+    """mds_copy_rows (the predictor's ring / store addressing): dst row dst_slot[r] <- src row src_slot[r], slot numbers in the
+    kernel arguments; 16-byte vectors where the rows allow, bytes otherwise; bytes between rows and untouched slots stay"""
+    g = torch.Generator().manual_seed(row_bytes + nrows)
+    nsrc, ndst = nrows + 3, nrows + 2
+    src = torch.randint(0, 256, (nsrc, src_pitch), generator=g, dtype=torch.uint8)
+    dst0 = torch.randint(0, 256, (ndst, dst_pitch), generator=g, dtype=torch.uint8)
+    src_slot = torch.randint(0, nsrc, (nrows,), generator=g).tolist()
+    dst_slot = torch.randperm(ndst, generator=g)[:nrows].tolist()
+    sd, dd = be.t(src), be.t(dst0.clone())
+    be.call("copy_rows", cabi.make("mds_copy_rows_args", dst=dd, src=sd, dst_pitch=dst_pitch, src_pitch=src_pitch, row_bytes=row_bytes,
+                                   nrows=nrows, dst_slot=dst_slot, src_slot=src_slot))
+    be.sync()
+    want = dst0.clone()
+    for r in range(nrows):
+        want[dst_slot[r], :row_bytes] = src[src_slot[r], :row_bytes]
+    assert torch.equal(dd.cpu(), want)
+
+
+def test_copy_rows_refuses_more_rows_than_its_argument_block_holds(be):
+    t = be.t(torch.zeros(4, 16, dtype=torch.uint8))
+    a = cabi.make("mds_copy_rows_args", dst=t, src=t, dst_pitch=16, src_pitch=16, row_bytes=16, nrows=cabi.MDS_COPY_ROWS_MAX + 1)
+    assert be.lib.fn["copy_rows"](a, 0) != 0
+
+
 def test_rocdecode_backend_is_reported_missing_not_faked():
     with pytest.raises(RuntimeError, match="rocDecode"):
         open_rocdecode("video.mkv", 0)
