@@ -112,7 +112,7 @@ def test_stream_predictor_matches_reference_logic(be, tta):
     check(got, "chunks of 3")
     # predict_stream: the same passes, the encoder of step j + 1 issued beside the tail of step j on two internal HIP streams
     # (plain calls on the CPU simulator) - what it yields is what predict() returned, in order, nothing lost at the end
-    for chunk in (1, 3):
+    for chunk in ((3,) if be.name == "emu" else (1, 3)):      # (the simulator steps every kernel on the host: one pass over the stream)
         ss = StreamPredictor(prod, frame_size=size, tta=tta)
         res = list(ss.predict_stream(iter(all_frames), 0, chunk=chunk))
         assert [ip for _, ip in res] == [i - 14 for i in range(n)]
