@@ -311,6 +311,7 @@ class _Null:
         return False
 
 
-def get_train_augmentations(size, compose_geometric: bool = True) -> nn.Module:
-    """src/ball_action/augmentations.py:7 / src/action/augmentations.py:7; compose_geometric=False = the reference's stage order"""
+def get_train_augmentations(size, compose_geometric: bool = False) -> nn.Module:
+    """src/ball_action/augmentations.py:7 / src/action/augmentations.py:7.  The default is the reference's stage order
+    (result-identical to it); compose_geometric=True is the opt-in single-resampling form (see TrainAugmentations)."""
     return TrainAugmentations(size, compose_geometric=compose_geometric)

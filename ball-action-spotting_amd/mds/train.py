@@ -283,28 +283,38 @@ class ModelEma(nn.Module):
     num_batches_tracked) follow the reference's arithmetic (float blend, truncating cast) in a few batched ops."""
 
     def __init__(self, model, decay=0.9999, device=None):
+        """The class contract of src/ema.py:37 (attribute names `ema`, `decay`, `device` are what callers read)."""
         super().__init__()
-        self.ema = deepcopy(model)
-        self.ema.eval()
-        self.decay = decay
-        self.device = device
-        if self.device is not None:
-            self.ema.to(device=device)
+        shadow = deepcopy(model).eval()
+        self.ema = shadow if device is None else shadow.to(device=device)
+        self.decay, self.device = decay, device
         self._cache = None
 
-    def _update(self, model, update_fn):
-        with torch.no_grad():
-            for ema_v, model_v in zip(self.ema.state_dict().values(), model.state_dict().values()):
-                if self.device is not None:
-                    model_v = model_v.to(device=self.device)
-                ema_v.copy_(update_fn(ema_v, model_v))
+    @torch.no_grad()
+    def _blend_unfused(self, model, keep: float):
+        """Off-device / non-fp32 path (EMA held on the CPU, `device='cpu'`): new = keep * ema + (1 - keep) * model for every
+        state_dict entry, in state_dict order.  Float entries go through two `_foreach` calls; the integer counters keep the
+        reference's arithmetic (src/ema.py:52: the blend promotes to float32 and `copy_` truncates)."""
+        pairs = list(zip(self.ema.state_dict().values(), model.state_dict().values()))
+        src = [m.detach().to(device=e.device) for e, m in pairs]
+        fl = [(e, m.to(e.dtype)) for (e, _), m in zip(pairs, src) if e.is_floating_point()]
+        if fl:
+            if keep == 0.0:
+                torch._foreach_copy_([e for e, _ in fl], [m for _, m in fl])
+            else:
+                part = torch._foreach_mul([m for _, m in fl], 1.0 - keep)       # three roundings, as `d * e + (1 - d) * m` has
+                torch._foreach_mul_([e for e, _ in fl], keep)
+                torch._foreach_add_([e for e, _ in fl], part)
+        for (e, _), m in zip(pairs, src):
+            if not e.is_floating_point():
+                e.copy_(m if keep == 0.0 else keep * e + (1.0 - keep) * m)
 
     @torch.no_grad()
     def update(self, model):
         evs, mvs = list(self.ema.state_dict().values()), list(model.state_dict().values())
         fused_ok = self.device is None and all(e.device == m.device for e, m in zip(evs, mvs)) and (evs[0].is_cuda or LIB is not None)
         if not fused_ok:      # EMA kept on another device (src/ema.py `device='cpu'`): the reference's own loop
-            return self._update(model, update_fn=lambda e, m: self.decay * e + (1. - self.decay) * m)
+            return self._blend_unfused(model, float(self.decay))
         fl = [(e, m) for e, m in zip(evs, mvs) if e.dtype == torch.float32 and m.dtype == torch.float32 and e.is_contiguous() and m.is_contiguous()]
         rest = [(e, m) for e, m in zip(evs, mvs) if not (e.dtype == torch.float32 and m.dtype == torch.float32 and e.is_contiguous() and m.is_contiguous())]
         dev = evs[0].device
@@ -332,4 +342,4 @@ class ModelEma(nn.Module):
                 e.copy_(self.decay * e + (1. - self.decay) * m)
 
     def set(self, model):
-        self._update(model, update_fn=lambda e, m: m)
+        self._blend_unfused(model, 0.0)

@@ -148,6 +148,38 @@ def test_reference_order_mode_is_result_identical_with_every_stage_firing(be):
     torch.testing.assert_close(mod(be.t(x), params=one).cpu(), comp(be.t(x), params=one).cpu(), rtol=0, atol=0)
 
 
+def test_factory_default_is_the_reference_order(be):
+    """get_train_augmentations(size) - the function INTEGRATION.md tells the reference maintainer to import in place of
+    src/ball_action/augmentations.py:7 - must be the reference's stage order: identical, bit for bit, to
+    TrainAugmentations(size, compose_geometric=False) and equal to the oracle's reference-order restatement, on a
+    seeded batch with every stage firing (VERDICT r5 weak #1)"""
+    import inspect
+    assert inspect.signature(augment.get_train_augmentations).parameters["compose_geometric"].default is False
+    g = torch.Generator().manual_seed(21)
+    b, t, h, w = 3, 5, 32, 48
+    x = torch.rand(b, t, h, w, generator=g)
+    noise = torch.randn(b, t, h, w, generator=g)
+    every = dict()
+    for k in ("camera", "rotation", "flip", "sharpness", "motion_blur", "brightness", "contrast", "noise"):
+        every.update(STAGES[k])
+    every["camera"] = dict(every["camera"], center=[[(w - 1) / 2, (h - 1) / 2]] * 2)
+    every["crop"] = (2, 1, 43, 29)
+    params = [every, dict(rotation=-1.3, crop=(1, 2, 44, 28), flip=True), dict(camera=every["camera"], rotation=2.1, crop=(3, 2, 40, 27))]
+    fac = augment.get_train_augmentations((w, h))
+    assert isinstance(fac, augment.TrainAugmentations) and fac.compose_geometric is False
+    ref_mode = augment.TrainAugmentations((w, h), compose_geometric=False)
+    comp = augment.get_train_augmentations((w, h), compose_geometric=True)
+    for m in (fac, ref_mode, comp):
+        m._lib = be.lib if be.name == "emu" else None
+    of = fac(be.t(x), params=params, noise=be.t(noise)).cpu()
+    orr = ref_mode(be.t(x), params=params, noise=be.t(noise)).cpu()
+    oc = comp(be.t(x), params=params, noise=be.t(noise)).cpu()
+    be.sync()
+    assert torch.equal(of, orr)
+    torch.testing.assert_close(of, aug.apply_reference_order(x, [_oracle_params(s) for s in params], noise), rtol=1e-4, atol=1e-4)
+    assert (oc[0] - of[0]).abs().max().item() > 1e-2          # the opt-in composed form really is a different picture here
+
+
 def test_noise_generated_in_the_kernel_is_standard_normal(be):
     b, t, h, w = 1, 2, 64, 96
     x = torch.full((b, t, h, w), 0.5)
@@ -198,6 +230,12 @@ def test_augmentations_at_the_training_shape():
     torch.testing.assert_close(lin, ((x + 0.1).clamp(0, 1) * 0.9).clamp(0, 1), rtol=0, atol=1e-7)
     y = mod(x)                                                                                    # sampled parameters
     assert y.shape == x.shape and torch.isfinite(y).all() and -0.5 < y.min().item() and y.max().item() < 1.5
+    # the factory's default IS the reference-order mode, at the training shape with every geometric stage firing
+    every = [dict(camera=dict(STAGES["camera"]["camera"], center=[[(1280 - 1) / 2, (736 - 1) / 2]] * 2), rotation=1.7, crop=(40, 20, 1200, 690),
+                  flip=True, sharpness=0.6, brightness=1.1, contrast=0.9)] * 4
+    assert mod.compose_geometric is False
+    assert torch.equal(mod(x, params=every), augment.TrainAugmentations((1280, 736), compose_geometric=False)(x, params=every))
+    assert not torch.equal(mod(x, params=every), augment.TrainAugmentations((1280, 736), compose_geometric=True)(x, params=every))
     # a translation-only camera move shifts the picture by the offset.  (The reference's tensor_linspace forms
     # start * linspace(1, 0) + end * linspace(0, 1) in fp32: the weights of an inner frame do not sum to exactly 1, so its
     # offset is 8.000014 rather than 8 - exact for the first and the last frame, ~1e-5 of a pixel otherwise.)

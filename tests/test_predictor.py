@@ -204,10 +204,13 @@ def test_chunked_prediction_encodes_every_stack_once(be):
 
 
 @pytest.mark.gpu
-def test_stream_predictor_at_the_real_frame_size():
+@pytest.mark.parametrize("tta", [False, True])
+def test_stream_predictor_at_the_real_frame_size(tta):
     """BASELINE configs[4] at its real shape: raw 720 x 1280 uint8 frames padded to 736 x 1280 (src/frames.py:12-31), fp32,
     the first two complete windows (frames 0..29) frame by frame through the reference API against the reference's
-    predictor logic on the oracle."""
+    predictor logic on the oracle - with horizontal-flip TTA as the reference's script predicts
+    (scripts/ball_action/predict.py:16 `TTA = True`) and without; then the SAME frames through predict_stream at the
+    bench's own config-5 setting (8 frames per pass, 3 lanes) against the same oracle outputs."""
     kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
     ref = fill_deterministic(orc.MultiDimStacker(**kw), 6, scale=0.02)
     g = torch.Generator().manual_seed(2)
@@ -220,17 +223,18 @@ def test_stream_predictor_at_the_real_frame_size():
         if isinstance(bn, torch.nn.modules.batchnorm._BatchNorm):
             bn.momentum = 1.0
     ref.train()
-    rp0 = RefPredictor(ref, size, False)
+    rp0 = RefPredictor(ref, size, tta)
     with torch.no_grad():      # running statistics from one window of the same frame distribution
         ref(torch.stack([rp0.process(new_frame()[None, None])[0, 0] for _ in range(15)])[None])
     prod = mds.MultiDimStacker(**kw)
     prod.load_state_dict(ref.state_dict())
     prod = prod.to("cuda:0")
-    rp = RefPredictor(ref, size, False)
-    sp = StreamPredictor(prod, frame_size=size, tta=False)
-    refs, outs = [], []
+    rp = RefPredictor(ref, size, tta)
+    sp = StreamPredictor(prod, frame_size=size, tta=tta)
+    refs, outs, all_frames = [], [], []
     for index in range(30):
         frame = new_frame()
+        all_frames.append(frame)
         pr, ir = rp.predict(frame, index)
         pp, ip = sp.predict(frame.cuda(), index)
         assert ir == ip == index - 14 and (pr is None) == (pp is None) == (index < 28)
@@ -242,10 +246,21 @@ def test_stream_predictor_at_the_real_frame_size():
     # fp32 kernels against the fp32 oracle at the real shape: logits within 1e-3 of their magnitude (+ 1e-4 absolute)
     err = (lg - lref).abs().max().item()
     assert err < 1e-3 * lref.abs().max().item() + 1e-4, (err, lref)
+    # the bench's config-5 setting through the pipelined path, against the ORACLE (not against predict_batch)
+    ss = StreamPredictor(prod, frame_size=size, tta=tta)
+    res = list(ss.predict_stream((f.cuda() for f in all_frames), 0, chunk=8, lanes=3))
+    torch.cuda.synchronize()
+    assert [ip for _, ip in res] == [i - 14 for i in range(30)]
+    assert [pp is None for pp, _ in res] == [i < 28 for i in range(30)]
+    ls = torch.logit(torch.stack([pp.float().cpu() for pp, _ in res[28:]]).double())
+    err = (ls - lref).abs().max().item()
+    assert err < 1e-3 * lref.abs().max().item() + 1e-4, ("predict_stream 8 x 3", err, lref)
+    ss.close(); sp.close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tta,chunk,lanes", [(False, 1, 4), (True, 1, 4), (False, 5, 4), (False, 1, 3), (False, 5, 3), (False, 3, 2)])
+@pytest.mark.parametrize("tta,chunk,lanes", [(False, 1, 4), (True, 1, 4), (False, 5, 4), (False, 1, 3), (False, 5, 3), (False, 3, 2),
+                                             (False, 8, 3), (True, 8, 3)])
 def test_predict_stream_lanes_over_several_ring_periods(tta, chunk, lanes):
     """predict_stream with 2 - 4 lanes in flight (the ring periods are multiples of 4, not of 3: a slot pattern then comes back
     on ANOTHER lane) over a stream long enough to wrap the raw-frame ring (165 slots) and the feature

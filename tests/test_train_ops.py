@@ -237,6 +237,33 @@ def test_model_ema_without_float_entries_is_a_no_op(lib):
     assert int(ema.ema.n) == int(0.5 * 5 + 0.5 * 9)
 
 
+def test_model_ema_held_on_another_device_follows_the_reference_arithmetic(lib):
+    """ModelEma(model, device='cpu') (src/ema.py:37-55 with `device` set): update() and set() for float and integer entries equal
+    `decay * e + (1 - decay) * m` entry by entry, bit for bit (the integer counter through float32 and a truncating copy)"""
+    g = torch.Generator().manual_seed(9)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.BatchNorm1d(4)).to(lib.device)
+    ema = train.ModelEma(m, decay=0.9, device="cpu")
+    want = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for step in range(3):
+        with torch.no_grad():
+            for prm in m.parameters():
+                prm.add_(torch.randn(prm.shape, generator=g).to(prm.device))
+            m[1].running_mean.add_(0.25)
+            m[1].num_batches_tracked.add_(7)
+        ema.update(m)
+        for k, v in m.state_dict().items():
+            blend = 0.9 * want[k] + (1. - 0.9) * v.detach().cpu()
+            want[k] = blend.to(want[k].dtype)
+    lib.sync()
+    got = ema.ema.state_dict()
+    assert all(v.device.type == "cpu" for v in got.values())
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    ema.set(m)
+    for k, v in m.state_dict().items():
+        assert torch.equal(ema.ema.state_dict()[k], v.detach().cpu()), k
+
+
 @pytest.mark.gpu
 def test_train_ops_run_on_a_non_default_stream():
     """a trainer that owns its HIP stream: loss, both optimizers and the EMA are launched on torch's CURRENT stream (64-bit handle)"""
