@@ -284,7 +284,9 @@ def test_predict_stream_lanes_over_several_ring_periods(tta, chunk, lanes):
     sp = StreamPredictor(prod, frame_size=size, tta=tta)
     got = list(sp.predict_stream(iter(frames), 0, chunk=chunk, lanes=lanes))
     torch.cuda.synchronize()
-    assert len(got) == len(want) == n and sp.encoder_passes <= -(-n // chunk) + 8
+    # one encoder pass per chunk in steady state; the start of the stream costs extra passes (the first complete windows are run
+    # frame by frame - 5 new stacks each - and the stacks of frames before the first window are encoded when first needed)
+    assert len(got) == len(want) == n and sp.encoder_passes <= -(-n // chunk) + 8 + 3 * chunk
     live = 0
     for j, ((pg, ig), (pw, iw)) in enumerate(zip(got, want)):
         assert ig == iw == j - 14 and (pg is None) == (pw is None), j
