@@ -1,0 +1,471 @@
+// k_c3.hip — stride-1 3x3 convolutions (forward and stride-1 data gradient) with the FILTER IN REGISTERS:
+// a row-streaming implicit GEMM for gfx950 (round 6).
+//
+// The persistent kernel of k_conv.hip keeps the filter slab in LDS and reads one operand fragment per MFMA operand: at
+// 0.5 ds_read_b128 per MFMA its four waves ask the LDS for half of what it can deliver, stage every patch through VGPRs
+// (13-cycle ds_write_b128) behind two block barriers per tile, and reach 13-20 % of the MFMA peak on layers whose HBM floor
+// is 2-3x below their time.  These layers have tiny filters (9 x Cin x Cout <= 74 KB) and millions of pixels, so here
+//
+//   * every CONSUMER wave (4 per block, one per SIMD) keeps its slice of the filter in VGPRs for the whole launch
+//     (<= 180 registers) - weight fragments cost no LDS read at all;
+//   * a wave owns a 16-pixel-wide column strip of a band and walks DOWN the image: for one input row it reads each
+//     (dx, channel) fragment ONCE from LDS and issues the MFMAs of all three dy taps into three ROLLING accumulator sets
+//     (output rows r-1, r, r+1) - one ds_read_b128 per 3 x NF MFMAs (NF = 16-channel output fragments per wave), i.e.
+//     5-17 % of the LDS read bandwidth; an output row is finished, converted and stored when its third input row is done;
+//   * the input rows (+ one halo pixel either side, + the residual operand's row) come through a ring of rows in LDS
+//     filled by LDS-DMA (global_load_lds_dwordx4) from dedicated PRODUCER waves, RA rows ahead of the consumers and
+//     straight across work-item boundaries: no staging registers, no ds_write, one bare s_barrier per row.  The producers'
+//     vmcnt counts nothing but their own DMA, so the counted wait is exact; the consumers' vmcnt carries only their
+//     output stores, which nothing ever waits for;
+//   * the 16-byte parts of a pixel are rotated by a function of the pixel index on the way in (the DMA lane picks its
+//     SOURCE address; the LDS image stays lane-linear), which makes the shifted fragment reads bank-conflict free
+//     (tools/probes/c3_swizzle_check.py);
+//   * out-of-image pixels and rows are DMA'd from a zero page, so every row of every item issues the same number of
+//     pieces (exact vmcnt) and the inner loop has no masks.
+//
+// Work item = (image, band of WB columns, segment of rows); a block walks items blockIdx.x, + gridDim.x, ...
+// bf16 only (fp32 plans keep k_conv.hip); prologue-free inputs only (activated / materialised tensors).
+#include <stdlib.h>
+#include <type_traits>
+#include "gemm.h"
+
+struct C3Args {
+  const bf16_t* x;
+  const bf16_t* w;     // [Cout][wtaps][Cin]
+  bf16_t* y;
+  const bf16_t* res;   // optional, indexed like y
+  double* stats;       // optional [SLOTS][2][Cout]
+  int N, H, W, wtaps;
+  int tapw[9];         // weight slot of tap (dy, dx) at [3 * (dy + 1) + (dx + 1)]
+  int nbands, nseg, rps, items;
+  int RA, NR;
+  int dbg;             // MDS_KNOB_C3_DBG bits
+  void* trace;         // C3_TRACE builds: 160 x 8 x 4 cycle stamps of one block (passed in mds_conv_fwd_args.epi.scale, mode NONE)
+};
+
+__device__ __attribute__((aligned(256))) unsigned int c3_zero_page[64];
+#define C3_DUMP_BYTES (128 * 1024)
+__device__ __attribute__((aligned(256))) unsigned int c3_dump_page[C3_DUMP_BYTES / 4 + 64];   // one whole output row: where rows outside an item are stored
+
+template <int CIN> struct C3Swz;     // part' = (part + ((A * pixel) >> SH)) % (CIN / 8): tools/probes/c3_swizzle_check.py search
+template <> struct C3Swz<16> { static constexpr int A = 0, SH = 0; };
+template <> struct C3Swz<32> { static constexpr int A = 1, SH = 1; };
+template <> struct C3Swz<48> { static constexpr int A = 0, SH = 0; };
+template <> struct C3Swz<64> { static constexpr int A = 1, SH = 0; };
+template <> struct C3Swz<128> { static constexpr int A = 2, SH = 0; };
+template <> struct C3Swz<192> { static constexpr int A = 1, SH = 0; };
+
+template <int CIN, int NF, int NSPL, int SPW, bool RES> struct C3Cfg {
+  static constexpr int PP = CIN / 8;                 // 16-byte parts per input pixel
+  static constexpr int KSR = (3 * PP + 3) / 4;       // k-steps (32 channels) of one input row: 3 dx x CIN, flattened
+  static constexpr int NSG = 4 / NSPL;               // strip groups among the four consumer waves
+  static constexpr int WB = 16 * NSG * SPW;          // band width (output columns)
+  static constexpr int COUT = 16 * NF * NSPL;
+  static constexpr int CP = COUT / 8;                // 16-byte parts per output pixel (residual operand)
+  static constexpr int RPX = (WB + 2) * PP;          // 16-byte slots of one input row of the band (+ halo)
+  static constexpr int RPXP = RES ? (RPX + 63) / 64 * 64 : RPX;   // the residual row starts on a DMA-piece boundary: a piece is all input or all residual
+  static constexpr int RS = RPXP + (RES ? WB * CP : 0);
+  static constexpr int PIECES = (RS + 63) / 64;      // LDS-DMA instructions per row
+  static constexpr int ROWB = RS * 16;
+};
+
+struct C3Item {
+  int n, x0, r0, r1;
+};
+MDS_DEV C3Item c3_item(const C3Args& g, int it, int WB) {
+  const int seg = it % g.nseg, t = it / g.nseg;
+  const int band = t % g.nbands, n = t / g.nbands;
+  C3Item r;
+  r.n = n; r.x0 = band * WB; r.r0 = seg * g.rps;
+  r.r1 = r.r0 + g.rps < g.H ? r.r0 + g.rps : g.H;
+  return r;
+}
+
+template <int NF> struct C3Out;
+template <> struct C3Out<1> {
+  static MDS_DEV void st(bf16_t* p, const float (&v)[4]) { store4(p, v); }
+};
+template <> struct C3Out<2> {
+  static MDS_DEV void st(bf16_t* p, const float (&v)[8]) { store8(p, v); }
+};
+template <> struct C3Out<3> {
+  static MDS_DEV void st(bf16_t* p, const float (&v)[12]) {
+    float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]}, c[4] = {v[8], v[9], v[10], v[11]};
+    store4(p, a); store4(p + 4, b); store4(p + 8, c);
+  }
+};
+
+#ifdef C3_TRACE   /* experiment build (make c3trace): cycle stamps of block C3_TRACE, [batch][wave][phase] in LDS behind the ring, dumped through g.trace */
+#define C3_STAMP(b_, ph_) do { if (trc && lane == 0 && (b_) < 160) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+    asm volatile("ds_write_b64 %0, %1" ::"v"((lds_t)(trc_base + (((b_) * 8 + wave) * 4 + (ph_)) * 8)), "v"(t_) : "memory"); } } while (0)
+#else
+#define C3_STAMP(b_, ph_) ((void)0)
+#endif
+
+template <int CIN, int NF, int NSPL, int SPW, int NPW, bool RES, bool STATS, bool MASKED>
+__global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
+  typedef C3Cfg<CIN, NF, NSPL, SPW, RES> CF;
+  constexpr int PP = CF::PP, KSR = CF::KSR, WB = CF::WB, COUT = CF::COUT, CP = CF::CP, RPX = CF::RPX, RPXP = CF::RPXP, RS = CF::RS;
+  constexpr int PIECES = CF::PIECES, ROWB = CF::ROWB;
+  MDS_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int G = gridDim.x;
+  // entries (rows to stage and to consume) of this block: every item has (rows + 2)
+  int E = 0;
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item(g, it, WB);
+    E += im.r1 - im.r0 + 2;
+  }
+
+#ifdef C3_TRACE
+  const bool trc = blockIdx.x == C3_TRACE && g.trace != nullptr;
+  const lds_t trc_base = lds_addr_of(smem) + (lds_t)(g.NR * ROWB);
+  int tb = 0;
+#endif
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers: LDS-DMA, RA rows ahead
+    MDS_SETPRIO(3);       // the DMA stream is what every barrier waits for
+    const int pw = wave - 4;
+    constexpr int PCWMAX = (PIECES + NPW - 1) / NPW;
+    const int pcw = (PIECES - pw + NPW - 1) / NPW;        // pieces this wave issues per row
+    // what this lane moves in each of its pieces: constant over the launch (a piece = 64 consecutive 16-byte slots of a ring row)
+    int dcol[PCWMAX], eoff[PCWMAX];          // column - x0 (INT_MIN/2: nothing: the gap in front of the residual row / past the end); element offset inside the pixel
+#pragma unroll
+    for (int j = 0; j < PCWMAX; ++j) {
+      const int sg_ = 64 * (pw + NPW * j) + lane;
+      if (sg_ < RPX) {
+        const int p = sg_ / PP, psw = sg_ - p * PP;
+        const int rot = ((C3Swz<CIN>::A * p) >> C3Swz<CIN>::SH) % PP;
+        dcol[j] = p - 1; eoff[j] = 8 * ((psw - rot + PP) % PP);
+      } else if (sg_ >= RPXP && sg_ < RS) {
+        const int t = sg_ - RPXP, p = t / CP;
+        dcol[j] = p; eoff[j] = 8 * (t - p * CP);
+      } else {
+        dcol[j] = -(1 << 30); eoff[j] = 0;
+      }
+    }
+    const lds_t ring = lds_addr_of(smem);
+    int hit = blockIdx.x, hk = 0;                           // head of the DMA stream: (item, row index inside it)
+    C3Item him = c3_item(g, hit < g.items ? hit : 0, WB);
+    int C = 0, hslot = 0;
+    // per item: this lane's byte offset inside an input / residual row for each of its pieces (-1: out of the image -> zero page)
+    int boff[PCWMAX];
+    const char *xrow0 = nullptr, *rrow0 = nullptr;          // row r0 - 1 of the input / row r0 - 2 of the residual operand (entry 0's rows)
+    auto open_item = [&]() {
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const bool isres = RES && 64 * (pw + NPW * j) >= RPXP;
+        const int gx = him.x0 + dcol[j];
+        boff[j] = (gx >= 0 && gx < g.W) ? (gx * (isres ? COUT : CIN) + eoff[j]) * 2 : -1;
+      }
+      xrow0 = (const char*)g.x + ((long)him.n * g.H + him.r0 - 1) * g.W * CIN * 2;
+      if (RES) rrow0 = (const char*)g.res + ((long)him.n * g.H + him.r0 - 2) * g.W * COUT * 2;
+    };
+    open_item();
+    auto issue = [&]() {
+      const int ri = him.r0 - 1 + hk, ro = ri - 1;
+      const bool xok = ri >= 0 && ri < g.H, rok = ro >= 0 && ro < g.H;
+      const char* xr = xrow0 + (long)hk * g.W * CIN * 2;
+      const char* rr = RES ? rrow0 + (long)hk * g.W * COUT * 2 : nullptr;
+      const lds_t dst = ring + (lds_t)(hslot * ROWB);
+      hslot = hslot + 1 == g.NR ? 0 : hslot + 1;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const int pi = pw + NPW * j;
+        if (pi < PIECES) {
+          const bool isres = RES && 64 * pi >= RPXP;              // wave-uniform
+          const char* base = isres ? rr : xr;
+          const bool rowok = isres ? rok : xok;
+          const char* src = (rowok && boff[j] >= 0) ? base + boff[j] : (const char*)c3_zero_page;
+          if (dcol[j] > -(1 << 29)) glds16(src, dst + (lds_t)(pi * 1024));
+        }
+      }
+      ++C;
+      if (++hk == him.r1 - him.r0 + 2) {
+        hk = 0; hit += G;
+        if (hit < g.items) { him = c3_item(g, hit, WB); open_item(); }
+      }
+    };
+    while (C < g.RA && C < E) issue();
+    // the consumers take their rows in batches of three (the rolling accumulators' period) behind ONE barrier: per batch wait
+    // for its last row, arrive, then top the stream up to RA rows ahead of the next batch (ring: RA + 3 rows)
+    int e0 = 0;
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3_item(g, it, WB);
+      const int K = im.r1 - im.r0 + 2;
+      for (int k0 = 0; k0 < K; k0 += 3) {
+        const int n = K - k0 < 3 ? K - k0 : 3;
+        C3_STAMP(tb, 0);
+        wait_vm_dyn(pcw * (C - e0 - n));      // rows e0 .. e0 + n - 1 have landed; the rows issued after them stay in flight
+        C3_STAMP(tb, 1);
+        raw_barrier();
+        C3_STAMP(tb, 2);
+        e0 += n;
+        while (C < e0 + g.RA && C < E) issue();   // into slots of rows < e0 - n: every consumer is past them
+        C3_STAMP(tb, 3);
+#ifdef C3_TRACE
+        ++tb;
+#endif
+      }
+    }
+#ifdef C3_TRACE
+    raw_barrier();
+#endif
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  MDS_SETPRIO(2);
+  const int i = lane & 15, q = lane >> 4;
+  const int nsl = wave % NSPL, sg = wave / NSPL;
+  const int cb = nsl * 16 * NF;                              // first output channel of this wave's slice
+  // filter slice -> registers.  MFMA row (nf, i) is output channel cb + 4 NF (i >> 2) + 4 nf + (i & 3), so that accumulator
+  // lane (i, q) ends up holding the 4 NF CONSECUTIVE channels cb + 4 NF q ... of its pixel (one 8 NF-byte store)
+  u16x8 wr[3][KSR][NF];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int s = 0; s < KSR; ++s)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int gr = 4 * s + q;
+        u16x8 v = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (gr < 3 * PP) {
+          const int dxi = gr / PP, part = gr - dxi * PP;
+          const int slot = dxi == 0 ? g.tapw[3 * d] : (dxi == 1 ? g.tapw[3 * d + 1] : g.tapw[3 * d + 2]);
+          const int ch = cb + 4 * NF * (i >> 2) + 4 * nf + (i & 3);
+          v = *(const u16x8*)(g.w + ((long)ch * g.wtaps + slot) * CIN + 8 * part);
+        }
+        wr[d][s][nf] = v;
+      }
+  // LDS byte offset (inside a ring row) of this lane's fragment of k-step s of its first strip: pixel i + dxi, part rotated by the pixel
+  int xoff[KSR];
+#pragma unroll
+  for (int s = 0; s < KSR; ++s) {
+    const int gr = (4 * s + q) < 3 * PP ? 4 * s + q : 3 * PP - 1;     // zero-weight tail granules read a legal address
+    const int dxi = gr / PP, part = gr - dxi * PP, p = i + dxi;
+    xoff[s] = (p * PP + (part + ((C3Swz<CIN>::A * p) >> C3Swz<CIN>::SH)) % PP) * 16 + sg * SPW * 256 * PP;
+  }
+  f32x4 acc[3][SPW][NF];
+  float ps[4 * NF], pss[4 * NF];
+#pragma unroll
+  for (int c = 0; c < 4 * NF; ++c) { ps[c] = 0.f; pss[c] = 0.f; }
+  int slot = 0;                                              // ring slot of the next row to consume
+  constexpr int FR = SPW * KSR;                              // operand fragments of one row
+  constexpr int CH = FR <= 6 ? FR : 6;                       // fragments per register set ("chunk"): two sets ping-pong
+  constexpr int NCH = (FR + CH - 1) / CH;
+  bf16_t* const dump = (bf16_t*)c3_dump_page;               // where the rows an item does not own are stored (zeros)
+
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item(g, it, WB);
+    const int K = im.r1 - im.r0 + 2;
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+      for (int st = 0; st < SPW; ++st)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[sl][st][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // One batch = up to three consecutive rows behind one barrier, as straight-line code: the fragment reads of chunk c + 1 are
+    // issued before the MFMAs of chunk c (two register sets); the first MFMA into an accumulator set (tap row dy = -1, first
+    // k-step) takes a zero C operand, so finished sets are never cleared; the first batch of an item (HEAD) leaves out the taps
+    // that would feed rows above the item, so those sets stay zero and their "output rows" are zeros written to a dump row
+    // (a scalar pointer select): no masks and no branch in the conversion / statistics / store code, which the scheduler
+    // can then spread among the MFMAs.
+    auto batch = [&](auto fullc, auto headc, int k0, int n) {
+      constexpr bool FULL = decltype(fullc)::value, HEAD = decltype(headc)::value;
+      C3_STAMP(tb, 0);
+      asm volatile("" ::: "memory");
+      raw_barrier();                      // the batch's rows are in LDS (the producers waited for their DMA before arriving)
+      asm volatile("" ::: "memory");
+      C3_STAMP(tb, 1);
+      const char* rows[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        rows[j] = smem + slot * ROWB;
+        if (FULL || j < n) slot = slot + 1 == g.NR ? 0 : slot + 1;
+      }
+      u16x8 xs[2][CH];
+      auto load_chunk = [&](int c) {       // (c is a compile-time constant after unrolling)
+        const int j = c / NCH, cc = c - j * NCH;
+        if (FULL || j < n) {
+#pragma unroll
+          for (int f = 0; f < CH; ++f) {
+            const int fr = cc * CH + f;
+            if (fr < FR) xs[c & 1][f] = *(const u16x8*)(rows[j] + (fr / KSR) * 256 * PP + xoff[fr % KSR]);
+          }
+        }
+      };
+      load_chunk(0);
+#pragma unroll
+      for (int c = 0; c < 3 * NCH; ++c) {
+        const int j = c / NCH, cc = c - j * NCH;
+        if (c + 1 < 3 * NCH) load_chunk(c + 1);
+        if (FULL || j < n) {
+#pragma unroll
+          for (int f = 0; f < CH; ++f) {
+            const int fr = cc * CH + f;
+            if (fr < FR) {
+              const int st = fr / KSR, s = fr % KSR;
+#pragma unroll
+              for (int d = 2; d >= 0; --d) {
+                if (HEAD && d > j) continue;          // input row r0 - 1 + j, tap row d - 1: output row r0 + j - d is above the item
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                  if (d == 0 && s == 0) {
+                    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    mma16(wr[d][s][nf], xs[c & 1][f], z);
+                    acc[(j + 4 - d) % 3][st][nf] = z;
+                  } else {
+                    mma16(wr[d][s][nf], xs[c & 1][f], acc[(j + 4 - d) % 3][st][nf]);
+                  }
+                }
+              }
+            }
+          }
+          if (cc == NCH - 1) {
+            // output row r0 + k - 2 has seen its three input rows (phase j = k % 3: batches start at multiples of three)
+            const int SL = (j + 2) % 3;
+            const int k = k0 + j, ro = im.r0 + k - 2;
+            const bool rowok = k >= 2 && ro < im.r1;                                           // wave-uniform
+            bf16_t* const orow = rowok ? g.y + ((long)im.n * g.H + ro) * g.W * COUT : dump;    // a scalar select
+#pragma unroll
+            for (int st = 0; st < SPW; ++st) {
+              const int cl = 16 * (sg * SPW + st) + i, gx = im.x0 + cl;
+              float v[4 * NF];
+#pragma unroll
+              for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * nf + r] = acc[SL][st][nf][r];
+              if (RES) {
+                const bf16_t* rp = (const bf16_t*)(rows[j] + RPXP * 16) + cl * COUT + cb + 4 * NF * q;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                  const u16x4 rv = *(const u16x4*)(rp + 4 * nf);
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) v[4 * nf + r] += bf2f(rv[r]);
+                }
+              }
+              bf16_t* dst = orow + gx * COUT + cb + 4 * NF * q;
+              if (MASKED) {                           // ragged last band: columns past the image go to the dump row's head
+                const bool ok = gx < g.W;
+                dst = ok ? dst : dump + lane * 16;
+                if (STATS) {
+#pragma unroll
+                  for (int c2 = 0; c2 < 4 * NF; ++c2) v[c2] = ok ? v[c2] : 0.f;
+                }
+              }
+              C3Out<NF>::st(dst, v);
+              if (STATS) {
+#pragma unroll
+                for (int c2 = 0; c2 < 4 * NF; ++c2) { ps[c2] += v[c2]; pss[c2] += v[c2] * v[c2]; }
+              }
+            }
+          }
+        }
+      }
+    };
+    for (int k0 = 0; k0 < K; k0 += 3) {
+      if (k0 + 3 <= K) {
+        if (k0 == 0) batch(std::true_type(), std::true_type(), k0, 3);
+        else batch(std::true_type(), std::false_type(), k0, 3);
+      } else {
+        if (k0 == 0) batch(std::false_type(), std::true_type(), k0, K - k0);
+        else batch(std::false_type(), std::false_type(), k0, K - k0);
+      }
+      C3_STAMP(tb, 2);
+#ifdef C3_TRACE
+      ++tb;
+#endif
+    }
+  }
+#ifdef C3_TRACE
+  raw_barrier();
+  if (trc) {
+    const unsigned long long* tl = (const unsigned long long*)(smem + g.NR * ROWB);
+    for (int e = tid; e < 160 * 32; e += 256) ((unsigned long long*)g.trace)[e] = tl[e];
+  }
+#endif
+  if (STATS) {
+    double* st = g.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * COUT;
+#pragma unroll
+    for (int c = 0; c < 4 * NF; ++c) {
+      const float a = sum_over_i16(ps[c]), b = sum_over_i16(pss[c]);
+      if (i == 0) {
+        atomicAdd(st + cb + 4 * NF * q + c, (double)a);
+        atomicAdd(st + COUT + cb + 4 * NF * q + c, (double)b);
+      }
+    }
+  }
+}
+
+// host side ------------------------------------------------------------------------------------------------------------
+template <int CIN, int NF, int NSPL, int SPW, int NPW>
+static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
+  typedef C3Cfg<CIN, NF, NSPL, SPW, true> CFR;
+  typedef C3Cfg<CIN, NF, NSPL, SPW, false> CFN;
+  const bool res = a->residual != nullptr, stats = a->stats != nullptr;
+  const int WB = CFN::WB, rowb = res ? CFR::ROWB : CFN::ROWB, pieces = res ? CFR::PIECES : CFN::PIECES;
+  C3Args g;
+  g.x = (const bf16_t*)a->x; g.w = (const bf16_t*)a->w; g.y = (bf16_t*)a->y; g.res = (const bf16_t*)a->residual; g.stats = a->stats;
+  g.N = a->N; g.H = a->IH; g.W = a->IW; g.wtaps = a->wtaps;
+  for (int t = 0; t < 9; ++t) g.tapw[t] = tapw[t];
+  // rows in flight: ~40 KB per CU ahead of the consumers (HBM latency x a CU's share of the bandwidth), at least 3 rows;
+  // the producers' vmcnt (6 bits) carries pcw * (RA - 1) pieces
+  const int pcw = (pieces + NPW - 1) / NPW;
+  int RA = (40 * 1024 + rowb - 1) / rowb;
+  if (RA < 3) RA = 3;
+  while (RA > 3 && pcw * (RA - 1) > 40) --RA;
+  int NR = RA + 3;
+  while ((size_t)NR * rowb > 150 * 1024 && RA > 3) { --RA; NR = RA + 3; }
+  if ((size_t)NR * rowb > 150 * 1024) return 0;
+  g.RA = RA; g.NR = NR; g.dbg = mds_knob(MDS_KNOB_C3_DBG); g.trace = (void*)a->epi.scale;
+  // items: bands x row segments, the segment count that minimises the longest block's rows (+2 halo rows, + a fill per item)
+  int CUS = 256;
+  if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);      // tests: few blocks, many items each
+  g.nbands = cdiv(a->IW, WB);
+  long best = -1;
+  for (int ns = 1; ns <= 64 && ns <= a->IH; ++ns) {
+    const int rps = cdiv(a->IH, ns), nsr = cdiv(a->IH, rps);
+    const long items = (long)a->N * g.nbands * nsr;
+    const long per = (items + CUS - 1) / CUS;
+    const long cost = per * (rps + 2 + 2);
+    if (best < 0 || cost < best) { best = cost; g.nseg = nsr; g.rps = rps; g.items = (int)items; }
+  }
+  const int grid = g.items < CUS ? g.items : CUS;
+  size_t smem = (size_t)NR * rowb;
+#ifdef C3_TRACE
+  smem += 160 * 32 * 8;
+#endif
+  dim3 block(256 + 64 * NPW);
+  const bool masked = a->IW % WB != 0;
+  if ((size_t)a->IW * CFN::COUT * 2 > C3_DUMP_BYTES) return 0;
+#define C3_GO(R, S) do { if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, R, S, true>), dim3(grid), block, smem, stream, g); \
+                         else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, R, S, false>), dim3(grid), block, smem, stream, g); } while (0)
+  if (res) { if (stats) return 0; C3_GO(true, false); }      // (a residual operand and statistics never meet in the network)
+  else { if (stats) C3_GO(false, true); else C3_GO(false, false); }
+#undef C3_GO
+  return 1;
+}
+
+// 1 = launched, 0 = not a shape of this kernel (the caller goes on to k_conv.hip's kernels)
+int c3_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
+  if (mds_knob(MDS_KNOB_C3) == 1) return 0;
+  if (a->dtype != MDS_BF16 || a->is != 1 || a->os != 1 || a->ntaps != 9 || a->ngroups > 1) return 0;
+  if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE) return 0;
+  if (a->A != a->OH || a->B != a->OW || a->OH != a->IH || a->OW != a->IW || a->oy0 || a->ox0) return 0;
+  if ((long)a->IH * a->IW * (a->Cin > a->Cout ? a->Cin : a->Cout) >= (1L << 30)) return 0;
+  int tapw[9];
+  for (int t = 0; t < 9; ++t) tapw[t] = -1;
+  for (int t = 0; t < 9; ++t) {
+    if (a->dy[t] < -1 || a->dy[t] > 1 || a->dx[t] < -1 || a->dx[t] > 1) return 0;
+    tapw[3 * (a->dy[t] + 1) + a->dx[t] + 1] = a->wi[t];
+  }
+  for (int t = 0; t < 9; ++t) if (tapw[t] < 0 || tapw[t] >= a->wtaps) return 0;
+  const long rows = (long)a->N * a->IH * a->IW;
+  if (rows < 16384 && mds_knob(MDS_KNOB_C3) != 2) return 0;      // small launches (inference, tests of the old kernels): k_conv.hip
+  const bool npw4 = (mds_knob(MDS_KNOB_C3_DBG) & 16) != 0;
+  if (a->Cin == 128 && a->Cout == 32) return npw4 ? c3_launch<128, 1, 2, 1, 4>(a, tapw, stream) : c3_launch<128, 1, 2, 1, 2>(a, tapw, stream);
+  if (a->Cin == 32 && a->Cout == 128) return npw4 ? c3_launch<32, 2, 4, 2, 4>(a, tapw, stream) : c3_launch<32, 2, 4, 2, 2>(a, tapw, stream);
+  return 0;
+}

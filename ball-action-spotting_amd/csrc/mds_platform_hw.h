@@ -55,6 +55,7 @@ MDS_DEV void mds_wait_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // gfx9
 #define MDS_CHAIN_PRIO_LEVEL 3
 #endif
 #define MDS_CHAIN_PRIO() __builtin_amdgcn_s_setprio(MDS_CHAIN_PRIO_LEVEL)
+#define MDS_SETPRIO(n) __builtin_amdgcn_s_setprio(n)   /* a role's issue priority inside one kernel (producer / consumer waves) */
 #define MDS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MDS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  /* wave-uniform value -> scalar register */
 #define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]

@@ -46,6 +46,7 @@ MDS_DEV void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
 }
 MDS_DEV void mds_wait_stores() {}
 #define MDS_CHAIN_PRIO() ((void)0)
+#define MDS_SETPRIO(n) ((void)0)
 #define MDS_SCHED_FENCE() ((void)0)
 #define MDS_UNIFORM(x) (x)
 #define MDS_DYN_SMEM(name) char* name = hipemu::dyn_smem()

@@ -221,6 +221,50 @@ def test_conv_wgrad(be, dt, N, H, W, Cin, Cout, stride, mode):
     assert_close(dw, ww.grad, dt, scale=(N * OH * OW) ** 0.5, msg="dw")
 
 
+C3_CASES = [  # N, H, W, Cin, Cout, residual, statistics, block cap (0 = default grid)
+    (2, 13, 37, 32, 128, False, True, 0),      # forward shape of blocks.1.1 / 2.0's stride-1 sibling: ragged band, two images
+    (1, 23, 64, 32, 128, False, True, 3),      # three blocks walk several items each: the DMA ring runs across item boundaries
+    (2, 11, 21, 128, 32, True, False, 0),      # its data gradient: residual operand through the ring
+    (1, 40, 70, 128, 32, True, False, 2),
+    (1, 9, 33, 128, 32, False, False, 1),      # one block, every item; no residual
+    (1, 3, 16, 32, 128, False, True, 0),       # fewer rows than the ring is deep
+    (1, 2, 15, 128, 32, True, False, 0),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,res,stats,blocks", C3_CASES)
+def test_c3_filter_in_registers(be, N, H, W, Cin, Cout, res, stats, blocks):
+    """k_c3.hip (bf16, stride 1, no prologue): producer / consumer row ring, rolling output rows, rotated LDS parts, zero-page
+    borders - against torch's conv2d; MDS_KNOB_C3 = 2 sends every legal shape there whatever its size"""
+    code, tdt = DT["bf16"]
+    g = gen(H * W + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g).to(tdt)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(tdt)
+    r = torch.randn(N, H, W, Cout, generator=g).to(tdt) if res else None
+    dy, dx, wi = geo.taps_fwd(1, 1)
+    y = torch.full((N, H, W, Cout), float("nan")).to(tdt).to(be.device)
+    st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, Cout, device=be.device, dtype=torch.float64) if stats else None
+    args = cabi.make("mds_conv_fwd_args", dtype=code, N=N, IH=H, IW=W, Cin=Cin, OH=H, OW=W, Cout=Cout, A=H, B=W, oy0=0, ox0=0, os=1,
+                     **{"is": 1}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9, x=be.t(nhwc(x)), w=be.t(pack(w, "oi", tdt)), y=y,
+                     pro=cabi.pro(0), residual=be.t(r) if res else None, stats=st)
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        be.call("conv_fwd", args)
+        be.sync()
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+    ref = nhwc(ref_conv(x.float(), w.float(), 1))
+    if stats:
+        s = st.sum(0).cpu()
+        assert_close(s[0], ref.sum((0, 1, 2)), "bf16", scale=(N * H * W) ** 0.5, msg="sum")
+        assert_close(s[1], (ref * ref).sum((0, 1, 2)), "bf16", scale=(N * H * W) ** 0.5, msg="sumsq")
+    if res:
+        ref = ref + r.float()
+    assert_close(y, ref, "bf16", msg="y")
+
+
 def _rand_cases(n, seed):
     import random
     r = random.Random(seed)
