@@ -95,6 +95,9 @@ template <> struct C3Out<3> {
   }
 };
 
+#ifndef C3_ABL
+#define C3_ABL 0   /* experiment builds (make c3abl ABL=n): 1 no output stores, 2 no statistics, 4 fragment reads replaced by a register, 8 no MFMAs */
+#endif
 #ifdef C3_TRACE   /* experiment build (make c3trace): cycle stamps of block C3_TRACE, [batch][wave][phase] in LDS behind the ring, dumped through g.trace */
 #define C3_STAMP(b_, ph_) do { if (trc && lane == 0 && (b_) < 160) { const unsigned long long t_ = __builtin_readcyclecounter(); \
     asm volatile("ds_write_b64 %0, %1" ::"v"((lds_t)(trc_base + (((b_) * 8 + wave) * 4 + (ph_)) * 8)), "v"(t_) : "memory"); } } while (0)
@@ -148,36 +151,48 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
     int hit = blockIdx.x, hk = 0;                           // head of the DMA stream: (item, row index inside it)
     C3Item him = c3_item(g, hit < g.items ? hit : 0, WB);
     int C = 0, hslot = 0;
-    // per item: this lane's byte offset inside an input / residual row for each of its pieces (-1: out of the image -> zero page)
-    int boff[PCWMAX];
-    const char *xrow0 = nullptr, *rrow0 = nullptr;          // row r0 - 1 of the input / row r0 - 2 of the residual operand (entry 0's rows)
+    // per item and piece: this lane's source address for the NEXT row and what it advances by per row (lanes whose column is
+    // outside the image stay on the zero page with step 0) - a piece of a row inside the image is then one 64-bit add, the
+    // M0 write and the DMA instruction
+    const char* cur[PCWMAX];
+    unsigned step[PCWMAX];
     auto open_item = [&]() {
+      const char* xrow0 = (const char*)g.x + ((long)him.n * g.H + him.r0 - 1) * g.W * CIN * 2;                   // entry 0's rows:
+      const char* rrow0 = RES ? (const char*)g.res + ((long)him.n * g.H + him.r0 - 2) * g.W * COUT * 2 : nullptr;   // r0 - 1 / r0 - 2
 #pragma unroll
       for (int j = 0; j < PCWMAX; ++j) {
         const bool isres = RES && 64 * (pw + NPW * j) >= RPXP;
         const int gx = him.x0 + dcol[j];
-        boff[j] = (gx >= 0 && gx < g.W) ? (gx * (isres ? COUT : CIN) + eoff[j]) * 2 : -1;
+        const bool ok = gx >= 0 && gx < g.W;
+        cur[j] = ok ? (isres ? rrow0 : xrow0) + (gx * (isres ? COUT : CIN) + eoff[j]) * 2 : (const char*)c3_zero_page;
+        step[j] = ok ? (unsigned)(g.W * (isres ? COUT : CIN) * 2) : 0u;
       }
-      xrow0 = (const char*)g.x + ((long)him.n * g.H + him.r0 - 1) * g.W * CIN * 2;
-      if (RES) rrow0 = (const char*)g.res + ((long)him.n * g.H + him.r0 - 2) * g.W * COUT * 2;
     };
     open_item();
     auto issue = [&]() {
       const int ri = him.r0 - 1 + hk, ro = ri - 1;
-      const bool xok = ri >= 0 && ri < g.H, rok = ro >= 0 && ro < g.H;
-      const char* xr = xrow0 + (long)hk * g.W * CIN * 2;
-      const char* rr = RES ? rrow0 + (long)hk * g.W * COUT * 2 : nullptr;
+      const bool xok = ri >= 0 && ri < g.H, rok = !RES || (ro >= 0 && ro < g.H);
       const lds_t dst = ring + (lds_t)(hslot * ROWB);
       hslot = hslot + 1 == g.NR ? 0 : hslot + 1;
+      if (xok && rok) {
 #pragma unroll
-      for (int j = 0; j < PCWMAX; ++j) {
-        const int pi = pw + NPW * j;
-        if (pi < PIECES) {
-          const bool isres = RES && 64 * pi >= RPXP;              // wave-uniform
-          const char* base = isres ? rr : xr;
-          const bool rowok = isres ? rok : xok;
-          const char* src = (rowok && boff[j] >= 0) ? base + boff[j] : (const char*)c3_zero_page;
-          if (dcol[j] > -(1 << 29)) glds16(src, dst + (lds_t)(pi * 1024));
+        for (int j = 0; j < PCWMAX; ++j) {
+          const int pi = pw + NPW * j;
+          if (pi < PIECES) {
+            if (dcol[j] > -(1 << 29)) glds16(cur[j], dst + (lds_t)(pi * 1024));
+            cur[j] += step[j];
+          }
+        }
+      } else {          // a row above / below the image (the first and last rows of the items that touch its border): zeros
+#pragma unroll
+        for (int j = 0; j < PCWMAX; ++j) {
+          const int pi = pw + NPW * j;
+          if (pi < PIECES) {
+            const bool isres = RES && 64 * pi >= RPXP;              // wave-uniform
+            const char* src = (isres ? rok : xok) ? cur[j] : (const char*)c3_zero_page;
+            if (dcol[j] > -(1 << 29)) glds16(src, dst + (lds_t)(pi * 1024));
+            cur[j] += step[j];
+          }
         }
       }
       ++C;
@@ -254,11 +269,15 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
   constexpr int FR = SPW * KSR;                              // operand fragments of one row
   constexpr int CH = FR <= 6 ? FR : 6;                       // fragments per register set ("chunk"): two sets ping-pong
   constexpr int NCH = (FR + CH - 1) / CH;
-  bf16_t* const dump = (bf16_t*)c3_dump_page;               // where the rows an item does not own are stored (zeros)
+  // where the rows an item does not own are stored (zeros): as an element offset from y, so that the select below is
+  // between two scalar integers and the store keeps its global address space
+  long dump_off = (bf16_t*)c3_dump_page - g.y;
+  MDS_PIN_SGPR(dump_off);
 
   for (int it = blockIdx.x; it < g.items; it += G) {
     const C3Item im = c3_item(g, it, WB);
     const int K = im.r1 - im.r0 + 2;
+    const long yitem_off = ((long)im.n * g.H + im.r0 - 2) * g.W * COUT;            // the output row that entry 0 "finishes" (r0 - 2: never stored)
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
@@ -292,78 +311,103 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
 #pragma unroll
           for (int f = 0; f < CH; ++f) {
             const int fr = cc * CH + f;
-            if (fr < FR) xs[c & 1][f] = *(const u16x8*)(rows[j] + (fr / KSR) * 256 * PP + xoff[fr % KSR]);
+            if (fr < FR) xs[c & 1][f] = (C3_ABL & 4) ? wr[0][0][0] : *(const u16x8*)(rows[j] + (fr / KSR) * 256 * PP + xoff[fr % KSR]);
           }
+        }
+      };
+      // What a finished output row-strip still needs - conversion + store, and (forward layers) its share of the BatchNorm
+      // statistics - is cut into NT small tasks that are placed IN FRONT of the MFMAs of the following fragments, one per
+      // fragment, each fragment a scheduling region of its own: the vector instructions then issue while the previous
+      // fragment's MFMAs are still in the pipe.  (Left to itself the scheduler sinks all of them behind the batch's last MFMA:
+      // ~500 cycles per batch with the matrix pipe idle.)  The tasks of strip (jj, ss) must precede the first MFMA that
+      // re-opens its accumulator set: row jj + 1's first k-step of the same strip, (SPW - 1) KSR fragments later.
+      constexpr int NT = (STATS && SPW > 1) ? 3 : 1;
+      auto task = [&](int jj, int ss, int tt) {
+        if (!(FULL || jj < n)) return;
+        const int SL = (jj + 2) % 3;        // output row r0 + k - 2 has seen its three input rows (phase jj = k % 3: batches start at multiples of three)
+        const int k = k0 + jj, ro = im.r0 + k - 2;
+        const bool rowok = k >= 2 && ro < im.r1;                                           // wave-uniform
+        const int cl = 16 * (sg * SPW + ss) + i, gx = im.x0 + cl;
+        const bool ok = !MASKED || gx < g.W;
+        float v[4 * NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * nf + r] = acc[SL][ss][nf][r];
+        if (MASKED && STATS) {
+#pragma unroll
+          for (int c2 = 0; c2 < 4 * NF; ++c2) v[c2] = ok ? v[c2] : 0.f;
+        }
+        if (tt == 0) {
+          if (RES) {
+            const bf16_t* rp = (const bf16_t*)(rows[jj] + RPXP * 16) + cl * COUT + cb + 4 * NF * q;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+              const u16x4 rv = *(const u16x4*)(rp + 4 * nf);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[4 * nf + r] += bf2f(rv[r]);
+            }
+          }
+          // a scalar select written as mask arithmetic: hipcc turns `c ? a : b` on scalars into a two-instruction branch, and a
+          // branch ends a scheduling region
+          const long realoff = yitem_off + (long)k * (g.W * COUT);
+          bf16_t* const orow = g.y + (dump_off ^ ((dump_off ^ realoff) & -(long)rowok));
+          bf16_t* dst = orow + gx * COUT + cb + 4 * NF * q;
+          if (MASKED) dst = ok ? dst : g.y + dump_off + lane * 16;      // ragged last band: columns past the image go to the dump row's head
+          if (!(C3_ABL & 1)) C3Out<NF>::st(dst, v);
+          else if (v[0] == 12345.678f) C3Out<NF>::st(dst, v);      // (never true: keeps the arithmetic alive)
+        }
+        if (STATS && !(C3_ABL & 2) && (NT == 1 || tt == 1)) {
+#pragma unroll
+          for (int c2 = 0; c2 < 4 * NF; ++c2) ps[c2] += v[c2];
+        }
+        if (STATS && !(C3_ABL & 2) && (NT == 1 || tt == 2)) {
+#pragma unroll
+          for (int c2 = 0; c2 < 4 * NF; ++c2) pss[c2] += v[c2] * v[c2];
         }
       };
       load_chunk(0);
 #pragma unroll
-      for (int c = 0; c < 3 * NCH; ++c) {
-        const int j = c / NCH, cc = c - j * NCH;
-        if (c + 1 < 3 * NCH) load_chunk(c + 1);
+      for (int L = 0; L < 3 * FR; ++L) {
+        const int j = L / FR, fr = L - j * FR, st = fr / KSR, s = fr - st * KSR;
+        const int c = j * NCH + fr / CH, f = fr % CH;
+        if (f == 0 && c + 1 < 3 * NCH) load_chunk(c + 1);
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+          for (int ss = 0; ss < SPW; ++ss)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+              if (jj * FR + ss * KSR + KSR + tt == L) task(jj, ss, tt);
         if (FULL || j < n) {
 #pragma unroll
-          for (int f = 0; f < CH; ++f) {
-            const int fr = cc * CH + f;
-            if (fr < FR) {
-              const int st = fr / KSR, s = fr % KSR;
+          for (int d = 2; d >= 0; --d) {
+            if (HEAD && d > j) continue;          // input row r0 - 1 + j, tap row d - 1: output row r0 + j - d is above the item
 #pragma unroll
-              for (int d = 2; d >= 0; --d) {
-                if (HEAD && d > j) continue;          // input row r0 - 1 + j, tap row d - 1: output row r0 + j - d is above the item
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) {
-                  if (d == 0 && s == 0) {
-                    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    mma16(wr[d][s][nf], xs[c & 1][f], z);
-                    acc[(j + 4 - d) % 3][st][nf] = z;
-                  } else {
-                    mma16(wr[d][s][nf], xs[c & 1][f], acc[(j + 4 - d) % 3][st][nf]);
-                  }
-                }
-              }
-            }
-          }
-          if (cc == NCH - 1) {
-            // output row r0 + k - 2 has seen its three input rows (phase j = k % 3: batches start at multiples of three)
-            const int SL = (j + 2) % 3;
-            const int k = k0 + j, ro = im.r0 + k - 2;
-            const bool rowok = k >= 2 && ro < im.r1;                                           // wave-uniform
-            bf16_t* const orow = rowok ? g.y + ((long)im.n * g.H + ro) * g.W * COUT : dump;    // a scalar select
-#pragma unroll
-            for (int st = 0; st < SPW; ++st) {
-              const int cl = 16 * (sg * SPW + st) + i, gx = im.x0 + cl;
-              float v[4 * NF];
-#pragma unroll
-              for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * nf + r] = acc[SL][st][nf][r];
-              if (RES) {
-                const bf16_t* rp = (const bf16_t*)(rows[j] + RPXP * 16) + cl * COUT + cb + 4 * NF * q;
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) {
-                  const u16x4 rv = *(const u16x4*)(rp + 4 * nf);
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) v[4 * nf + r] += bf2f(rv[r]);
-                }
-              }
-              bf16_t* dst = orow + gx * COUT + cb + 4 * NF * q;
-              if (MASKED) {                           // ragged last band: columns past the image go to the dump row's head
-                const bool ok = gx < g.W;
-                dst = ok ? dst : dump + lane * 16;
-                if (STATS) {
-#pragma unroll
-                  for (int c2 = 0; c2 < 4 * NF; ++c2) v[c2] = ok ? v[c2] : 0.f;
-                }
-              }
-              C3Out<NF>::st(dst, v);
-              if (STATS) {
-#pragma unroll
-                for (int c2 = 0; c2 < 4 * NF; ++c2) { ps[c2] += v[c2]; pss[c2] += v[c2] * v[c2]; }
+            for (int nf = 0; nf < NF; ++nf) {
+              if (C3_ABL & 8) {
+                acc[(j + 4 - d) % 3][st][nf][0] += bf2f(xs[c & 1][f][nf]);
+              } else if (d == 0 && s == 0) {
+                f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                mma16(wr[d][s][nf], xs[c & 1][f], z);
+                acc[(j + 4 - d) % 3][st][nf] = z;
+              } else {
+                mma16(wr[d][s][nf], xs[c & 1][f], acc[(j + 4 - d) % 3][st][nf]);
               }
             }
           }
         }
+        if (FULL) {
+        }
       }
+      // the tasks whose fragment lies in the next batch
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+        for (int ss = 0; ss < SPW; ++ss)
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt)
+            if (jj * FR + ss * KSR + KSR + tt >= 3 * FR) task(jj, ss, tt);
     };
     for (int k0 = 0; k0 < K; k0 += 3) {
       if (k0 + 3 <= K) {

@@ -57,6 +57,8 @@ MDS_DEV void mds_wait_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // gfx9
 #define MDS_CHAIN_PRIO() __builtin_amdgcn_s_setprio(MDS_CHAIN_PRIO_LEVEL)
 #define MDS_SETPRIO(n) __builtin_amdgcn_s_setprio(n)   /* a role's issue priority inside one kernel (producer / consumer waves) */
 #define MDS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define MDS_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)   /* LLVM SchedGroupMask: VALU 2, SALU 4, MFMA 8, VMEM read 0x20, write 0x40, DS read 0x100 */
+#define MDS_PIN_SGPR(x) asm volatile("" : "+s"(x))   /* keep a wave-uniform value in scalar registers (no rematerialisation at its uses) */
 #define MDS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  /* wave-uniform value -> scalar register */
 #define MDS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 // gfx950 has 160 KiB of LDS per CU; launches above the 64 KiB default opt in once per kernel.

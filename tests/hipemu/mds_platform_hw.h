@@ -48,6 +48,8 @@ MDS_DEV void mds_wait_stores() {}
 #define MDS_CHAIN_PRIO() ((void)0)
 #define MDS_SETPRIO(n) ((void)0)
 #define MDS_SCHED_FENCE() ((void)0)
+#define MDS_SCHED_GROUP(mask, n) ((void)0)
+#define MDS_PIN_SGPR(x) ((void)0)
 #define MDS_UNIFORM(x) (x)
 #define MDS_DYN_SMEM(name) char* name = hipemu::dyn_smem()
 #define MDS_LAUNCH(kernel, grid, block, smem, stream, ...) \

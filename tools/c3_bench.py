@@ -6,6 +6,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "ball-action-spotting_amd")]
 import torch
 from mds import cabi, geometry as geo
 dev = torch.device("cuda:0")
+if os.environ.get("C3_LIB"):      # an experiment build (make c3abl ABL=n)
+    cabi.HIP_LIB = os.path.join(ROOT, "ball-action-spotting_amd", "csrc", os.environ["C3_LIB"])
 lib = cabi.load()
 BF = torch.bfloat16
 SHAPES = [(20, 184, 320, 32, 128, False, True, "b1.1 fwd 32->128 +stats"), (20, 184, 320, 128, 32, True, False, "b1.1 dgrad 128->32 +res"),
