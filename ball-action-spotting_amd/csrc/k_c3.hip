@@ -36,6 +36,7 @@ struct C3Args {
   const bf16_t* res;   // optional, indexed like y
   double* stats;       // optional [SLOTS][2][Cout]
   int N, H, W, wtaps;
+  int Ctot;            // channels of the output tensor: a launch computes COUT of them per grid.y slice ("channel pass")
   int tapw[9];         // weight slot of tap (dy, dx) at [3 * (dy + 1) + (dx + 1)]
   int nbands, nseg, rps, items;
   int RA, NR;
@@ -44,8 +45,6 @@ struct C3Args {
 };
 
 __device__ __attribute__((aligned(256))) unsigned int c3_zero_page[64];
-#define C3_DUMP_BYTES (128 * 1024)
-__device__ __attribute__((aligned(256))) unsigned int c3_dump_page[C3_DUMP_BYTES / 4 + 64];   // one whole output row: where rows outside an item are stored
 
 template <int CIN> struct C3Swz;     // part' = (part + ((A * pixel) >> SH)) % (CIN / 8): tools/probes/c3_swizzle_check.py search
 template <> struct C3Swz<16> { static constexpr int A = 0, SH = 0; };
@@ -105,14 +104,19 @@ template <> struct C3Out<3> {
 #define C3_STAMP(b_, ph_) ((void)0)
 #endif
 
-template <int CIN, int NF, int NSPL, int SPW, int NPW, bool RES, bool STATS, bool MASKED>
-__global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
+template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool RES, bool STATS, bool MASKED>
+__global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
   typedef C3Cfg<CIN, NF, NSPL, SPW, RES> CF;
   constexpr int PP = CF::PP, KSR = CF::KSR, WB = CF::WB, COUT = CF::COUT, CP = CF::CP, RPX = CF::RPX, RPXP = CF::RPXP, RS = CF::RS;
   constexpr int PIECES = CF::PIECES, ROWB = CF::ROWB;
+  constexpr int CPP = COUT / 8;                      // 16-byte chunks of an output pixel
+  constexpr int STGROW = WB * COUT * 2;              // bytes of one staged output row of the band
+  constexpr int RSH = CPP == 4 ? 1 : 0;              // staged chunk c of pixel p sits at chunk (c + (p >> RSH)) % CPP: spreads the consumers' writes over the banks
   MDS_DYN_SMEM(smem);
+  char* const stg = smem + g.NR * ROWB;               // [2 batch parities][3 rows][WB pixels][COUT] bf16
   const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
   const int G = gridDim.x;
+  const int c0 = blockIdx.y * COUT;                  // first output channel of this channel pass
   // entries (rows to stage and to consume) of this block: every item has (rows + 2)
   int E = 0;
   for (int it = blockIdx.x; it < g.items; it += G) {
@@ -122,10 +126,10 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
 
 #ifdef C3_TRACE
   const bool trc = blockIdx.x == C3_TRACE && g.trace != nullptr;
-  const lds_t trc_base = lds_addr_of(smem) + (lds_t)(g.NR * ROWB);
+  const lds_t trc_base = lds_addr_of(smem) + (lds_t)(g.NR * ROWB + 6 * STGROW);
   int tb = 0;
 #endif
-  if (wave >= 4) {
+  if (wave >= 4 && wave < 4 + NPW) {
     // ------------------------------------------------------------------ producers: LDS-DMA, RA rows ahead
     MDS_SETPRIO(3);       // the DMA stream is what every barrier waits for
     const int pw = wave - 4;
@@ -158,14 +162,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
     unsigned step[PCWMAX];
     auto open_item = [&]() {
       const char* xrow0 = (const char*)g.x + ((long)him.n * g.H + him.r0 - 1) * g.W * CIN * 2;                   // entry 0's rows:
-      const char* rrow0 = RES ? (const char*)g.res + ((long)him.n * g.H + him.r0 - 2) * g.W * COUT * 2 : nullptr;   // r0 - 1 / r0 - 2
+      const char* rrow0 = RES ? (const char*)(g.res + c0) + ((long)him.n * g.H + him.r0 - 2) * g.W * g.Ctot * 2 : nullptr;   // r0 - 1 / r0 - 2
 #pragma unroll
       for (int j = 0; j < PCWMAX; ++j) {
         const bool isres = RES && 64 * (pw + NPW * j) >= RPXP;
         const int gx = him.x0 + dcol[j];
         const bool ok = gx >= 0 && gx < g.W;
-        cur[j] = ok ? (isres ? rrow0 : xrow0) + (gx * (isres ? COUT : CIN) + eoff[j]) * 2 : (const char*)c3_zero_page;
-        step[j] = ok ? (unsigned)(g.W * (isres ? COUT : CIN) * 2) : 0u;
+        cur[j] = ok ? (isres ? rrow0 : xrow0) + (gx * (isres ? g.Ctot : CIN) + eoff[j]) * 2 : (const char*)c3_zero_page;
+        step[j] = ok ? (unsigned)(g.W * (isres ? g.Ctot : CIN) * 2) : 0u;
       }
     };
     open_item();
@@ -223,6 +227,58 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
 #endif
       }
     }
+    raw_barrier();        // the closing barrier: the last batch's outputs are staged
+#ifdef C3_TRACE
+    raw_barrier();
+#endif
+    return;
+  }
+  if (wave >= 4 + NPW) {
+    // ------------------------------------------------------------------ store waves: staged output rows -> global memory
+    // The consumers own channel slices, so a wave's own store would touch 64-byte pieces of sixteen pixels (measured: 40 of the
+    // forward layer's 127 us); they stage the converted rows of a batch in LDS instead, and after the NEXT batch's barrier these
+    // waves move them out as whole pixels: 1 KiB of consecutive bytes per wave instruction.  Their vmcnt holds stores only.
+    MDS_SETPRIO(3);       // short bursts after each barrier; the consumers' next barrier waits for them
+    const int sw = wave - 4 - NPW;
+    // a piece = PPP whole pixels: lane l moves chunk l % CPP of pixel l / CPP
+    constexpr int PPP = 64 / CPP, NP = (WB + PPP - 1) / PPP;
+    static_assert(CPP <= 64, "an output pixel is at most one DMA piece wide");
+    const int lpx = lane / CPP, chunk = lane - lpx * CPP;
+    const bool lact = lpx < PPP;
+    int bidx = 0;
+    C3Item pim = c3_item(g, blockIdx.x, WB);
+    int pk0 = 0, pn = 0;
+    auto flush = [&](int par) {
+      for (int j = 0; j < pn; ++j) {
+        const int k = pk0 + j, ro = pim.r0 + k - 2;
+        if (k < 2 || ro >= pim.r1) continue;              // a row above / below the item: zeros or partial sums, never stored
+        const char* srow = stg + (par * 3 + j) * STGROW;
+        bf16_t* const orow = g.y + c0 + (((long)pim.n * g.H + ro) * g.W + pim.x0) * g.Ctot;
+        for (int pc = sw; pc < NP; pc += NSW) {
+          const int cl = pc * PPP + lpx;
+          if (lact && cl < WB && (!MASKED || pim.x0 + cl < g.W)) {
+            const u16x8 v = *(const u16x8*)(srow + (cl * CPP + (chunk + (cl >> RSH)) % CPP) * 16);
+            *(u16x8*)(orow + cl * g.Ctot + 8 * chunk) = v;
+          }
+        }
+      }
+    };
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3_item(g, it, WB);
+      const int K = im.r1 - im.r0 + 2;
+      for (int k0 = 0; k0 < K; k0 += 3) {
+        asm volatile("" ::: "memory");
+        raw_barrier();                                    // batch bidx starts; batch bidx - 1 is staged
+        asm volatile("" ::: "memory");
+        if (bidx > 0) flush((bidx - 1) & 1);
+        pim = im; pk0 = k0; pn = K - k0 < 3 ? K - k0 : 3;
+        ++bidx;
+      }
+    }
+    asm volatile("" ::: "memory");
+    raw_barrier();
+    asm volatile("" ::: "memory");
+    flush((bidx - 1) & 1);
 #ifdef C3_TRACE
     raw_barrier();
 #endif
@@ -248,7 +304,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
         if (gr < 3 * PP) {
           const int dxi = gr / PP, part = gr - dxi * PP;
           const int slot = dxi == 0 ? g.tapw[3 * d] : (dxi == 1 ? g.tapw[3 * d + 1] : g.tapw[3 * d + 2]);
-          const int ch = cb + 4 * NF * (i >> 2) + 4 * nf + (i & 3);
+          const int ch = c0 + cb + 4 * NF * (i >> 2) + 4 * nf + (i & 3);
           v = *(const u16x8*)(g.w + ((long)ch * g.wtaps + slot) * CIN + 8 * part);
         }
         wr[d][s][nf] = v;
@@ -262,22 +318,18 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
     xoff[s] = (p * PP + (part + ((C3Swz<CIN>::A * p) >> C3Swz<CIN>::SH)) % PP) * 16 + sg * SPW * 256 * PP;
   }
   f32x4 acc[3][SPW][NF];
-  float ps[4 * NF], pss[4 * NF];
+  float ps[4 * NF], pss[4 * NF];          // BatchNorm sums of this lane's channels (forward layers), taken from the fp32 accumulators
 #pragma unroll
   for (int c = 0; c < 4 * NF; ++c) { ps[c] = 0.f; pss[c] = 0.f; }
   int slot = 0;                                              // ring slot of the next row to consume
   constexpr int FR = SPW * KSR;                              // operand fragments of one row
   constexpr int CH = FR <= 6 ? FR : 6;                       // fragments per register set ("chunk"): two sets ping-pong
   constexpr int NCH = (FR + CH - 1) / CH;
-  // where the rows an item does not own are stored (zeros): as an element offset from y, so that the select below is
-  // between two scalar integers and the store keeps its global address space
-  long dump_off = (bf16_t*)c3_dump_page - g.y;
-  MDS_PIN_SGPR(dump_off);
+  int bpar = 0;                                              // parity of the batch: which half of the staging area it fills
 
   for (int it = blockIdx.x; it < g.items; it += G) {
     const C3Item im = c3_item(g, it, WB);
     const int K = im.r1 - im.r0 + 2;
-    const long yitem_off = ((long)im.n * g.H + im.r0 - 2) * g.W * COUT;            // the output row that entry 0 "finishes" (r0 - 2: never stored)
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
@@ -288,16 +340,17 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
     // One batch = up to three consecutive rows behind one barrier, as straight-line code: the fragment reads of chunk c + 1 are
     // issued before the MFMAs of chunk c (two register sets); the first MFMA into an accumulator set (tap row dy = -1, first
     // k-step) takes a zero C operand, so finished sets are never cleared; the first batch of an item (HEAD) leaves out the taps
-    // that would feed rows above the item, so those sets stay zero and their "output rows" are zeros written to a dump row
-    // (a scalar pointer select): no masks and no branch in the conversion / statistics / store code, which the scheduler
-    // can then spread among the MFMAs.
+    // that would feed rows above the item, so those sets stay zero: the "output rows" above the item are zeros, staged like
+    // any other row and skipped by the store waves - no masks and no branch in the conversion / statistics / staging code.
     auto batch = [&](auto fullc, auto headc, int k0, int n) {
       constexpr bool FULL = decltype(fullc)::value, HEAD = decltype(headc)::value;
       C3_STAMP(tb, 0);
-      asm volatile("" ::: "memory");
+      wait_lgkm0();                       // this wave's staged output rows of the previous batch are written
       raw_barrier();                      // the batch's rows are in LDS (the producers waited for their DMA before arriving)
       asm volatile("" ::: "memory");
       C3_STAMP(tb, 1);
+      char* const sbat = stg + bpar * 3 * STGROW;
+      bpar ^= 1;
       const char* rows[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -326,18 +379,13 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
         if (!(FULL || jj < n)) return;
         const int SL = (jj + 2) % 3;        // output row r0 + k - 2 has seen its three input rows (phase jj = k % 3: batches start at multiples of three)
         const int k = k0 + jj, ro = im.r0 + k - 2;
-        const bool rowok = k >= 2 && ro < im.r1;                                           // wave-uniform
-        const int cl = 16 * (sg * SPW + ss) + i, gx = im.x0 + cl;
-        const bool ok = !MASKED || gx < g.W;
+        const int cl = 16 * (sg * SPW + ss) + i;
+        const bool ok = !MASKED || im.x0 + cl < g.W;
         float v[4 * NF];
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[4 * nf + r] = acc[SL][ss][nf][r];
-        if (MASKED && STATS) {
-#pragma unroll
-          for (int c2 = 0; c2 < 4 * NF; ++c2) v[c2] = ok ? v[c2] : 0.f;
-        }
         if (tt == 0) {
           if (RES) {
             const bf16_t* rp = (const bf16_t*)(rows[jj] + RPXP * 16) + cl * COUT + cb + 4 * NF * q;
@@ -348,22 +396,24 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
               for (int r = 0; r < 4; ++r) v[4 * nf + r] += bf2f(rv[r]);
             }
           }
-          // a scalar select written as mask arithmetic: hipcc turns `c ? a : b` on scalars into a two-instruction branch, and a
-          // branch ends a scheduling region
-          const long realoff = yitem_off + (long)k * (g.W * COUT);
-          bf16_t* const orow = g.y + (dump_off ^ ((dump_off ^ realoff) & -(long)rowok));
-          bf16_t* dst = orow + gx * COUT + cb + 4 * NF * q;
-          if (MASKED) dst = ok ? dst : g.y + dump_off + lane * 16;      // ragged last band: columns past the image go to the dump row's head
-          if (!(C3_ABL & 1)) C3Out<NF>::st(dst, v);
-          else if (v[0] == 12345.678f) C3Out<NF>::st(dst, v);      // (never true: keeps the arithmetic alive)
-        }
-        if (STATS && !(C3_ABL & 2) && (NT == 1 || tt == 1)) {
+          // staged at [row jj][pixel cl], 16-byte chunks rotated by the pixel (bank spread); rows the item does not own are staged
+          // too (zeros / partial sums) and skipped by the store waves
+          char* const sp = sbat + (jj * WB + cl) * (COUT * 2);
+          const int rot = (cl >> RSH) % CPP;
 #pragma unroll
-          for (int c2 = 0; c2 < 4 * NF; ++c2) ps[c2] += v[c2];
+          for (int nf = 0; nf < NF; ++nf) {
+            const int o = (cb + 4 * NF * q + 4 * nf) * 2;           // byte offset of these four channels inside the pixel
+            float v4[4] = {v[4 * nf], v[4 * nf + 1], v[4 * nf + 2], v[4 * nf + 3]};
+            if (!(C3_ABL & 1)) store4((bf16_t*)(sp + ((o / 16 + rot) % CPP) * 16 + (o & 8)), v4);
+          }
         }
-        if (STATS && !(C3_ABL & 2) && (NT == 1 || tt == 2)) {
+        if (STATS && !(C3_ABL & 2) && tt == (NT == 1 ? 0 : 1)) {
 #pragma unroll
-          for (int c2 = 0; c2 < 4 * NF; ++c2) pss[c2] += v[c2] * v[c2];
+          for (int c2 = 0; c2 < 4 * NF; ++c2) ps[c2] += (MASKED && !ok) ? 0.f : v[c2];
+        }
+        if (STATS && !(C3_ABL & 2) && tt == (NT == 1 ? 0 : 2)) {
+#pragma unroll
+          for (int c2 = 0; c2 < 4 * NF; ++c2) pss[c2] += (MASKED && !ok) ? 0.f : v[c2] * v[c2];
         }
       };
       load_chunk(0);
@@ -423,28 +473,30 @@ __global__ __launch_bounds__(256 + 64 * NPW) void c3_kernel(C3Args g) {
 #endif
     }
   }
-#ifdef C3_TRACE
-  raw_barrier();
-  if (trc) {
-    const unsigned long long* tl = (const unsigned long long*)(smem + g.NR * ROWB);
-    for (int e = tid; e < 160 * 32; e += 256) ((unsigned long long*)g.trace)[e] = tl[e];
-  }
-#endif
+  wait_lgkm0();
+  raw_barrier();          // the closing barrier: the store waves take the last batch
   if (STATS) {
-    double* st = g.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * COUT;
+    double* st = g.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * g.Ctot + c0;
 #pragma unroll
     for (int c = 0; c < 4 * NF; ++c) {
       const float a = sum_over_i16(ps[c]), b = sum_over_i16(pss[c]);
       if (i == 0) {
         atomicAdd(st + cb + 4 * NF * q + c, (double)a);
-        atomicAdd(st + COUT + cb + 4 * NF * q + c, (double)b);
+        atomicAdd(st + g.Ctot + cb + 4 * NF * q + c, (double)b);
       }
     }
   }
+#ifdef C3_TRACE
+  raw_barrier();
+  if (trc) {
+    const unsigned long long* tl = (const unsigned long long*)(smem + g.NR * ROWB + 6 * STGROW);
+    for (int e = tid; e < 160 * 32; e += 256) ((unsigned long long*)g.trace)[e] = tl[e];
+  }
+#endif
 }
 
 // host side ------------------------------------------------------------------------------------------------------------
-template <int CIN, int NF, int NSPL, int SPW, int NPW>
+template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW>
 static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
   typedef C3Cfg<CIN, NF, NSPL, SPW, true> CFR;
   typedef C3Cfg<CIN, NF, NSPL, SPW, false> CFN;
@@ -452,20 +504,23 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
   const int WB = CFN::WB, rowb = res ? CFR::ROWB : CFN::ROWB, pieces = res ? CFR::PIECES : CFN::PIECES;
   C3Args g;
   g.x = (const bf16_t*)a->x; g.w = (const bf16_t*)a->w; g.y = (bf16_t*)a->y; g.res = (const bf16_t*)a->residual; g.stats = a->stats;
-  g.N = a->N; g.H = a->IH; g.W = a->IW; g.wtaps = a->wtaps;
+  g.N = a->N; g.H = a->IH; g.W = a->IW; g.wtaps = a->wtaps; g.Ctot = a->Cout;
+  const int passes = a->Cout / CFN::COUT;
   for (int t = 0; t < 9; ++t) g.tapw[t] = tapw[t];
   // rows in flight: ~40 KB per CU ahead of the consumers (HBM latency x a CU's share of the bandwidth), at least 3 rows;
   // the producers' vmcnt (6 bits) carries pcw * (RA - 1) pieces
   const int pcw = (pieces + NPW - 1) / NPW;
-  int RA = (40 * 1024 + rowb - 1) / rowb;
+  int RA = (64 * 1024 + rowb - 1) / rowb;
   if (RA < 3) RA = 3;
   while (RA > 3 && pcw * (RA - 1) > 40) --RA;
+  if (pcw * (RA - 1) > 40) return 0;
   int NR = RA + 3;
-  while ((size_t)NR * rowb > 150 * 1024 && RA > 3) { --RA; NR = RA + 3; }
-  if ((size_t)NR * rowb > 150 * 1024) return 0;
+  const size_t lds_cap = 156 * 1024 - 6 * (size_t)WB * CFN::COUT * 2;     // the staged output rows share the LDS
+  while ((size_t)NR * rowb > lds_cap && RA > 3) { --RA; NR = RA + 3; }
+  if ((size_t)NR * rowb > lds_cap) return 0;
   g.RA = RA; g.NR = NR; g.dbg = mds_knob(MDS_KNOB_C3_DBG); g.trace = (void*)a->epi.scale;
   // items: bands x row segments, the segment count that minimises the longest block's rows (+2 halo rows, + a fill per item)
-  int CUS = 256;
+  int CUS = 256 / passes;
   if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);      // tests: few blocks, many items each
   g.nbands = cdiv(a->IW, WB);
   long best = -1;
@@ -477,15 +532,14 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
     if (best < 0 || cost < best) { best = cost; g.nseg = nsr; g.rps = rps; g.items = (int)items; }
   }
   const int grid = g.items < CUS ? g.items : CUS;
-  size_t smem = (size_t)NR * rowb;
+  size_t smem = (size_t)NR * rowb + 6 * (size_t)WB * CFN::COUT * 2;
 #ifdef C3_TRACE
   smem += 160 * 32 * 8;
 #endif
-  dim3 block(256 + 64 * NPW);
+  dim3 block(256 + 64 * (NPW + NSW));
   const bool masked = a->IW % WB != 0;
-  if ((size_t)a->IW * CFN::COUT * 2 > C3_DUMP_BYTES) return 0;
-#define C3_GO(R, S) do { if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, R, S, true>), dim3(grid), block, smem, stream, g); \
-                         else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, R, S, false>), dim3(grid), block, smem, stream, g); } while (0)
+#define C3_GO(R, S) do { if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, true>), dim3(grid, passes), block, smem, stream, g); \
+                         else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, false>), dim3(grid, passes), block, smem, stream, g); } while (0)
   if (res) { if (stats) return 0; C3_GO(true, false); }      // (a residual operand and statistics never meet in the network)
   else { if (stats) C3_GO(false, true); else C3_GO(false, false); }
 #undef C3_GO
@@ -508,8 +562,11 @@ int c3_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
   for (int t = 0; t < 9; ++t) if (tapw[t] < 0 || tapw[t] >= a->wtaps) return 0;
   const long rows = (long)a->N * a->IH * a->IW;
   if (rows < 16384 && mds_knob(MDS_KNOB_C3) != 2) return 0;      // small launches (inference, tests of the old kernels): k_conv.hip
-  const bool npw4 = (mds_knob(MDS_KNOB_C3_DBG) & 16) != 0;
-  if (a->Cin == 128 && a->Cout == 32) return npw4 ? c3_launch<128, 1, 2, 1, 4>(a, tapw, stream) : c3_launch<128, 1, 2, 1, 2>(a, tapw, stream);
-  if (a->Cin == 32 && a->Cout == 128) return npw4 ? c3_launch<32, 2, 4, 2, 4>(a, tapw, stream) : c3_launch<32, 2, 4, 2, 2>(a, tapw, stream);
+  // helper waves: the data gradients read wide rows and write narrow ones (three DMA waves, one store wave); the forward layers two and two
+  const bool alt = (mds_knob(MDS_KNOB_C3_DBG) & 16) != 0;      // A/B: the other split
+  if (a->Cin == 128 && a->Cout == 32) return alt ? c3_launch<128, 1, 2, 1, 2, 2>(a, tapw, stream) : c3_launch<128, 1, 2, 1, 3, 1>(a, tapw, stream);
+  if (a->Cin == 48 && a->Cout == 192) return c3_launch<48, 2, 2, 1, 2, 2>(a, tapw, stream);      // three passes of 64 channels: a 96-channel slice per wave pair does not fit the registers
+  if (a->Cin == 16 && a->Cout == 32) return c3_launch<16, 2, 1, 1, 2, 2>(a, tapw, stream);
+  if (a->Cin == 32 && a->Cout == 128) return alt ? c3_launch<32, 2, 4, 2, 1, 3>(a, tapw, stream) : c3_launch<32, 2, 4, 2, 2, 2>(a, tapw, stream);
   return 0;
 }

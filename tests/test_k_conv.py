@@ -229,6 +229,10 @@ C3_CASES = [  # N, H, W, Cin, Cout, residual, statistics, block cap (0 = default
     (1, 9, 33, 128, 32, False, False, 1),      # one block, every item; no residual
     (1, 3, 16, 32, 128, False, True, 0),       # fewer rows than the ring is deep
     (1, 2, 15, 128, 32, True, False, 0),
+    (2, 12, 37, 48, 192, False, True, 0),      # blocks.2.1's forward: three channel passes of 64
+    (1, 20, 50, 48, 192, False, True, 2),
+    (2, 9, 70, 16, 32, False, False, 0),       # blocks.0.0's data gradient: 16 input channels (half-empty second k-step), 64-column bands
+    (1, 17, 130, 16, 32, True, False, 3),
 ]
 
 
