@@ -36,6 +36,7 @@ struct C3Args {
   const bf16_t* res;   // optional, indexed like y
   double* stats;       // optional [SLOTS][2][Cout]
   int N, H, W, wtaps;
+  int OH, OW;          // output extents (stride-2 data gradient: 2 H x 2 W; otherwise H x W)
   int Ctot;            // channels of the output tensor: a launch computes COUT of them per grid.y slice ("channel pass")
   int tapw[9];         // weight slot of tap (dy, dx) at [3 * (dy + 1) + (dx + 1)]
   int nbands, nseg, rps, items;
@@ -495,6 +496,270 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Stride-2 data gradient (the transposed convolution of a TF-SAME stride-2 3x3 layer with even input extents: pads 0 / 1).
+// Input = dy [N][H][W][CIN], output = dx [N][2H][2W][COUT].  Input pixel (a, b) feeds output (2a + ky, 2b + kx) through
+// w[ky][kx], ky, kx in 0..2.  Same machinery as c3_kernel (filter slice in registers, DMA ring, store waves); what changes:
+//   * one input row finishes TWO output rows: 2a (taps ky = 0 of row a + ky = 2 of row a - 1, carried in a rolling set) and
+//     2a + 1 (ky = 1, this row only); one fragment (16 input pixels) serves the even AND the odd output columns (kx = 0 / 1)
+//     and, read one pixel to the left, the even columns again (kx = 2): 9 KS NF MFMAs per 2 KS fragment reads;
+//   * batches of two rows (the rolling set's period); an item's first row (a = r0 - 1) only contributes its ky = 2 taps.
+// k_conv.hip evaluates this layer as four tap groups with a 16 x NF-wide LDS filter slab: one MFMA per two fragment reads.
+template <int CIN, int NF, int NSPL, int NPW, int NSW, bool MASKED>
+__global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
+  constexpr int PP = CIN / 8, KS = CIN / 32, NSG = 4 / NSPL, WBI = 16 * NSG, WBO = 2 * WBI, COUT = 16 * NF * NSPL, CPP = COUT / 8;
+  constexpr int RS = (WBI + 1) * PP, PIECES = (RS + 63) / 64, ROWB = RS * 16;
+  constexpr int STGROW = WBO * COUT * 2;
+  constexpr int RSH = CPP == 4 ? 1 : 0;
+  static_assert(CIN % 32 == 0, "whole k-steps per tap");
+  MDS_DYN_SMEM(smem);
+  char* const stg = smem + g.NR * ROWB;               // [2 batch parities][2 input rows][2 output rows][WBO pixels][COUT] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int G = gridDim.x;
+  const int c0 = blockIdx.y * COUT;
+  int E = 0;
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item(g, it, WBI);
+    E += im.r1 - im.r0 + 1;
+  }
+  if (wave >= 4 && wave < 4 + NPW) {
+    // ------------------------------------------------------------------ DMA waves
+    MDS_SETPRIO(3);
+    const int pw = wave - 4;
+    constexpr int PCWMAX = (PIECES + NPW - 1) / NPW;
+    const int pcw = (PIECES - pw + NPW - 1) / NPW;
+    int dcol[PCWMAX], eoff[PCWMAX];
+#pragma unroll
+    for (int j = 0; j < PCWMAX; ++j) {
+      const int sg_ = 64 * (pw + NPW * j) + lane;
+      if (sg_ < RS) {
+        const int p = sg_ / PP, psw = sg_ - p * PP;
+        const int rot = ((C3Swz<CIN>::A * p) >> C3Swz<CIN>::SH) % PP;
+        dcol[j] = p - 1; eoff[j] = 8 * ((psw - rot + PP) % PP);
+      } else {
+        dcol[j] = -(1 << 30); eoff[j] = 0;
+      }
+    }
+    const lds_t ring = lds_addr_of(smem);
+    int hit = blockIdx.x, hk = 0;
+    C3Item him = c3_item(g, hit < g.items ? hit : 0, WBI);
+    int C = 0, hslot = 0;
+    const char* cur[PCWMAX];
+    unsigned step[PCWMAX];
+    auto open_item = [&]() {
+      const char* xrow0 = (const char*)g.x + ((long)him.n * g.H + him.r0 - 1) * g.W * CIN * 2;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const int gx = him.x0 + dcol[j];
+        const bool ok = gx >= 0 && gx < g.W;
+        cur[j] = ok ? xrow0 + (gx * CIN + eoff[j]) * 2 : (const char*)c3_zero_page;
+        step[j] = ok ? (unsigned)(g.W * CIN * 2) : 0u;
+      }
+    };
+    open_item();
+    auto issue = [&]() {
+      const int ri = him.r0 - 1 + hk;
+      const bool xok = ri >= 0 && ri < g.H;
+      const lds_t dst = ring + (lds_t)(hslot * ROWB);
+      hslot = hslot + 1 == g.NR ? 0 : hslot + 1;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const int pi = pw + NPW * j;
+        if (pi < PIECES) {
+          const char* src = xok ? cur[j] : (const char*)c3_zero_page;
+          if (dcol[j] > -(1 << 29)) glds16(src, dst + (lds_t)(pi * 1024));
+          cur[j] += step[j];
+        }
+      }
+      ++C;
+      if (++hk == him.r1 - him.r0 + 1) {
+        hk = 0; hit += G;
+        if (hit < g.items) { him = c3_item(g, hit, WBI); open_item(); }
+      }
+    };
+    while (C < g.RA && C < E) issue();
+    int e0 = 0;
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3_item(g, it, WBI);
+      const int K = im.r1 - im.r0 + 1;
+      for (int k0 = 0; k0 < K; k0 += 2) {
+        const int n = K - k0 < 2 ? K - k0 : 2;
+        wait_vm_dyn(pcw * (C - e0 - n));
+        raw_barrier();
+        e0 += n;
+        while (C < e0 + g.RA && C < E) issue();
+      }
+    }
+    raw_barrier();
+    return;
+  }
+  if (wave >= 4 + NPW) {
+    // ------------------------------------------------------------------ store waves
+    MDS_SETPRIO(3);
+    const int sw = wave - 4 - NPW;
+    constexpr int PPP = 64 / CPP, NP = (WBO + PPP - 1) / PPP;
+    const int lpx = lane / CPP, chunk = lane - lpx * CPP;
+    const bool lact = lpx < PPP;
+    int bidx = 0;
+    C3Item pim = c3_item(g, blockIdx.x, WBI);
+    int pk0 = 0, pn = 0;
+    auto flush = [&](int par) {
+      for (int j = 0; j < pn; ++j) {
+        const int k = pk0 + j, a = pim.r0 - 1 + k;
+        if (k < 1) continue;                              // the item's first row only opens the carried set
+        for (int yp = 0; yp < 2; ++yp) {
+          const int Y = 2 * a + yp;
+          if (Y >= g.OH) continue;
+          const char* srow = stg + ((par * 2 + j) * 2 + yp) * STGROW;
+          bf16_t* const orow = g.y + c0 + (((long)pim.n * g.OH + Y) * g.OW + 2 * pim.x0) * g.Ctot;
+          for (int pc = sw; pc < NP; pc += NSW) {
+            const int cl = pc * PPP + lpx;
+            if (lact && cl < WBO && (!MASKED || 2 * pim.x0 + cl < g.OW)) {
+              const u16x8 v = *(const u16x8*)(srow + (cl * CPP + (chunk + (cl >> RSH)) % CPP) * 16);
+              *(u16x8*)(orow + cl * g.Ctot + 8 * chunk) = v;
+            }
+          }
+        }
+      }
+    };
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3_item(g, it, WBI);
+      const int K = im.r1 - im.r0 + 1;
+      for (int k0 = 0; k0 < K; k0 += 2) {
+        asm volatile("" ::: "memory");
+        raw_barrier();
+        asm volatile("" ::: "memory");
+        if (bidx > 0) flush((bidx - 1) & 1);
+        pim = im; pk0 = k0; pn = K - k0 < 2 ? K - k0 : 2;
+        ++bidx;
+      }
+    }
+    asm volatile("" ::: "memory");
+    raw_barrier();
+    asm volatile("" ::: "memory");
+    flush((bidx - 1) & 1);
+    return;
+  }
+  // -------------------------------------------------------------------- consumers
+  MDS_SETPRIO(2);
+  const int i = lane & 15, q = lane >> 4;
+  const int nsl = wave % NSPL, sg = wave / NSPL;
+  const int cb = nsl * 16 * NF;
+  u16x8 wr[3][3][KS][NF];                                   // [ky][kx][k-step][output fragment]
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const int ch = c0 + cb + 4 * NF * (i >> 2) + 4 * nf + (i & 3);
+          wr[ky][kx][s][nf] = *(const u16x8*)(g.w + ((long)ch * g.wtaps + g.tapw[3 * ky + kx]) * CIN + 8 * (4 * s + q));
+        }
+  int xoff[2][KS];                                          // [0]: the pixel itself (taps kx = 0, 1), [1]: its left neighbour (kx = 2)
+#pragma unroll
+  for (int dxi = 0; dxi < 2; ++dxi)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int p = i + 1 - dxi, part = 4 * s + q;
+      xoff[dxi][s] = (p * PP + (part + ((C3Swz<CIN>::A * p) >> C3Swz<CIN>::SH)) % PP) * 16 + sg * 256 * PP;
+    }
+  f32x4 ev[2][2][NF], od[2][NF];                            // even output rows: [rolling set][x parity]; odd output row: [x parity]
+  int slot = 0, bpar = 0;
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item(g, it, WBI);
+    const int K = im.r1 - im.r0 + 1;
+    auto batch = [&](auto fullc, auto headc, int k0, int n) {
+      constexpr bool FULL = decltype(fullc)::value, HEAD = decltype(headc)::value;
+      wait_lgkm0();
+      raw_barrier();
+      asm volatile("" ::: "memory");
+      char* const sbat = stg + bpar * 4 * STGROW;
+      bpar ^= 1;
+      const char* rows[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        rows[j] = smem + slot * ROWB;
+        if (FULL || j < n) slot = slot + 1 == g.NR ? 0 : slot + 1;
+      }
+      u16x8 xs[2][KS];
+      auto load_chunk = [&](int c) {       // chunk c = (row c / 2, left-neighbour flag c % 2)
+        const int j = c >> 1, dxi = c & 1;
+        if (FULL || j < n) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) xs[c & 1][s] = *(const u16x8*)(rows[j] + xoff[dxi][s]);
+        }
+      };
+      load_chunk(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = c >> 1, dxi = c & 1;
+        if (c + 1 < 4) load_chunk(c + 1);
+        if (FULL || j < n) {
+          const bool head = HEAD && j == 0;                 // row r0 - 1: only the taps that reach down into the item (ky = 2)
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int ky = 2; ky >= 0; --ky) {
+              if (head && ky != 2) continue;
+#pragma unroll
+              for (int nf = 0; nf < NF; ++nf) {
+                // ky = 0 adds to the set row a - 1 opened (ev[j]), ky = 1 is the odd row (fresh), ky = 2 opens ev[j ^ 1] (fresh)
+                if (dxi == 0) {
+                  f32x4& te = ky == 0 ? ev[j][0][nf] : (ky == 1 ? od[0][nf] : ev[j ^ 1][0][nf]);
+                  f32x4& to = ky == 0 ? ev[j][1][nf] : (ky == 1 ? od[1][nf] : ev[j ^ 1][1][nf]);
+                  if (ky != 0 && s == 0) {
+                    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f}, z2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    mma16(wr[ky][0][s][nf], xs[c & 1][s], z);  te = z;
+                    mma16(wr[ky][1][s][nf], xs[c & 1][s], z2); to = z2;
+                  } else {
+                    mma16(wr[ky][0][s][nf], xs[c & 1][s], te);
+                    mma16(wr[ky][1][s][nf], xs[c & 1][s], to);
+                  }
+                } else {
+                  f32x4& te = ky == 0 ? ev[j][0][nf] : (ky == 1 ? od[0][nf] : ev[j ^ 1][0][nf]);
+                  mma16(wr[ky][2][s][nf], xs[c & 1][s], te);
+                }
+              }
+            }
+          if (dxi == 1) {
+            // rows 2a (ev[j]) and 2a + 1 (od) of the band are complete: convert and stage (the store waves skip an item's row r0 - 1)
+            const int clb = 2 * (16 * sg + i);
+#pragma unroll
+            for (int yp = 0; yp < 2; ++yp)
+#pragma unroll
+              for (int xp = 0; xp < 2; ++xp) {
+                const int cl = clb + xp;
+                char* const sp = sbat + ((j * 2 + yp) * WBO + cl) * (COUT * 2);
+                const int rot = (cl >> RSH) % CPP;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                  const f32x4& t = yp == 0 ? ev[j][xp][nf] : od[xp][nf];
+                  const int o = (cb + 4 * NF * q + 4 * nf) * 2;
+                  float v4[4] = {t[0], t[1], t[2], t[3]};
+                  store4((bf16_t*)(sp + ((o / 16 + rot) % CPP) * 16 + (o & 8)), v4);
+                }
+              }
+          }
+        }
+      }
+    };
+    for (int k0 = 0; k0 < K; k0 += 2) {
+      if (k0 + 2 <= K) {
+        if (k0 == 0) batch(std::true_type(), std::true_type(), k0, 2);
+        else batch(std::true_type(), std::false_type(), k0, 2);
+      } else {
+        if (k0 == 0) batch(std::false_type(), std::true_type(), k0, K - k0);
+        else batch(std::false_type(), std::false_type(), k0, K - k0);
+      }
+    }
+  }
+  wait_lgkm0();
+  raw_barrier();
+}
+
 // host side ------------------------------------------------------------------------------------------------------------
 template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW>
 static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
@@ -504,7 +769,7 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
   const int WB = CFN::WB, rowb = res ? CFR::ROWB : CFN::ROWB, pieces = res ? CFR::PIECES : CFN::PIECES;
   C3Args g;
   g.x = (const bf16_t*)a->x; g.w = (const bf16_t*)a->w; g.y = (bf16_t*)a->y; g.res = (const bf16_t*)a->residual; g.stats = a->stats;
-  g.N = a->N; g.H = a->IH; g.W = a->IW; g.wtaps = a->wtaps; g.Ctot = a->Cout;
+  g.N = a->N; g.H = a->IH; g.W = a->IW; g.OH = a->OH; g.OW = a->OW; g.wtaps = a->wtaps; g.Ctot = a->Cout;
   const int passes = a->Cout / CFN::COUT;
   for (int t = 0; t < 9; ++t) g.tapw[t] = tapw[t];
   // rows in flight: ~40 KB per CU ahead of the consumers (HBM latency x a CU's share of the bandwidth), at least 3 rows;
@@ -546,9 +811,79 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
   return 1;
 }
 
+
+template <int CIN, int NF, int NSPL, int NPW, int NSW>
+static int c3t_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
+  constexpr int PP = CIN / 8, NSG = 4 / NSPL, WBI = 16 * NSG, COUT = 16 * NF * NSPL;
+  constexpr int RS = (WBI + 1) * PP, PIECES = (RS + 63) / 64, ROWB = RS * 16;
+  C3Args g;
+  g.x = (const bf16_t*)a->x; g.w = (const bf16_t*)a->w; g.y = (bf16_t*)a->y; g.res = nullptr; g.stats = nullptr;
+  g.N = a->N; g.H = a->IH; g.W = a->IW; g.OH = a->OH; g.OW = a->OW; g.wtaps = a->wtaps; g.Ctot = a->Cout;
+  for (int t = 0; t < 9; ++t) g.tapw[t] = tapw[t];
+  const int passes = a->Cout / COUT;
+  const int pcw = (PIECES + NPW - 1) / NPW;
+  const size_t stage = 8 * (size_t)(2 * WBI) * COUT * 2;
+  int RA = (64 * 1024 + ROWB - 1) / ROWB;
+  if (RA < 2) RA = 2;
+  while (RA > 2 && pcw * (RA - 1) > 40) --RA;
+  if (pcw * (RA - 1) > 40) return 0;
+  int NR = RA + 2;
+  while ((size_t)NR * ROWB + stage > 156 * 1024 && RA > 2) { --RA; NR = RA + 2; }
+  if ((size_t)NR * ROWB + stage > 156 * 1024) return 0;
+  g.RA = RA; g.NR = NR; g.dbg = 0; g.trace = nullptr;
+  int CUS = 256 / passes;
+  if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);
+  g.nbands = cdiv(a->IW, WBI);
+  long best = -1;
+  for (int ns = 1; ns <= 64 && ns <= a->IH; ++ns) {
+    const int rps = cdiv(a->IH, ns), nsr = cdiv(a->IH, rps);
+    const long items = (long)a->N * g.nbands * nsr;
+    const long per = (items + CUS - 1) / CUS;
+    const long cost = per * (rps + 1 + 2);
+    if (best < 0 || cost < best) { best = cost; g.nseg = nsr; g.rps = rps; g.items = (int)items; }
+  }
+  const int grid = g.items < CUS ? g.items : CUS;
+  const size_t smem = (size_t)NR * ROWB + stage;
+  dim3 block(256 + 64 * (NPW + NSW));
+  if (2 * a->IW != a->OW || a->IW % WBI != 0) MDS_LAUNCH((c3t_kernel<CIN, NF, NSPL, NPW, NSW, true>), dim3(grid, passes), block, smem, stream, g);
+  else MDS_LAUNCH((c3t_kernel<CIN, NF, NSPL, NPW, NSW, false>), dim3(grid, passes), block, smem, stream, g);
+  return 1;
+}
+
+// the stride-2 data gradient as mds_conv_fwd receives it: four tap groups (one per output parity), is = 1, os = 2
+static int c3t_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
+  if (a->dtype != MDS_BF16 || a->is != 1 || a->os != 2 || a->ngroups != 4 || a->ntaps != 9) return 0;
+  if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE || a->residual || a->stats) return 0;
+  if (a->OH != 2 * a->IH && a->OH != 2 * a->IH - 1) return 0;
+  if (a->OW != 2 * a->IW && a->OW != 2 * a->IW - 1) return 0;
+  if ((long)a->OH * a->OW * (a->Cin > a->Cout ? a->Cin : a->Cout) >= (1L << 30)) return 0;
+  int tapw[9];
+  for (int t = 0; t < 9; ++t) tapw[t] = -1;
+  int t = 0;
+  for (int gi = 0; gi < 4; ++gi) {
+    const int py = a->g_oy0[gi], px = a->g_ox0[gi];
+    if (py < 0 || py > 1 || px < 0 || px > 1) return 0;
+    for (int u = 0; u < a->g_ntaps[gi]; ++u, ++t) {
+      // pads 0: output 2a + py reads input a + dy with (py, dy) in {(0, 0): ky 0, (0, -1): ky 2, (1, 0): ky 1}; the same in x
+      const int dy = a->dy[t], dx = a->dx[t];
+      const int ky = py == 1 ? (dy == 0 ? 1 : -1) : (dy == 0 ? 0 : (dy == -1 ? 2 : -1));
+      const int kx = px == 1 ? (dx == 0 ? 1 : -1) : (dx == 0 ? 0 : (dx == -1 ? 2 : -1));
+      if (ky < 0 || kx < 0 || tapw[3 * ky + kx] >= 0) return 0;
+      tapw[3 * ky + kx] = a->wi[t];
+    }
+  }
+  for (int u = 0; u < 9; ++u) if (tapw[u] < 0 || tapw[u] >= a->wtaps) return 0;
+  const long rows = (long)a->N * a->OH * a->OW;
+  if (rows < 16384 && mds_knob(MDS_KNOB_C3) != 2) return 0;
+  if (a->Cin == 128 && a->Cout == 32) return c3t_launch<128, 1, 2, 3, 1>(a, tapw, stream);
+  if (a->Cin == 64 && a->Cout == 16) return c3t_launch<64, 1, 1, 2, 2>(a, tapw, stream);
+  return 0;
+}
+
 // 1 = launched, 0 = not a shape of this kernel (the caller goes on to k_conv.hip's kernels)
 int c3_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
   if (mds_knob(MDS_KNOB_C3) == 1) return 0;
+  if (a->ngroups == 4) return c3t_try(a, stream);
   if (a->dtype != MDS_BF16 || a->is != 1 || a->os != 1 || a->ntaps != 9 || a->ngroups > 1) return 0;
   if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE) return 0;
   if (a->A != a->OH || a->B != a->OW || a->OH != a->IH || a->OW != a->IW || a->oy0 || a->ox0) return 0;

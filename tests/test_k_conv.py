@@ -269,6 +269,26 @@ def test_c3_filter_in_registers(be, N, H, W, Cin, Cout, res, stats, blocks):
     assert_close(y, ref, "bf16", msg="y")
 
 
+C3T_CASES = [  # N, H, W (of the layer's input = the gradient that comes out), Cin, Cout of the FORWARD layer, block cap
+    (2, 12, 64, 32, 128, 0),       # blocks.2.0's data gradient (128 -> 32 channels): two images, exact bands
+    (1, 22, 40, 32, 128, 2),       # ragged band (20 gradient columns per 32-column band), two blocks walk several items
+    (1, 8, 128, 16, 64, 0),        # blocks.1.0's (64 -> 16): 64-column bands, one wave per strip
+    (1, 30, 70, 16, 64, 3),
+    (1, 2, 32, 32, 128, 1),        # a single input row per item
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,blocks", C3T_CASES)
+def test_c3t_stride2_data_gradient(be, N, H, W, Cin, Cout, blocks):
+    """k_c3.hip's transposed-convolution kernel (bf16, even extents: TF-SAME pads 0 / 1) through the tap-group form of
+    mds_conv_fwd that engine._conv_dgrad launches, against autograd; MDS_KNOB_C3 = 2 lifts the size bar"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
+    try:
+        test_conv_dgrad_s2_tap_groups(be, "bf16", N, H, W, Cin, Cout, blocks)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+
+
 def _rand_cases(n, seed):
     import random
     r = random.Random(seed)
