@@ -42,6 +42,8 @@ struct C3Args {
   int nbands, nseg, rps, items;
   int RA, NR;
   int dbg;             // MDS_KNOB_C3_DBG bits
+  // post statistics (mds_poststat_t; PLAIN, or MASK with one value per image): sum g, sum g * xhat of the BatchNorm below
+  const bf16_t* py; const float* pbn; const float* pmask; double* pstats;
   void* trace;         // C3_TRACE builds: 160 x 8 x 4 cycle stamps of one block (passed in mds_conv_fwd_args.epi.scale, mode NONE)
 };
 
@@ -55,7 +57,7 @@ template <> struct C3Swz<64> { static constexpr int A = 1, SH = 0; };
 template <> struct C3Swz<128> { static constexpr int A = 2, SH = 0; };
 template <> struct C3Swz<192> { static constexpr int A = 1, SH = 0; };
 
-template <int CIN, int NF, int NSPL, int SPW, bool RES> struct C3Cfg {
+template <int CIN, int NF, int NSPL, int SPW, bool RES, bool POST = false> struct C3Cfg {
   static constexpr int PP = CIN / 8;                 // 16-byte parts per input pixel
   static constexpr int KSR = (3 * PP + 3) / 4;       // k-steps (32 channels) of one input row: 3 dx x CIN, flattened
   static constexpr int NSG = 4 / NSPL;               // strip groups among the four consumer waves
@@ -64,7 +66,8 @@ template <int CIN, int NF, int NSPL, int SPW, bool RES> struct C3Cfg {
   static constexpr int CP = COUT / 8;                // 16-byte parts per output pixel (residual operand)
   static constexpr int RPX = (WB + 2) * PP;          // 16-byte slots of one input row of the band (+ halo)
   static constexpr int RPXP = RES ? (RPX + 63) / 64 * 64 : RPX;   // the residual row starts on a DMA-piece boundary: a piece is all input or all residual
-  static constexpr int RS = RPXP + (RES ? WB * CP : 0);
+  static constexpr int RPYP = (RPXP + (RES ? WB * CP : 0) + (POST ? 63 : 0)) / (POST ? 64 : 1) * (POST ? 64 : 1);   // post.y's row of the band: on a piece boundary too
+  static constexpr int RS = RPYP + (POST ? WB * CP : 0);
   static constexpr int PIECES = (RS + 63) / 64;      // LDS-DMA instructions per row
   static constexpr int ROWB = RS * 16;
 };
@@ -105,9 +108,11 @@ template <> struct C3Out<3> {
 #define C3_STAMP(b_, ph_) ((void)0)
 #endif
 
-template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool RES, bool STATS, bool MASKED>
+template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool RES, bool STATS, bool MASKED, bool POST = false>
 __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
-  typedef C3Cfg<CIN, NF, NSPL, SPW, RES> CF;
+  typedef C3Cfg<CIN, NF, NSPL, SPW, RES, POST> CF;
+  constexpr int RPYP = CF::RPYP;
+  static_assert(!(POST && STATS), "forward statistics and post statistics never meet");
   constexpr int PP = CF::PP, KSR = CF::KSR, WB = CF::WB, COUT = CF::COUT, CP = CF::CP, RPX = CF::RPX, RPXP = CF::RPXP, RS = CF::RS;
   constexpr int PIECES = CF::PIECES, ROWB = CF::ROWB;
   constexpr int CPP = COUT / 8;                      // 16-byte chunks of an output pixel
@@ -145,8 +150,11 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
         const int p = sg_ / PP, psw = sg_ - p * PP;
         const int rot = ((C3Swz<CIN>::A * p) >> C3Swz<CIN>::SH) % PP;
         dcol[j] = p - 1; eoff[j] = 8 * ((psw - rot + PP) % PP);
-      } else if (sg_ >= RPXP && sg_ < RS) {
+      } else if (RES && sg_ >= RPXP && sg_ < RPXP + WB * CP) {
         const int t = sg_ - RPXP, p = t / CP;
+        dcol[j] = p; eoff[j] = 8 * (t - p * CP);
+      } else if (POST && sg_ >= RPYP && sg_ < RS) {
+        const int t = sg_ - RPYP, p = t / CP;
         dcol[j] = p; eoff[j] = 8 * (t - p * CP);
       } else {
         dcol[j] = -(1 << 30); eoff[j] = 0;
@@ -164,19 +172,21 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
     auto open_item = [&]() {
       const char* xrow0 = (const char*)g.x + ((long)him.n * g.H + him.r0 - 1) * g.W * CIN * 2;                   // entry 0's rows:
       const char* rrow0 = RES ? (const char*)(g.res + c0) + ((long)him.n * g.H + him.r0 - 2) * g.W * g.Ctot * 2 : nullptr;   // r0 - 1 / r0 - 2
+      const char* yrow0 = POST ? (const char*)(g.py + c0) + ((long)him.n * g.H + him.r0 - 2) * g.W * g.Ctot * 2 : nullptr;
 #pragma unroll
       for (int j = 0; j < PCWMAX; ++j) {
-        const bool isres = RES && 64 * (pw + NPW * j) >= RPXP;
+        const bool isy = POST && 64 * (pw + NPW * j) >= RPYP;
+        const bool isres = (RES || POST) && 64 * (pw + NPW * j) >= RPXP;           // an output-shaped row (residual or post.y)
         const int gx = him.x0 + dcol[j];
         const bool ok = gx >= 0 && gx < g.W;
-        cur[j] = ok ? (isres ? rrow0 : xrow0) + (gx * (isres ? g.Ctot : CIN) + eoff[j]) * 2 : (const char*)c3_zero_page;
+        cur[j] = ok ? (isy ? yrow0 : (isres ? rrow0 : xrow0)) + (gx * (isres ? g.Ctot : CIN) + eoff[j]) * 2 : (const char*)c3_zero_page;
         step[j] = ok ? (unsigned)(g.W * (isres ? g.Ctot : CIN) * 2) : 0u;
       }
     };
     open_item();
     auto issue = [&]() {
       const int ri = him.r0 - 1 + hk, ro = ri - 1;
-      const bool xok = ri >= 0 && ri < g.H, rok = !RES || (ro >= 0 && ro < g.H);
+      const bool xok = ri >= 0 && ri < g.H, rok = !(RES || POST) || (ro >= 0 && ro < g.H);
       const lds_t dst = ring + (lds_t)(hslot * ROWB);
       hslot = hslot + 1 == g.NR ? 0 : hslot + 1;
       if (xok && rok) {
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
         for (int j = 0; j < PCWMAX; ++j) {
           const int pi = pw + NPW * j;
           if (pi < PIECES) {
-            const bool isres = RES && 64 * pi >= RPXP;              // wave-uniform
+            const bool isres = (RES || POST) && 64 * pi >= RPXP;              // wave-uniform
             const char* src = (isres ? rok : xok) ? cur[j] : (const char*)c3_zero_page;
             if (dcol[j] > -(1 << 29)) glds16(src, dst + (lds_t)(pi * 1024));
             cur[j] += step[j];
@@ -249,17 +259,42 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
     int bidx = 0;
     C3Item pim = c3_item(g, blockIdx.x, WB);
     int pk0 = 0, pn = 0;
+    // POST (mds_poststat_t): the rows these waves move out are u of the BatchNorm below.  Its raw input y came through the ring
+    // with the batch (with post statistics the ring is three rows longer: a batch's slots stay untouched until the barrier after
+    // next), so sum g and sum g * xhat - of the
+    // stored, rounded values - cost the consumers nothing.
+    int rslot = 0, pslot = 0;                             // ring slot of the next row / of the previous batch's first row
+    float ps[8], pss[8], pmu[8], prs[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      ps[c] = 0.f; pss[c] = 0.f;
+      pmu[c] = POST ? g.pbn[2 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
+      prs[c] = POST ? g.pbn[3 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
+    }
     auto flush = [&](int par) {
+      const float pmk = (POST && g.pmask) ? g.pmask[pim.n] : 1.f;      // MASK: DropPath's per-image factor
       for (int j = 0; j < pn; ++j) {
         const int k = pk0 + j, ro = pim.r0 + k - 2;
         if (k < 2 || ro >= pim.r1) continue;              // a row above / below the item: zeros or partial sums, never stored
         const char* srow = stg + (par * 3 + j) * STGROW;
+        int rs_ = pslot + j;
+        if (rs_ >= g.NR) rs_ -= g.NR;
+        const bf16_t* yrow = (const bf16_t*)(smem + rs_ * ROWB + RPYP * 16);
         bf16_t* const orow = g.y + c0 + (((long)pim.n * g.H + ro) * g.W + pim.x0) * g.Ctot;
         for (int pc = sw; pc < NP; pc += NSW) {
           const int cl = pc * PPP + lpx;
           if (lact && cl < WB && (!MASKED || pim.x0 + cl < g.W)) {
             const u16x8 v = *(const u16x8*)(srow + (cl * CPP + (chunk + (cl >> RSH)) % CPP) * 16);
             *(u16x8*)(orow + cl * g.Ctot + 8 * chunk) = v;
+            if (POST) {
+              const u16x8 yv = *(const u16x8*)(yrow + cl * COUT + 8 * chunk);
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                const float gg = bf2f(v[c]) * pmk;
+                ps[c] += gg;
+                pss[c] += gg * ((bf2f(yv[c]) - pmu[c]) * prs[c]);
+              }
+            }
           }
         }
       }
@@ -273,6 +308,8 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
         asm volatile("" ::: "memory");
         if (bidx > 0) flush((bidx - 1) & 1);
         pim = im; pk0 = k0; pn = K - k0 < 3 ? K - k0 : 3;
+        pslot = rslot; rslot += pn;
+        if (rslot >= g.NR) rslot -= g.NR;
         ++bidx;
       }
     }
@@ -280,6 +317,18 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
     raw_barrier();
     asm volatile("" ::: "memory");
     flush((bidx - 1) & 1);
+    if (POST) {      // lanes chunk, chunk + CPP, ... hold the same channels
+      double* st = g.pstats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * g.Ctot + c0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float a = lact ? ps[c] : 0.f, b = lact ? pss[c] : 0.f;
+        for (int o = CPP; o < 64; o += CPP) { a += __shfl_down(lact ? ps[c] : 0.f, o); b += __shfl_down(lact ? pss[c] : 0.f, o); }
+        if (lane < CPP) {
+          atomicAdd(st + 8 * chunk + c, (double)a);
+          atomicAdd(st + g.Ctot + 8 * chunk + c, (double)b);
+        }
+      }
+    }
 #ifdef C3_TRACE
     raw_barrier();
 #endif
@@ -319,7 +368,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
     xoff[s] = (p * PP + (part + ((C3Swz<CIN>::A * p) >> C3Swz<CIN>::SH)) % PP) * 16 + sg * SPW * 256 * PP;
   }
   f32x4 acc[3][SPW][NF];
-  float ps[4 * NF], pss[4 * NF];          // BatchNorm sums of this lane's channels (forward layers), taken from the fp32 accumulators
+  float ps[4 * NF], pss[4 * NF];          // BatchNorm sums of this lane's channels: forward statistics (sum, sum of squares) or post statistics (sum g, sum g * xhat)
 #pragma unroll
   for (int c = 0; c < 4 * NF; ++c) { ps[c] = 0.f; pss[c] = 0.f; }
   int slot = 0;                                              // ring slot of the next row to consume
@@ -506,10 +555,12 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
 //     and, read one pixel to the left, the even columns again (kx = 2): 9 KS NF MFMAs per 2 KS fragment reads;
 //   * batches of two rows (the rolling set's period); an item's first row (a = r0 - 1) only contributes its ky = 2 taps.
 // k_conv.hip evaluates this layer as four tap groups with a 16 x NF-wide LDS filter slab: one MFMA per two fragment reads.
-template <int CIN, int NF, int NSPL, int NPW, int NSW, bool MASKED>
+template <int CIN, int NF, int NSPL, int NPW, int NSW, bool MASKED, bool POST>
 __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
   constexpr int PP = CIN / 8, KS = CIN / 32, NSG = 4 / NSPL, WBI = 16 * NSG, WBO = 2 * WBI, COUT = 16 * NF * NSPL, CPP = COUT / 8;
-  constexpr int RS = (WBI + 1) * PP, PIECES = (RS + 63) / 64, ROWB = RS * 16;
+  constexpr int RSX = (WBI + 1) * PP;                // the input row of the band (+ the left neighbour pixel)
+  constexpr int RPYP = (RSX + 63) / 64 * 64;         // POST: post.y's two output rows of the band follow on a piece boundary
+  constexpr int RS = POST ? RPYP + 2 * WBO * CPP : RSX, PIECES = (RS + 63) / 64, ROWB = RS * 16;
   constexpr int STGROW = WBO * COUT * 2;
   constexpr int RSH = CPP == 4 ? 1 : 0;
   static_assert(CIN % 32 == 0, "whole k-steps per tap");
@@ -533,10 +584,13 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
 #pragma unroll
     for (int j = 0; j < PCWMAX; ++j) {
       const int sg_ = 64 * (pw + NPW * j) + lane;
-      if (sg_ < RS) {
+      if (sg_ < RSX) {
         const int p = sg_ / PP, psw = sg_ - p * PP;
         const int rot = ((C3Swz<CIN>::A * p) >> C3Swz<CIN>::SH) % PP;
         dcol[j] = p - 1; eoff[j] = 8 * ((psw - rot + PP) % PP);
+      } else if (POST && sg_ >= RPYP && sg_ < RS) {
+        const int t = sg_ - RPYP, yr = t / (WBO * CPP), u = t - yr * (WBO * CPP), p = u / CPP;
+        dcol[j] = p + (yr << 20); eoff[j] = 8 * (u - p * CPP);      // output column (relative to 2 x0) and, in bit 20, the output row's parity
       } else {
         dcol[j] = -(1 << 30); eoff[j] = 0;
       }
@@ -549,12 +603,20 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
     unsigned step[PCWMAX];
     auto open_item = [&]() {
       const char* xrow0 = (const char*)g.x + ((long)him.n * g.H + him.r0 - 1) * g.W * CIN * 2;
+      const char* yrow0 = POST ? (const char*)(g.py + c0) + ((long)him.n * g.OH + 2 * (him.r0 - 1)) * g.OW * g.Ctot * 2 : nullptr;
 #pragma unroll
       for (int j = 0; j < PCWMAX; ++j) {
-        const int gx = him.x0 + dcol[j];
-        const bool ok = gx >= 0 && gx < g.W;
-        cur[j] = ok ? xrow0 + (gx * CIN + eoff[j]) * 2 : (const char*)c3_zero_page;
-        step[j] = ok ? (unsigned)(g.W * CIN * 2) : 0u;
+        if (POST && 64 * (pw + NPW * j) >= RPYP) {
+          const int yr = dcol[j] >> 20, gx = 2 * him.x0 + (dcol[j] & 0xfffff);
+          const bool ok = dcol[j] >= 0 && gx < g.OW && 2 * (g.H - 1) + yr < g.OH;
+          cur[j] = ok ? yrow0 + ((long)(yr * g.OW + gx) * g.Ctot + eoff[j]) * 2 : (const char*)c3_zero_page;
+          step[j] = ok ? (unsigned)(2 * g.OW * g.Ctot * 2) : 0u;
+        } else {
+          const int gx = him.x0 + dcol[j];
+          const bool ok = gx >= 0 && gx < g.W;
+          cur[j] = ok ? xrow0 + (gx * CIN + eoff[j]) * 2 : (const char*)c3_zero_page;
+          step[j] = ok ? (unsigned)(g.W * CIN * 2) : 0u;
+        }
       }
     };
     open_item();
@@ -604,20 +666,41 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
     int bidx = 0;
     C3Item pim = c3_item(g, blockIdx.x, WBI);
     int pk0 = 0, pn = 0;
+    int rslot = 0, pslot = 0;                             // POST (see c3_kernel's store waves): ring slot of the next row / of the previous batch's first row
+    float ps[8], pss[8], pmu[8], prs[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      ps[c] = 0.f; pss[c] = 0.f;
+      pmu[c] = POST ? g.pbn[2 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
+      prs[c] = POST ? g.pbn[3 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
+    }
     auto flush = [&](int par) {
+      const float pmk = (POST && g.pmask) ? g.pmask[pim.n] : 1.f;
       for (int j = 0; j < pn; ++j) {
         const int k = pk0 + j, a = pim.r0 - 1 + k;
         if (k < 1) continue;                              // the item's first row only opens the carried set
+        int rs_ = pslot + j;
+        if (rs_ >= g.NR) rs_ -= g.NR;
         for (int yp = 0; yp < 2; ++yp) {
           const int Y = 2 * a + yp;
           if (Y >= g.OH) continue;
           const char* srow = stg + ((par * 2 + j) * 2 + yp) * STGROW;
+          const bf16_t* yrow = (const bf16_t*)(smem + rs_ * ROWB + RPYP * 16) + yp * WBO * COUT;
           bf16_t* const orow = g.y + c0 + (((long)pim.n * g.OH + Y) * g.OW + 2 * pim.x0) * g.Ctot;
           for (int pc = sw; pc < NP; pc += NSW) {
             const int cl = pc * PPP + lpx;
             if (lact && cl < WBO && (!MASKED || 2 * pim.x0 + cl < g.OW)) {
               const u16x8 v = *(const u16x8*)(srow + (cl * CPP + (chunk + (cl >> RSH)) % CPP) * 16);
               *(u16x8*)(orow + cl * g.Ctot + 8 * chunk) = v;
+              if (POST) {
+                const u16x8 yv = *(const u16x8*)(yrow + cl * COUT + 8 * chunk);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                  const float gg = bf2f(v[c]) * pmk;
+                  ps[c] += gg;
+                  pss[c] += gg * ((bf2f(yv[c]) - pmu[c]) * prs[c]);
+                }
+              }
             }
           }
         }
@@ -632,6 +715,8 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
         asm volatile("" ::: "memory");
         if (bidx > 0) flush((bidx - 1) & 1);
         pim = im; pk0 = k0; pn = K - k0 < 2 ? K - k0 : 2;
+        pslot = rslot; rslot += pn;
+        if (rslot >= g.NR) rslot -= g.NR;
         ++bidx;
       }
     }
@@ -639,6 +724,18 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
     raw_barrier();
     asm volatile("" ::: "memory");
     flush((bidx - 1) & 1);
+    if (POST) {
+      double* st = g.pstats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * g.Ctot + c0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float a = lact ? ps[c] : 0.f, b = lact ? pss[c] : 0.f;
+        for (int o = CPP; o < 64; o += CPP) { a += __shfl_down(lact ? ps[c] : 0.f, o); b += __shfl_down(lact ? pss[c] : 0.f, o); }
+        if (lane < CPP) {
+          atomicAdd(st + 8 * chunk + c, (double)a);
+          atomicAdd(st + g.Ctot + 8 * chunk + c, (double)b);
+        }
+      }
+    }
     return;
   }
   // -------------------------------------------------------------------- consumers
@@ -765,8 +862,10 @@ template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW>
 static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
   typedef C3Cfg<CIN, NF, NSPL, SPW, true> CFR;
   typedef C3Cfg<CIN, NF, NSPL, SPW, false> CFN;
-  const bool res = a->residual != nullptr, stats = a->stats != nullptr;
-  const int WB = CFN::WB, rowb = res ? CFR::ROWB : CFN::ROWB, pieces = res ? CFR::PIECES : CFN::PIECES;
+  typedef C3Cfg<CIN, NF, NSPL, SPW, true, true> CFP;
+  const bool res = a->residual != nullptr, stats = a->stats != nullptr, post = a->post.mode != MDS_POST_NONE;
+  if (post && (!res || stats)) return 0;      // (post statistics are instantiated for the residual form: blocks.1.1's data gradient)
+  const int WB = CFN::WB, rowb = post ? CFP::ROWB : (res ? CFR::ROWB : CFN::ROWB), pieces = post ? CFP::PIECES : (res ? CFR::PIECES : CFN::PIECES);
   C3Args g;
   g.x = (const bf16_t*)a->x; g.w = (const bf16_t*)a->w; g.y = (bf16_t*)a->y; g.res = (const bf16_t*)a->residual; g.stats = a->stats;
   g.N = a->N; g.H = a->IH; g.W = a->IW; g.OH = a->OH; g.OW = a->OW; g.wtaps = a->wtaps; g.Ctot = a->Cout;
@@ -779,11 +878,13 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
   if (RA < 3) RA = 3;
   while (RA > 3 && pcw * (RA - 1) > 40) --RA;
   if (pcw * (RA - 1) > 40) return 0;
-  int NR = RA + 3;
-  const size_t lds_cap = 156 * 1024 - 6 * (size_t)WB * CFN::COUT * 2;     // the staged output rows share the LDS
-  while ((size_t)NR * rowb > lds_cap && RA > 3) { --RA; NR = RA + 3; }
+  const int keep = post ? 6 : 3;      // ring rows beyond the RA in flight: the batch being read (+ with post statistics the one before: its y rows serve the store waves)
+  int NR = RA + keep;
+  const size_t lds_cap = 155 * 1024 - 6 * (size_t)WB * CFN::COUT * 2;     // the staged output rows share the LDS
+  while ((size_t)NR * rowb > lds_cap && RA > 3) { --RA; NR = RA + keep; }
   if ((size_t)NR * rowb > lds_cap) return 0;
   g.RA = RA; g.NR = NR; g.dbg = mds_knob(MDS_KNOB_C3_DBG); g.trace = (void*)a->epi.scale;
+  g.py = (const bf16_t*)a->post.y; g.pbn = a->post.bn; g.pmask = a->post.mode == MDS_POST_MASK ? a->post.mask : nullptr; g.pstats = a->post.stats;
   // items: bands x row segments, the segment count that minimises the longest block's rows (+2 halo rows, + a fill per item)
   int CUS = 256 / passes;
   if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);      // tests: few blocks, many items each
@@ -805,7 +906,10 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
   const bool masked = a->IW % WB != 0;
 #define C3_GO(R, S) do { if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, true>), dim3(grid, passes), block, smem, stream, g); \
                          else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, false>), dim3(grid, passes), block, smem, stream, g); } while (0)
-  if (res) { if (stats) return 0; C3_GO(true, false); }      // (a residual operand and statistics never meet in the network)
+  if (post) {
+    if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, true, false, true, true>), dim3(grid, passes), block, smem, stream, g);
+    else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, true, false, false, true>), dim3(grid, passes), block, smem, stream, g);
+  } else if (res) { if (stats) return 0; C3_GO(true, false); }      // (a residual operand and statistics never meet in the network)
   else { if (stats) C3_GO(false, true); else C3_GO(false, false); }
 #undef C3_GO
   return 1;
@@ -815,7 +919,9 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
 template <int CIN, int NF, int NSPL, int NPW, int NSW>
 static int c3t_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
   constexpr int PP = CIN / 8, NSG = 4 / NSPL, WBI = 16 * NSG, COUT = 16 * NF * NSPL;
-  constexpr int RS = (WBI + 1) * PP, PIECES = (RS + 63) / 64, ROWB = RS * 16;
+  const bool post = a->post.mode != MDS_POST_NONE;
+  constexpr int RSX = (WBI + 1) * PP, RPYP = (RSX + 63) / 64 * 64;
+  const int RS = post ? RPYP + 2 * (2 * WBI) * (COUT / 8) : RSX, PIECES = (RS + 63) / 64, ROWB = RS * 16;
   C3Args g;
   g.x = (const bf16_t*)a->x; g.w = (const bf16_t*)a->w; g.y = (bf16_t*)a->y; g.res = nullptr; g.stats = nullptr;
   g.N = a->N; g.H = a->IH; g.W = a->IW; g.OH = a->OH; g.OW = a->OW; g.wtaps = a->wtaps; g.Ctot = a->Cout;
@@ -827,10 +933,12 @@ static int c3t_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stre
   if (RA < 2) RA = 2;
   while (RA > 2 && pcw * (RA - 1) > 40) --RA;
   if (pcw * (RA - 1) > 40) return 0;
-  int NR = RA + 2;
-  while ((size_t)NR * ROWB + stage > 156 * 1024 && RA > 2) { --RA; NR = RA + 2; }
+  const int keep = post ? 4 : 2;
+  int NR = RA + keep;
+  while ((size_t)NR * ROWB + stage > 156 * 1024 && RA > 2) { --RA; NR = RA + keep; }
   if ((size_t)NR * ROWB + stage > 156 * 1024) return 0;
   g.RA = RA; g.NR = NR; g.dbg = 0; g.trace = nullptr;
+  g.py = (const bf16_t*)a->post.y; g.pbn = a->post.bn; g.pmask = a->post.mode == MDS_POST_MASK ? a->post.mask : nullptr; g.pstats = a->post.stats;
   int CUS = 256 / passes;
   if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);
   g.nbands = cdiv(a->IW, WBI);
@@ -845,15 +953,27 @@ static int c3t_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stre
   const int grid = g.items < CUS ? g.items : CUS;
   const size_t smem = (size_t)NR * ROWB + stage;
   dim3 block(256 + 64 * (NPW + NSW));
-  if (2 * a->IW != a->OW || a->IW % WBI != 0) MDS_LAUNCH((c3t_kernel<CIN, NF, NSPL, NPW, NSW, true>), dim3(grid, passes), block, smem, stream, g);
-  else MDS_LAUNCH((c3t_kernel<CIN, NF, NSPL, NPW, NSW, false>), dim3(grid, passes), block, smem, stream, g);
+  const bool masked = 2 * a->IW != a->OW || a->IW % WBI != 0;
+#define C3T_GO(M, P) MDS_LAUNCH((c3t_kernel<CIN, NF, NSPL, NPW, NSW, M, P>), dim3(grid, passes), block, smem, stream, g)
+  if (post) { if (masked) C3T_GO(true, true); else C3T_GO(false, true); }
+  else { if (masked) C3T_GO(true, false); else C3T_GO(false, false); }
+#undef C3T_GO
   return 1;
+}
+
+// post statistics as these kernels take them: PLAIN, or MASK with one factor per image
+static bool c3_post_ok(const mds_conv_fwd_args* a) {
+  if (a->post.mode == MDS_POST_NONE) return true;
+  if (a->post.mode != MDS_POST_PLAIN && a->post.mode != MDS_POST_MASK) return false;
+  if (!a->post.y || !a->post.bn || !a->post.stats) return false;
+  return a->post.mode == MDS_POST_PLAIN || (a->post.mask && a->post.rows_per_group == (long)a->OH * a->OW);
 }
 
 // the stride-2 data gradient as mds_conv_fwd receives it: four tap groups (one per output parity), is = 1, os = 2
 static int c3t_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
   if (a->dtype != MDS_BF16 || a->is != 1 || a->os != 2 || a->ngroups != 4 || a->ntaps != 9) return 0;
   if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE || a->residual || a->stats) return 0;
+  if (!c3_post_ok(a)) return 0;
   if (a->OH != 2 * a->IH && a->OH != 2 * a->IH - 1) return 0;
   if (a->OW != 2 * a->IW && a->OW != 2 * a->IW - 1) return 0;
   if ((long)a->OH * a->OW * (a->Cin > a->Cout ? a->Cin : a->Cout) >= (1L << 30)) return 0;
@@ -885,7 +1005,7 @@ int c3_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
   if (mds_knob(MDS_KNOB_C3) == 1) return 0;
   if (a->ngroups == 4) return c3t_try(a, stream);
   if (a->dtype != MDS_BF16 || a->is != 1 || a->os != 1 || a->ntaps != 9 || a->ngroups > 1) return 0;
-  if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE) return 0;
+  if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE || !c3_post_ok(a)) return 0;
   if (a->A != a->OH || a->B != a->OW || a->OH != a->IH || a->OW != a->IW || a->oy0 || a->ox0) return 0;
   if ((long)a->IH * a->IW * (a->Cin > a->Cout ? a->Cin : a->Cout) >= (1L << 30)) return 0;
   int tapw[9];
@@ -903,5 +1023,15 @@ int c3_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
   if (a->Cin == 48 && a->Cout == 192) return c3_launch<48, 2, 2, 1, 2, 2>(a, tapw, stream);      // three passes of 64 channels: a 96-channel slice per wave pair does not fit the registers
   if (a->Cin == 16 && a->Cout == 32) return c3_launch<16, 2, 1, 1, 2, 2>(a, tapw, stream);
   if (a->Cin == 32 && a->Cout == 128) return alt ? c3_launch<32, 2, 4, 2, 1, 3>(a, tapw, stream) : c3_launch<32, 2, 4, 2, 2, 2>(a, tapw, stream);
+  return 0;
+}
+
+// what the planner asks before it folds a BatchNorm backward's sums into a 3x3 data gradient (engine._conv_dgrad): does the
+// launch - forward shape N x IH x IW x Cin -> Cout at `stride` - go to one of the kernels above that implement `post`?
+extern "C" int mds_conv_dgrad_post_ok(int dtype, int N, int IH, int IW, int Cin, int Cout, int stride, int has_residual) {
+  if (dtype != MDS_BF16 || mds_knob(MDS_KNOB_C3) == 1) return 0;
+  if ((long)N * IH * IW < 16384 && mds_knob(MDS_KNOB_C3) != 2) return 0;
+  if (stride == 1) return has_residual && Cout == 128 && Cin == 32;                       // c3_kernel<128 -> 32>, residual form
+  if (stride == 2) return !has_residual && IH % 2 == 0 && IW % 2 == 0 && ((Cout == 128 && Cin == 32) || (Cout == 64 && Cin == 16));
   return 0;
 }

@@ -497,7 +497,8 @@ extern "C" int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "conv_fwd: prologue needs scale/shift");
   MDS_REQUIRE(a->oy0 + (a->A - 1) * a->os < a->OH && a->ox0 + (a->B - 1) * a->os < a->OW, "conv_fwd: sub-grid exceeds output");
   MDS_REQUIRE(a->epi.mode == MDS_EPI_NONE || (a->epi.scale && a->epi.shift && !a->stats), "conv_fwd: an output transform needs scale/shift and excludes statistics");
-  if (c3_try(a, stream)) return mds_check_launch("conv_fwd");    // stride-1 bf16 layers whose filter slice fits the consumers' registers
+  if (c3_try(a, stream)) return mds_check_launch("conv_fwd");    // bf16 layers whose filter slice fits the consumers' registers (k_c3.hip)
+  MDS_REQUIRE(a->post.mode == MDS_POST_NONE, "conv_fwd: post statistics only where mds_conv_dgrad_post_ok() says so");
   int dymin, dxmin;
   const int eh = tap_extent(a->dy, a->ntaps, &dymin), ew = tap_extent(a->dx, a->ntaps, &dxmin);
   const int TA = a->is == 1 ? 16 : 8;

@@ -415,13 +415,21 @@ class Plan:
         bn.finalize(self, seg)
         return y, bn, OH, OW, (pt, pl)
 
-    def _conv_dgrad(self, seg, dyb, N, IH, IW, Cin, Cout, stride, wparam, pads, residual):
-        """grad wrt the conv input ([N][IH][IW][Cin]) from dy ([N][OH][OW][Cout])."""
+    def _conv_dgrad(self, seg, dyb, N, IH, IW, Cin, Cout, stride, wparam, pads, residual, head=None):
+        """grad wrt the conv input ([N][IH][IW][Cin]) from dy ([N][OH][OW][Cout]).  `head`: the BatchNorm backward that consumes
+        this gradient directly (the block below's last BatchNorm) - where the launch goes to a kernel that implements
+        mds_poststat_t (k_c3.hip: mds_conv_dgrad_post_ok) its sums are taken in the epilogue and the Grad says so."""
         OH, OW, _, _ = geo.conv_geometry(IH, IW, stride)
         w = self.pack(wparam, cabi.MDS_PACK_IO_FLIP, Cout, Cin, 9)
         dxb = self.act(N * IH * IW, Cin)
         common = dict(dtype=self.code, N=N, IH=OH, IW=OW, Cin=Cout, OH=IH, OW=IW, Cout=Cin, wtaps=9, x=dyb, w=w,
                       y=dxb, pro=dict(mode=0), residual=residual, stats=None)
+        fused = None
+        if (head is not None and head["mode"] in (POST_PLAIN, POST_MASK) and (head["mode"] == POST_PLAIN or head["rpg"] == IH * IW)
+                and os.environ.get("MDS_FUSE_CONV_POST", "1") == "1"
+                and self.lib.fn["conv_dgrad_post_ok"](int(self.code), int(N), int(IH), int(IW), int(Cin), int(Cout), int(stride), int(residual is not None))):
+            common["post"] = head["bn"].post(head)
+            fused = head["bn"]
         if stride == 1:
             dy, dx, wi = geo.taps_dgrad_s1()
             self.op(seg, "conv_fwd", A=IH, B=IW, oy0=0, ox0=0, os=1, **{"is": 1}, ntaps=9, dy=dy, dx=dx, wi=wi, **common)
@@ -441,10 +449,11 @@ class Plan:
                         g_oy0=[p[0] for p in par], g_ox0=[p[1] for p in par], g_A=[p[5] for p in par], g_B=[p[6] for p in par],
                         **common)
             else:
+                assert fused is None
                 for (py, px, dy, dx, wi, A, B_) in par:
                     self.op(seg, "conv_fwd", A=A, B=B_, oy0=py, ox0=px, os=2, **{"is": 1}, ntaps=len(dy), dy=dy, dx=dx,
                             wi=wi, **common)
-        return dxb
+        return Grad(dxb, fused)
 
     def _pw_bwd(self, seg, xin, pro, M, K, N_, wparam, dy, need_dx, residual=None, frozen=False, head=None):
         """wgrad (+ dgrad) of a 1x1 conv y[M][N] = pro(x)[M][K] w^T from the materialised dy; `head`: take the next BatchNorm
@@ -674,7 +683,7 @@ class Plan:
             dy_ = self.act(N * OH * OW, blk.cout)
             bn1.backward(self, seg, gsrc(G_SILU, u.buf), y, dy_)
             self._conv_wgrad(seg, xin, xin_bn.pro(), N, IH, IW, blk.cin, OH, OW, blk.cout, blk.stride, pads, dy_, blk.conv.weight)
-            return Grad(self._conv_dgrad(seg, dy_, N, IH, IW, blk.cin, blk.cout, blk.stride, blk.conv.weight, pads, None))
+            return self._conv_dgrad(seg, dy_, N, IH, IW, blk.cin, blk.cout, blk.stride, blk.conv.weight, pads, None, head=nxt_head)
 
         bwd.lo = self._lo(blk)
         recs.append(bwd)
@@ -716,8 +725,8 @@ class Plan:
             ua = self._pw_bwd(seg, ya, bn1.pro(), M, mid, cout, blk.conv_pwl.weight, dyb, True)
             bn1.backward(self, seg, gsrc(G_SILU, ua.buf), ya, dya)
             self._conv_wgrad(seg, xin, pro_in, N, IH, IW, cin, OH, OW, mid, blk.stride, pads, dya, blk.conv_exp.weight)
-            return Grad(self._conv_dgrad(seg, dya, N, IH, IW, cin, mid, blk.stride, blk.conv_exp.weight, pads,
-                                         dout.buf if has_skip else None))
+            return self._conv_dgrad(seg, dya, N, IH, IW, cin, mid, blk.stride, blk.conv_exp.weight, pads,
+                                    dout.buf if has_skip else None, head=nxt_head)
 
         bwd.head = bn2.head(yb, POST_MASK if mask is not None else POST_PLAIN, mask, rpg)
         bwd.lo = self._lo(blk)

@@ -236,8 +236,12 @@ typedef struct {
   int ngroups;
   int g_ntaps[4], g_oy0[4], g_ox0[4], g_A[4], g_B[4];
   mds_epi_t epi;        /* eval-mode output transform (no statistics with it; applied before `residual` is added) */
+  mds_poststat_t post;  /* data-gradient use: the BatchNorm-backward sums of the layer BELOW in the epilogue (PLAIN / MASK with one mask value per
+                           image); only launches for which mds_conv_dgrad_post_ok() says 1 may ask for it */
 } mds_conv_fwd_args;
 int mds_conv_fwd(const mds_conv_fwd_args* a, mds_stream_t stream);
+/* 1: the bf16 data gradient of a 3x3 layer (forward shape N x IH x IW x Cin -> Cout, stride 1 / 2) takes a kernel that implements `post` */
+int mds_conv_dgrad_post_ok(int dtype, int N, int IH, int IW, int Cin, int Cout, int stride, int has_residual);
 
 /* weight gradient of the 3x3 convolution (forward geometry: is = stride, os = 1):
  * dw[co][ci][tap] += sum_{n,a,b} dy[n][a][b][co] * pro(x)[n][a*is+dy[t]][b*is+dx[t]][ci]

@@ -289,6 +289,71 @@ def test_c3t_stride2_data_gradient(be, N, H, W, Cin, Cout, blocks):
         be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
 
 
+@pytest.mark.parametrize("stride,N,H,W,blocks,masked", [(1, 2, 14, 64, 0, True), (1, 1, 21, 45, 2, False), (2, 2, 12, 64, 0, True), (2, 1, 22, 40, 2, False)])
+def test_c3_post_statistics(be, stride, N, H, W, blocks, masked):
+    """mds_poststat_t in k_c3.hip's data gradients (what engine._conv_dgrad asks for when mds_conv_dgrad_post_ok says 1): the
+    output u is the gradient source of the BatchNorm below - sum g and sum g * xhat over all pixels with g = bf16(u) (x DropPath's
+    per-image factor), next to the unchanged u; stride 1 = blocks.1.1's form (32 -> 128 forward, residual operand), stride 2 =
+    blocks.2.0's"""
+    code, tdt = DT["bf16"]
+    Cin, Cout = 32, 128                       # forward layer: the gradient that comes out has Cin channels
+    g = gen(H * W + stride)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(tdt)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
+    dyt = torch.randn(N, Cout, OH, OW, generator=g).to(tdt)
+    res = torch.randn(N, H, W, Cin, generator=g).to(tdt) if stride == 1 else None
+    yb = torch.randn(N, H, W, Cin, generator=g).to(tdt)
+    bn = torch.stack([torch.ones(Cin), torch.zeros(Cin), 0.3 * torch.randn(Cin, generator=g), 0.5 + torch.rand(Cin, generator=g)])
+    mask = torch.tensor([1.25, 0.0][:N]) if masked else None
+    assert be.lib.fn["conv_dgrad_post_ok"](code, N, H, W, Cin, Cout, stride, int(res is not None)) == 0     # small: below the size bar
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        assert be.lib.fn["conv_dgrad_post_ok"](code, N, H, W, Cin, Cout, stride, int(res is not None)) == 1
+        xx = torch.zeros(N, Cin, H, W, requires_grad=True)
+        ref_conv(xx, w.float(), stride).backward(dyt.float())
+        ref = nhwc(xx.grad) + (res.float() if res is not None else 0)
+        dxo = torch.full((N, H, W, Cin), float("nan")).to(tdt).to(be.device)
+        st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, Cin, device=be.device, dtype=torch.float64)
+        post = cabi.make("mds_poststat_t", mode=2 if masked else 1, y=be.t(yb), bn=be.t(bn), mask=be.t(mask) if masked else None,
+                         rows_per_group=H * W, stats=st)
+        common = dict(dtype=code, N=N, IH=OH, IW=OW, Cin=Cout, OH=H, OW=W, Cout=Cin, wtaps=9, x=be.t(nhwc(dyt)), w=be.t(pack(w, "io", tdt)),
+                      y=dxo, pro=cabi.pro(0), residual=be.t(res) if res is not None else None, stats=None, post=post)
+        if stride == 1:
+            dy, dx, wi = geo.taps_dgrad_s1()
+            args = cabi.make("mds_conv_fwd_args", A=H, B=W, oy0=0, ox0=0, os=1, **{"is": 1}, ntaps=9, dy=dy, dx=dx, wi=wi, **common)
+        else:
+            par = []
+            for py in range(2):
+                for px in range(2):
+                    dy, dx, wi = geo.taps_dgrad_s2(py, px, pt, pl)
+                    par.append((py, px, dy, dx, wi, (H - py + 1) // 2, (W - px + 1) // 2))
+            args = cabi.make("mds_conv_fwd_args", A=max(p[5] for p in par), B=max(p[6] for p in par), oy0=0, ox0=0, os=2, **{"is": 1},
+                             ntaps=sum(len(p[2]) for p in par), dy=sum((p[2] for p in par), []), dx=sum((p[3] for p in par), []),
+                             wi=sum((p[4] for p in par), []), ngroups=4, g_ntaps=[len(p[2]) for p in par],
+                             g_oy0=[p[0] for p in par], g_ox0=[p[1] for p in par], g_A=[p[5] for p in par], g_B=[p[6] for p in par], **common)
+        be.call("conv_fwd", args)
+        be.sync()
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+    assert_close(dxo, ref, "bf16", msg="dx")
+    u = dxo.float().cpu()                                   # the sums are taken of what later readers will read
+    gg = u * (mask.view(N, 1, 1, 1) if masked else 1.0)
+    xhat = (yb.float() - bn[2]) * bn[3]
+    s = st.sum(0).cpu()
+    cnt = N * H * W
+    assert_close(s[0], gg.sum((0, 1, 2)), "bf16", scale=cnt ** 0.5, msg="sum g")
+    assert_close(s[1], (gg * xhat).sum((0, 1, 2)), "bf16", scale=cnt ** 0.5, msg="sum g xhat")
+    # the old kernels refuse post statistics instead of ignoring them
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 1), "dev_set")
+    try:
+        with pytest.raises(Exception):
+            be.call("conv_fwd", args)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+
+
 def _rand_cases(n, seed):
     import random
     r = random.Random(seed)
