@@ -108,8 +108,11 @@ template <> struct C3Out<3> {
 #define C3_STAMP(b_, ph_) ((void)0)
 #endif
 
-template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool RES, bool STATS, bool MASKED, bool POST = false>
+template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool RES, bool STATS, bool MASKED, bool POST = false, bool ONE = false>
 __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
+  // ONE: a 1x1 convolution through the same machinery (mds_pw_fwd's large prologue-free launches: the edge-residual projections'
+  // data gradients, 0.3 GB of output each): only the centre tap exists - one MFMA in nine - and the rows of the 'image' are just
+  // consecutive runs of W pixels.
   typedef C3Cfg<CIN, NF, NSPL, SPW, RES, POST> CF;
   constexpr int RPYP = CF::RPYP;
   static_assert(!(POST && STATS), "forward statistics and post statistics never meet");
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
       for (int nf = 0; nf < NF; ++nf) {
         const int gr = 4 * s + q;
         u16x8 v = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (gr < 3 * PP) {
+        if (gr < 3 * PP && (!ONE || (d == 1 && gr >= PP && gr < 2 * PP))) {
           const int dxi = gr / PP, part = gr - dxi * PP;
           const int slot = dxi == 0 ? g.tapw[3 * d] : (dxi == 1 ? g.tapw[3 * d + 1] : g.tapw[3 * d + 2]);
           const int ch = c0 + cb + 4 * NF * (i >> 2) + 4 * nf + (i & 3);
@@ -483,11 +486,12 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
 #pragma unroll
           for (int d = 2; d >= 0; --d) {
             if (HEAD && d > j) continue;          // input row r0 - 1 + j, tap row d - 1: output row r0 + j - d is above the item
+            if (ONE && (d != 1 || 4 * s + 3 < PP || 4 * s >= 2 * PP)) continue;      // 1x1: the centre tap's k-steps only
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
               if (C3_ABL & 8) {
                 acc[(j + 4 - d) % 3][st][nf][0] += bf2f(xs[c & 1][f][nf]);
-              } else if (d == 0 && s == 0) {
+              } else if (ONE ? (4 * s <= PP && PP < 4 * s + 4) : (d == 0 && s == 0)) {
                 f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
                 mma16(wr[d][s][nf], xs[c & 1][f], z);
                 acc[(j + 4 - d) % 3][st][nf] = z;
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
 }
 
 // host side ------------------------------------------------------------------------------------------------------------
-template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW>
+template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool ONE = false>
 static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
   typedef C3Cfg<CIN, NF, NSPL, SPW, true> CFR;
   typedef C3Cfg<CIN, NF, NSPL, SPW, false> CFN;
@@ -904,9 +908,13 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
 #endif
   dim3 block(256 + 64 * (NPW + NSW));
   const bool masked = a->IW % WB != 0;
-#define C3_GO(R, S) do { if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, true>), dim3(grid, passes), block, smem, stream, g); \
-                         else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, false>), dim3(grid, passes), block, smem, stream, g); } while (0)
-  if (post) {
+#define C3_GO(R, S) do { if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, true, false, ONE>), dim3(grid, passes), block, smem, stream, g); \
+                         else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, false, false, ONE>), dim3(grid, passes), block, smem, stream, g); } while (0)
+  if (ONE) {
+    if (post || stats || masked) return 0;
+    if (res) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, true, false, false, false, true>), dim3(grid, passes), block, smem, stream, g);
+    else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, false, false, false, false, true>), dim3(grid, passes), block, smem, stream, g);
+  } else if (post) {
     if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, true, false, true, true>), dim3(grid, passes), block, smem, stream, g);
     else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, true, false, false, true>), dim3(grid, passes), block, smem, stream, g);
   } else if (res) { if (stats) return 0; C3_GO(true, false); }      // (a residual operand and statistics never meet in the network)
@@ -1034,4 +1042,24 @@ extern "C" int mds_conv_dgrad_post_ok(int dtype, int N, int IH, int IW, int Cin,
   if (stride == 1) return has_residual && Cout == 128 && Cin == 32;                       // c3_kernel<128 -> 32>, residual form
   if (stride == 2) return !has_residual && IH % 2 == 0 && IW % 2 == 0 && ((Cout == 128 && Cin == 32) || (Cout == 64 && Cin == 16));
   return 0;
+}
+
+// mds_pw_fwd's large prologue-free bf16 launches (the edge-residual projections' data gradients: 0.3 - 1.2 M rows, 32 / 48 -> 64 ... 192
+// channels) as 1x1 "images" of W-pixel rows through c3_kernel<..., ONE>.  1 = launched, 0 = not one of these.
+int c3_pw_try(const mds_pw_fwd_args* a, mds_stream_t stream) {
+  if (mds_knob(MDS_KNOB_C3) == 1 || a->dtype != MDS_BF16) return 0;
+  if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE || a->post.mode != MDS_POST_NONE || a->stats || a->split > 1) return 0;
+  if (a->M < 262144 && mds_knob(MDS_KNOB_C3) != 2) return 0;
+  const bool k32 = a->K == 32 && (a->N == 64 || a->N == 128), k48 = a->K == 48 && a->N % 64 == 0 && a->N <= 192;
+  if (!k32 && !k48) return 0;
+  int W = 0;
+  for (int w = 640; w >= 32; w -= 32) if (a->M % w == 0 && a->M / w >= 3) { W = w; break; }
+  if (!W || a->M * (a->N > a->K ? a->N : a->K) >= (1L << 30)) return 0;
+  mds_conv_fwd_args c = {};
+  c.dtype = a->dtype; c.N = 1; c.IH = c.OH = c.A = (int)(a->M / W); c.IW = c.OW = c.B = W; c.Cin = a->K; c.Cout = a->N;
+  c.os = c.is = 1; c.ntaps = 9; c.wtaps = 1; c.x = a->x; c.w = a->w; c.y = a->y; c.residual = a->residual;
+  const int tapw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (a->K == 32 && a->N == 128) return c3_launch<32, 2, 4, 2, 1, 3, true>(&c, tapw, stream);
+  if (a->K == 32) return c3_launch<32, 2, 2, 1, 1, 3, true>(&c, tapw, stream);
+  return c3_launch<48, 2, 2, 1, 1, 3, true>(&c, tapw, stream);
 }

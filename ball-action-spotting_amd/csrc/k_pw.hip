@@ -430,6 +430,8 @@ __global__ __launch_bounds__(256, (WN == 2 && BM == 128) || TAIL == 1 || SPLIT |
 int pw_fwd_wres_try(const mds_pw_fwd_args* a, mds_stream_t stream);   // k_pwr.hip: short-K wide-N layers; 1 = not taken
 int pw_fwd_k_try(const mds_pw_fwd_args* a, mds_stream_t stream);      // k_pwk8.hip: K-streaming narrow-N layers (bf16); 1 = not taken
 
+int c3_pw_try(const mds_pw_fwd_args* a, mds_stream_t stream);      // k_c3.hip
+
 extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->M > 0 && a->K > 0 && a->N > 0, "pw_fwd: bad dims");
   MDS_REQUIRE(a->K % 8 == 0 && a->N % 16 == 0, "pw_fwd: K=%d must be a multiple of 8, N=%d of 16", a->K, a->N);
@@ -453,6 +455,7 @@ extern "C" int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream) {
     MDS_REQUIRE(!post && !a->stats && (a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_GATE),
                 "pw_fwd: split-K is an inference-plan feature (NONE / GATE prologue, no statistics, no post statistics)");
   }
+  if (!split && c3_pw_try(a, stream)) return mds_check_launch("pw_fwd");      // k_c3.hip: the large prologue-free bf16 launches
   if (!split) { const int rc = pw_fwd_k_try(a, stream); if (rc <= 0) return rc; }
   if (!split) { const int rc = pw_fwd_wres_try(a, stream); if (rc <= 0) return rc; }
   // 128x64 tiles for the narrow projections (N <= 64: half of a 128-column tile would be padding;

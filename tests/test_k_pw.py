@@ -75,6 +75,20 @@ def test_pw_fwd(be, dt, M, K, N, mode, res, stats):
         assert_close(s[1], (ref * ref).sum(0), dt, scale=M ** 0.5, msg="sumsq")
 
 
+@pytest.mark.parametrize("M,K,N,res,blocks", [(32 * 20, 32, 128, False, 0), (640 * 7, 32, 128, True, 2), (96 * 11, 32, 64, False, 0), (64 * 9, 48, 192, False, 1),
+                                             (160 * 6, 48, 128, True, 3)])
+def test_pw_fwd_through_the_row_streaming_kernel(be, M, K, N, res, blocks):
+    """the large prologue-free bf16 1x1 launches (the edge-residual projections' data gradients) go through k_c3.hip as one-tap
+    'images' of W-pixel rows (c3_pw_try); MDS_KNOB_C3 = 2 lifts the 262 144-row bar"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        test_pw_fwd(be, "bf16", M, K, N, 0, res, False)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,K,N,pmode,emode,res", [(300, 48, 144, 0, 2, False), (200, 112, 32, 4, 1, True), (130, 192, 192, 0, 2, False),
                                                    (150, 704, 192, 4, 1, True), (140, 320, 128, 0, 2, False)])   # K-heavy inference shapes (the predictor's one-image plans)
