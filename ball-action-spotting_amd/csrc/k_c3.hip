@@ -44,6 +44,7 @@ struct C3Args {
   int dbg;             // MDS_KNOB_C3_DBG bits
   // post statistics (mds_poststat_t; PLAIN, or MASK with one value per image): sum g, sum g * xhat of the BatchNorm below
   const bf16_t* py; const float* pbn; const float* pmask; double* pstats;
+  int pmode;           // MDS_POST_*: SILU also replaces the stored u by g = u * silu'(y * scale + shift)
   void* trace;         // C3_TRACE builds: 160 x 8 x 4 cycle stamps of one block (passed in mds_conv_fwd_args.epi.scale, mode NONE)
 };
 
@@ -267,10 +268,13 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
     // next), so sum g and sum g * xhat - of the
     // stored, rounded values - cost the consumers nothing.
     int rslot = 0, pslot = 0;                             // ring slot of the next row / of the previous batch's first row
-    float ps[8], pss[8], pmu[8], prs[8];
+    float ps[8], pss[8], pmu[8], prs[8], psc[8], psh[8];
+    const bool psilu = POST && g.pmode == MDS_POST_SILU;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       ps[c] = 0.f; pss[c] = 0.f;
+      psc[c] = psilu ? g.pbn[c0 + 8 * chunk + c] : 0.f;
+      psh[c] = psilu ? g.pbn[g.Ctot + c0 + 8 * chunk + c] : 0.f;
       pmu[c] = POST ? g.pbn[2 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
       prs[c] = POST ? g.pbn[3 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
     }
@@ -287,10 +291,15 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
         for (int pc = sw; pc < NP; pc += NSW) {
           const int cl = pc * PPP + lpx;
           if (lact && cl < WB && (!MASKED || pim.x0 + cl < g.W)) {
-            const u16x8 v = *(const u16x8*)(srow + (cl * CPP + (chunk + (cl >> RSH)) % CPP) * 16);
-            *(u16x8*)(orow + cl * g.Ctot + 8 * chunk) = v;
+            u16x8 v = *(const u16x8*)(srow + (cl * CPP + (chunk + (cl >> RSH)) % CPP) * 16);
             if (POST) {
               const u16x8 yv = *(const u16x8*)(yrow + cl * COUT + 8 * chunk);
+              if (psilu) {      // the BatchNorm below sits under a SiLU: its gradient source g = u * silu'(z) replaces u in memory
+                float gv[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) gv[c] = bf2f(v[c]) * silu_gradf_(bf2f(yv[c]) * psc[c] + psh[c]);
+                v = pack8(gv);
+              }
 #pragma unroll
               for (int c = 0; c < 8; ++c) {
                 const float gg = bf2f(v[c]) * pmk;
@@ -298,6 +307,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
                 pss[c] += gg * ((bf2f(yv[c]) - pmu[c]) * prs[c]);
               }
             }
+            *(u16x8*)(orow + cl * g.Ctot + 8 * chunk) = v;
           }
         }
       }
@@ -671,10 +681,13 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
     C3Item pim = c3_item(g, blockIdx.x, WBI);
     int pk0 = 0, pn = 0;
     int rslot = 0, pslot = 0;                             // POST (see c3_kernel's store waves): ring slot of the next row / of the previous batch's first row
-    float ps[8], pss[8], pmu[8], prs[8];
+    float ps[8], pss[8], pmu[8], prs[8], psc[8], psh[8];
+    const bool psilu = POST && g.pmode == MDS_POST_SILU;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       ps[c] = 0.f; pss[c] = 0.f;
+      psc[c] = psilu ? g.pbn[c0 + 8 * chunk + c] : 0.f;
+      psh[c] = psilu ? g.pbn[g.Ctot + c0 + 8 * chunk + c] : 0.f;
       pmu[c] = POST ? g.pbn[2 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
       prs[c] = POST ? g.pbn[3 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
     }
@@ -694,10 +707,15 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
           for (int pc = sw; pc < NP; pc += NSW) {
             const int cl = pc * PPP + lpx;
             if (lact && cl < WBO && (!MASKED || 2 * pim.x0 + cl < g.OW)) {
-              const u16x8 v = *(const u16x8*)(srow + (cl * CPP + (chunk + (cl >> RSH)) % CPP) * 16);
-              *(u16x8*)(orow + cl * g.Ctot + 8 * chunk) = v;
+              u16x8 v = *(const u16x8*)(srow + (cl * CPP + (chunk + (cl >> RSH)) % CPP) * 16);
               if (POST) {
                 const u16x8 yv = *(const u16x8*)(yrow + cl * COUT + 8 * chunk);
+                if (psilu) {
+                  float gv[8];
+#pragma unroll
+                  for (int c = 0; c < 8; ++c) gv[c] = bf2f(v[c]) * silu_gradf_(bf2f(yv[c]) * psc[c] + psh[c]);
+                  v = pack8(gv);
+                }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                   const float gg = bf2f(v[c]) * pmk;
@@ -705,6 +723,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
                   pss[c] += gg * ((bf2f(yv[c]) - pmu[c]) * prs[c]);
                 }
               }
+              *(u16x8*)(orow + cl * g.Ctot + 8 * chunk) = v;
             }
           }
         }
@@ -867,9 +886,11 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
   typedef C3Cfg<CIN, NF, NSPL, SPW, true> CFR;
   typedef C3Cfg<CIN, NF, NSPL, SPW, false> CFN;
   typedef C3Cfg<CIN, NF, NSPL, SPW, true, true> CFP;
+  typedef C3Cfg<CIN, NF, NSPL, SPW, false, true> CFQ;
   const bool res = a->residual != nullptr, stats = a->stats != nullptr, post = a->post.mode != MDS_POST_NONE;
-  if (post && (!res || stats)) return 0;      // (post statistics are instantiated for the residual form: blocks.1.1's data gradient)
-  const int WB = CFN::WB, rowb = post ? CFP::ROWB : (res ? CFR::ROWB : CFN::ROWB), pieces = post ? CFP::PIECES : (res ? CFR::PIECES : CFN::PIECES);
+  if (post && stats) return 0;
+  const int WB = CFN::WB, rowb = post ? (res ? CFP::ROWB : CFQ::ROWB) : (res ? CFR::ROWB : CFN::ROWB);
+  const int pieces = post ? (res ? CFP::PIECES : CFQ::PIECES) : (res ? CFR::PIECES : CFN::PIECES);
   C3Args g;
   g.x = (const bf16_t*)a->x; g.w = (const bf16_t*)a->w; g.y = (bf16_t*)a->y; g.res = (const bf16_t*)a->residual; g.stats = a->stats;
   g.N = a->N; g.H = a->IH; g.W = a->IW; g.OH = a->OH; g.OW = a->OW; g.wtaps = a->wtaps; g.Ctot = a->Cout;
@@ -888,9 +909,10 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
   while ((size_t)NR * rowb > lds_cap && RA > 3) { --RA; NR = RA + keep; }
   if ((size_t)NR * rowb > lds_cap) return 0;
   g.RA = RA; g.NR = NR; g.dbg = mds_knob(MDS_KNOB_C3_DBG); g.trace = (void*)a->epi.scale;
-  g.py = (const bf16_t*)a->post.y; g.pbn = a->post.bn; g.pmask = a->post.mode == MDS_POST_MASK ? a->post.mask : nullptr; g.pstats = a->post.stats;
+  g.py = (const bf16_t*)a->post.y; g.pbn = a->post.bn; g.pmask = a->post.mode == MDS_POST_MASK ? a->post.mask : nullptr; g.pstats = a->post.stats; g.pmode = a->post.mode;
   // items: bands x row segments, the segment count that minimises the longest block's rows (+2 halo rows, + a fill per item)
   int CUS = 256 / passes;
+  if (!stats && mds_knob(MDS_KNOB_C3_BWD_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_C3_BWD_BLOCKS) / passes;
   if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);      // tests: few blocks, many items each
   g.nbands = cdiv(a->IW, WB);
   long best = -1;
@@ -915,8 +937,10 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
     if (res) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, true, false, false, false, true>), dim3(grid, passes), block, smem, stream, g);
     else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, false, false, false, false, true>), dim3(grid, passes), block, smem, stream, g);
   } else if (post) {
-    if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, true, false, true, true>), dim3(grid, passes), block, smem, stream, g);
-    else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, true, false, false, true>), dim3(grid, passes), block, smem, stream, g);
+#define C3_GOP(R, M) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, false, M, true>), dim3(grid, passes), block, smem, stream, g)
+    if (res) { if (masked) C3_GOP(true, true); else C3_GOP(true, false); }
+    else { if (masked) C3_GOP(false, true); else C3_GOP(false, false); }
+#undef C3_GOP
   } else if (res) { if (stats) return 0; C3_GO(true, false); }      // (a residual operand and statistics never meet in the network)
   else { if (stats) C3_GO(false, true); else C3_GO(false, false); }
 #undef C3_GO
@@ -946,8 +970,9 @@ static int c3t_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stre
   while ((size_t)NR * ROWB + stage > 156 * 1024 && RA > 2) { --RA; NR = RA + keep; }
   if ((size_t)NR * ROWB + stage > 156 * 1024) return 0;
   g.RA = RA; g.NR = NR; g.dbg = 0; g.trace = nullptr;
-  g.py = (const bf16_t*)a->post.y; g.pbn = a->post.bn; g.pmask = a->post.mode == MDS_POST_MASK ? a->post.mask : nullptr; g.pstats = a->post.stats;
+  g.py = (const bf16_t*)a->post.y; g.pbn = a->post.bn; g.pmask = a->post.mode == MDS_POST_MASK ? a->post.mask : nullptr; g.pstats = a->post.stats; g.pmode = a->post.mode;
   int CUS = 256 / passes;
+  if (mds_knob(MDS_KNOB_C3_BWD_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_C3_BWD_BLOCKS) / passes;
   if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);
   g.nbands = cdiv(a->IW, WBI);
   long best = -1;
@@ -969,12 +994,12 @@ static int c3t_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stre
   return 1;
 }
 
-// post statistics as these kernels take them: PLAIN, or MASK with one factor per image
+// post statistics as these kernels take them: PLAIN, SILU, or MASK with one factor per image
 static bool c3_post_ok(const mds_conv_fwd_args* a) {
   if (a->post.mode == MDS_POST_NONE) return true;
-  if (a->post.mode != MDS_POST_PLAIN && a->post.mode != MDS_POST_MASK) return false;
+  if (a->post.mode != MDS_POST_PLAIN && a->post.mode != MDS_POST_MASK && a->post.mode != MDS_POST_SILU) return false;
   if (!a->post.y || !a->post.bn || !a->post.stats) return false;
-  return a->post.mode == MDS_POST_PLAIN || (a->post.mask && a->post.rows_per_group == (long)a->OH * a->OW);
+  return a->post.mode != MDS_POST_MASK || (a->post.mask && a->post.rows_per_group == (long)a->OH * a->OW);
 }
 
 // the stride-2 data gradient as mds_conv_fwd receives it: four tap groups (one per output parity), is = 1, os = 2
@@ -1039,7 +1064,7 @@ int c3_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
 extern "C" int mds_conv_dgrad_post_ok(int dtype, int N, int IH, int IW, int Cin, int Cout, int stride, int has_residual) {
   if (dtype != MDS_BF16 || mds_knob(MDS_KNOB_C3) == 1) return 0;
   if ((long)N * IH * IW < 16384 && mds_knob(MDS_KNOB_C3) != 2) return 0;
-  if (stride == 1) return has_residual && Cout == 128 && Cin == 32;                       // c3_kernel<128 -> 32>, residual form
+  if (stride == 1) return (Cout == 128 && Cin == 32) || (!has_residual && Cout == 16 && Cin == 32);      // c3_kernel<128 -> 32> / <16 -> 32>
   if (stride == 2) return !has_residual && IH % 2 == 0 && IW % 2 == 0 && ((Cout == 128 && Cin == 32) || (Cout == 64 && Cin == 16));
   return 0;
 }

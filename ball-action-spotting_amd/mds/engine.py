@@ -425,7 +425,8 @@ class Plan:
         common = dict(dtype=self.code, N=N, IH=OH, IW=OW, Cin=Cout, OH=IH, OW=IW, Cout=Cin, wtaps=9, x=dyb, w=w,
                       y=dxb, pro=dict(mode=0), residual=residual, stats=None)
         fused = None
-        if (head is not None and head["mode"] in (POST_PLAIN, POST_MASK) and (head["mode"] == POST_PLAIN or head["rpg"] == IH * IW)
+        if (head is not None and (head["mode"] != POST_MASK or head["rpg"] == IH * IW)
+                and (head["mode"] != POST_SILU or os.environ.get("MDS_FUSE_CONV_POST_SILU", "1") == "1")
                 and os.environ.get("MDS_FUSE_CONV_POST", "1") == "1"
                 and self.lib.fn["conv_dgrad_post_ok"](int(self.code), int(N), int(IH), int(IW), int(Cin), int(Cout), int(stride), int(residual is not None))):
             common["post"] = head["bn"].post(head)
@@ -613,22 +614,25 @@ class Plan:
         def stem_bwd(seg, u0, nxt_head):
             if fr:
                 return None
-            g0 = gsrc(G_SILU, u0.buf)
+            # (u0.reduced is bn0: the first 3x3 layer's data gradient stored g = u * silu'(z) and took the sums - k_c3.hip, POST_SILU)
+            g0 = gsrc(G_PLAIN, u0.buf) if u0.reduced is bn0 else gsrc(G_SILU, u0.buf)
             if self.tdt == torch.bfloat16 and os.environ.get("MDS_STEM_DYP", "1") == "1":
                 # the stem has no data gradient: its BatchNorm-backward apply pass would only feed the weight gradient, which
                 # forms dy = A*u*silu'(z) + B*y + D on load instead (no 0.9 GB apply launch at the very end of the step)
-                bn0.bwd_reduce(self, seg, g0, y0)
+                if u0.reduced is not bn0:
+                    bn0.bwd_reduce(self, seg, g0, y0)
                 bn0.bwd_finalize(self, seg)
                 self.op(seg, "stem_wgrad", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
                         x=self.x_in, dy=None, dw=self.grad(enc.conv_stem.weight),
                         dyp=dict(_struct="mds_dyp_t", mode=1, g=g0, y=y0, bn=bn0.buf, lin=bn0.lin))
                 return None
             dy0 = self.act(N * OH * OW, 32)
-            bn0.backward(self, seg, g0, y0, dy0)
+            bn0.backward(self, seg, g0, y0, dy0, reduce=u0.reduced is not bn0)
             self.op(seg, "stem_wgrad", dtype=self.code, N=N, H=H, W=W, OH=OH, OW=OW, Cout=32, pad_t=pt, pad_l=pl,
                     x=self.x_in, dy=dy0, dw=self.grad(enc.conv_stem.weight))
             return None
 
+        stem_bwd.head = bn0.head(y0, POST_SILU)
         stem_bwd.lo = self._lo(enc.conv_stem, enc.bn1)
         recs.append(stem_bwd)
         cur, cur_bn, ch, cw = y0, (None if self.eval_epilogues else bn0), OH, OW      # cur_bn != None: `cur` is a raw tensor read through BN+SiLU
@@ -681,10 +685,14 @@ class Plan:
             if fr:
                 return None
             dy_ = self.act(N * OH * OW, blk.cout)
-            bn1.backward(self, seg, gsrc(G_SILU, u.buf), y, dy_)
+            if u.reduced is bn1:      # the producer (a 3x3 data gradient of k_c3.hip) stored g = u * silu'(z) and took the sums
+                bn1.backward(self, seg, gsrc(G_PLAIN, u.buf), y, dy_, reduce=False)
+            else:
+                bn1.backward(self, seg, gsrc(G_SILU, u.buf), y, dy_)
             self._conv_wgrad(seg, xin, xin_bn.pro(), N, IH, IW, blk.cin, OH, OW, blk.cout, blk.stride, pads, dy_, blk.conv.weight)
             return self._conv_dgrad(seg, dy_, N, IH, IW, blk.cin, blk.cout, blk.stride, blk.conv.weight, pads, None, head=nxt_head)
 
+        bwd.head = bn1.head(y, POST_SILU)
         bwd.lo = self._lo(blk)
         recs.append(bwd)
         return y, bn1, OH, OW

@@ -289,21 +289,23 @@ def test_c3t_stride2_data_gradient(be, N, H, W, Cin, Cout, blocks):
         be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
 
 
-@pytest.mark.parametrize("stride,N,H,W,blocks,masked", [(1, 2, 14, 64, 0, True), (1, 1, 21, 45, 2, False), (2, 2, 12, 64, 0, True), (2, 1, 22, 40, 2, False)])
-def test_c3_post_statistics(be, stride, N, H, W, blocks, masked):
+@pytest.mark.parametrize("stride,N,H,W,blocks,masked,Cin,Cout", [(1, 2, 14, 64, 0, True, 32, 128), (1, 1, 21, 45, 2, False, 32, 128), (2, 2, 12, 64, 0, True, 32, 128),
+                                                                  (2, 1, 22, 40, 2, False, 32, 128), (1, 2, 9, 128, 0, "silu", 32, 16), (1, 1, 20, 70, 2, "silu", 32, 16),
+                                                                  (2, 1, 10, 128, 0, "silu", 16, 64), (2, 2, 6, 64, 2, "silu", 32, 128)])
+def test_c3_post_statistics(be, stride, N, H, W, blocks, masked, Cin, Cout):
     """mds_poststat_t in k_c3.hip's data gradients (what engine._conv_dgrad asks for when mds_conv_dgrad_post_ok says 1): the
     output u is the gradient source of the BatchNorm below - sum g and sum g * xhat over all pixels with g = bf16(u) (x DropPath's
     per-image factor), next to the unchanged u; stride 1 = blocks.1.1's form (32 -> 128 forward, residual operand), stride 2 =
     blocks.2.0's"""
-    code, tdt = DT["bf16"]
-    Cin, Cout = 32, 128                       # forward layer: the gradient that comes out has Cin channels
+    code, tdt = DT["bf16"]                    # (Cin, Cout: the forward layer - the gradient that comes out has Cin channels)
+    silu, masked = masked == "silu", masked is True
     g = gen(H * W + stride)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(tdt)
     OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
     dyt = torch.randn(N, Cout, OH, OW, generator=g).to(tdt)
-    res = torch.randn(N, H, W, Cin, generator=g).to(tdt) if stride == 1 else None
+    res = torch.randn(N, H, W, Cin, generator=g).to(tdt) if (stride == 1 and Cout == 128) else None
     yb = torch.randn(N, H, W, Cin, generator=g).to(tdt)
-    bn = torch.stack([torch.ones(Cin), torch.zeros(Cin), 0.3 * torch.randn(Cin, generator=g), 0.5 + torch.rand(Cin, generator=g)])
+    bn = torch.stack([1 + 0.2 * torch.randn(Cin, generator=g), 0.3 * torch.randn(Cin, generator=g), 0.3 * torch.randn(Cin, generator=g), 0.5 + torch.rand(Cin, generator=g)])
     mask = torch.tensor([1.25, 0.0][:N]) if masked else None
     assert be.lib.fn["conv_dgrad_post_ok"](code, N, H, W, Cin, Cout, stride, int(res is not None)) == 0     # small: below the size bar
     be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
@@ -315,7 +317,7 @@ def test_c3_post_statistics(be, stride, N, H, W, blocks, masked):
         ref = nhwc(xx.grad) + (res.float() if res is not None else 0)
         dxo = torch.full((N, H, W, Cin), float("nan")).to(tdt).to(be.device)
         st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, Cin, device=be.device, dtype=torch.float64)
-        post = cabi.make("mds_poststat_t", mode=2 if masked else 1, y=be.t(yb), bn=be.t(bn), mask=be.t(mask) if masked else None,
+        post = cabi.make("mds_poststat_t", mode=3 if silu else (2 if masked else 1), y=be.t(yb), bn=be.t(bn), mask=be.t(mask) if masked else None,
                          rows_per_group=H * W, stats=st)
         common = dict(dtype=code, N=N, IH=OH, IW=OW, Cin=Cout, OH=H, OW=W, Cout=Cin, wtaps=9, x=be.t(nhwc(dyt)), w=be.t(pack(w, "io", tdt)),
                       y=dxo, pro=cabi.pro(0), residual=be.t(res) if res is not None else None, stats=None, post=post)
@@ -337,6 +339,10 @@ def test_c3_post_statistics(be, stride, N, H, W, blocks, masked):
     finally:
         be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
         be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+    if silu:      # MDS_POST_SILU: g = u * silu'(y * scale + shift) replaces u in memory
+        z = yb.float() * bn[0] + bn[1]
+        sg = torch.sigmoid(z)
+        ref = ref.to(tdt).float() * (sg * (1 + z * (1 - sg)))
     assert_close(dxo, ref, "bf16", msg="dx")
     u = dxo.float().cpu()                                   # the sums are taken of what later readers will read
     gg = u * (mask.view(N, 1, 1, 1) if masked else 1.0)
