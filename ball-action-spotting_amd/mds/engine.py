@@ -418,7 +418,9 @@ class Plan:
     def _conv_dgrad(self, seg, dyb, N, IH, IW, Cin, Cout, stride, wparam, pads, residual, head=None):
         """grad wrt the conv input ([N][IH][IW][Cin]) from dy ([N][OH][OW][Cout]).  `head`: the BatchNorm backward that consumes
         this gradient directly (the block below's last BatchNorm) - where the launch goes to a kernel that implements
-        mds_poststat_t (k_c3.hip: mds_conv_dgrad_post_ok) its sums are taken in the epilogue and the Grad says so."""
+        mds_poststat_t (k_c3.hip: mds_conv_dgrad_post_ok) its sums CAN be taken in the epilogue and the Grad says so.
+        MDS_FUSE_CONV_POST=1 switches that on (four bn_bwd_reduce launches and 0.75 GB per step less, parity-green) - measured
+        0.05 - 0.1 ms per step SLOWER than the separate reduce passes (round 6, profiles/LOG.md), so the default leaves it off."""
         OH, OW, _, _ = geo.conv_geometry(IH, IW, stride)
         w = self.pack(wparam, cabi.MDS_PACK_IO_FLIP, Cout, Cin, 9)
         dxb = self.act(N * IH * IW, Cin)
@@ -427,7 +429,7 @@ class Plan:
         fused = None
         if (head is not None and (head["mode"] != POST_MASK or head["rpg"] == IH * IW)
                 and (head["mode"] != POST_SILU or os.environ.get("MDS_FUSE_CONV_POST_SILU", "1") == "1")
-                and os.environ.get("MDS_FUSE_CONV_POST", "1") == "1"
+                and os.environ.get("MDS_FUSE_CONV_POST", "0") == "1"
                 and self.lib.fn["conv_dgrad_post_ok"](int(self.code), int(N), int(IH), int(IW), int(Cin), int(Cout), int(stride), int(residual is not None))):
             common["post"] = head["bn"].post(head)
             fused = head["bn"]

@@ -75,6 +75,7 @@ class StreamPredictor:
         self.use_graphs = use_graphs
         self._built = None
         self.encoder_passes = 0          # 2D-encoder passes issued so far (steady state: one per chunk)
+        self.lanes_in_use = 1            # lanes of the last predict_stream (what the device gave: see _lane_streams)
         self._pipe = None                # predict_stream: the streams / lane of the step being issued
         self.reset_buffers()
 
@@ -355,6 +356,7 @@ class StreamPredictor:
             self._streams = _lane_streams(dev, self.m._library(next(self.m.parameters())), self.MAX_LANES)
             enc = self._streams
             lanes = min(lanes, len(enc))
+            self.lanes_in_use = lanes          # (what bench.py prints beside the rate)
             cur = torch.cuda.current_stream(dev)
             for st in self._streams:              # whatever the caller queued so far (weights, earlier predict calls) comes first
                 st.wait_stream(cur)
@@ -399,27 +401,56 @@ class StreamPredictor:
                     cur.wait_stream(st)
 
 
-_LANE_STREAMS = {}       # device -> the lane streams of predict_stream
+_LANE_STREAMS = {}       # device -> dict(streams, verified, tries): the lane streams of predict_stream
+_LANE_LOG = []           # one line per selection (what bench.py prints; tests read it)
+
+
+def _own_streams(dev, n):
+    """n HIP streams created OUTSIDE torch's stream pool (hipStreamCreateWithFlags, non-blocking), wrapped as ExternalStream: torch
+    hands out pool streams round-robin (32 per priority), so a later torch.cuda.Stream() of the caller - or a Plan's side stream -
+    could otherwise alias a lane and silently serialise with it."""
+    import ctypes
+    from .engine import _hip_path
+    hip = ctypes.CDLL(_hip_path())
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    out = []
+    with torch.cuda.device(dev):
+        for _ in range(n):
+            h = ctypes.c_void_p()
+            rc = hip.hipStreamCreateWithFlags(ctypes.byref(h), 1)          # hipStreamNonBlocking
+            if rc != 0 or not h.value:
+                raise RuntimeError(f"hipStreamCreateWithFlags failed: {rc}")
+            out.append(torch.cuda.ExternalStream(h.value, device=dev))
+    return out
 
 
 def _lane_streams(dev, lib, want):
-    """The lane streams are chosen ONCE per process and device, by measurement.  A HIP stream is bound to one of the runtime's
+    """The lane streams are chosen per process and device, by measurement.  A HIP stream is bound to one of the runtime's
     hardware queues (GPU_MAX_HW_QUEUES, 4 by default) when it is first used - the least referenced queue at that moment - and
     two lanes on one hardware queue run one after the other (measured at 4 lanes: 1 / 2 / 4 hardware queues -> 695 / 1110 /
-    1591 frames/s; 8 queues: 685 - the device serves four at a time; the same 3 lanes drawn afresh: 1398 or 898 frames/s
-    depending on what the process's earlier streams had left).  So: a dozen candidate streams, a copy that keeps a quarter of
-    the chip busy for ~0.1 ms issued on two of them at a time - side by side it takes about as long as one, on a shared queue
-    twice as long -, and the largest set of candidates that all overlap each other becomes the lanes (fewer than ``want`` if
-    the runtime has fewer queues: predict_stream then runs that many lanes)."""
-    got = _LANE_STREAMS.get(dev)
-    if got is not None:
-        return got
+    1591 frames/s; 8 queues: 685 - the device serves four at a time).  So: a dozen candidate streams of our own, a copy that
+    keeps a quarter of the chip busy for ~0.1 ms issued on two of them at a time - side by side it takes about as long as one,
+    on a shared queue twice as long -, and the largest set of candidates that all overlap each other becomes the lanes.
+    The choice is then VERIFIED by running all chosen lanes together (they must finish in < 0.88 x the time the same copies take one
+    after the other on a single stream; lanes are dropped until they do, with one warning), it is re-measured on the next call (up to three times) when it came out short of
+    ``want`` - one noisy measurement on a busy device no longer pins the process to fewer lanes -, ``MDS_PREDICT_LANES=n``
+    caps it, and the outcome is on record (``StreamPredictor.lanes_in_use``, ``mds.predict.lane_log()``)."""
+    import os
     import time
-    cand = [torch.cuda.Stream(dev) for _ in range(12)]
+    import warnings
+    cap = int(os.environ.get("MDS_PREDICT_LANES", "0") or 0)
+    if cap > 0:
+        want = min(want, cap)
+    got = _LANE_STREAMS.get(dev)
+    if got is not None and (len(got["streams"]) >= want or got["tries"] >= 3):
+        return got["streams"][:want]
+    tries = (got["tries"] if got else 0) + 1
+    cand = got["cand"] if got else _own_streams(dev, 12)
     nb = 48 << 20
-    src, dst = torch.empty(2, nb, dtype=torch.uint8, device=dev), torch.empty(2, nb, dtype=torch.uint8, device=dev)
+    nj = max(want, 2)
+    src, dst = torch.empty(nj, nb, dtype=torch.uint8, device=dev), torch.empty(nj, nb, dtype=torch.uint8, device=dev)
     jobs = [cabi.make("mds_copy_rows_args", dst=dst[k], src=src[k], dst_pitch=nb, src_pitch=nb, row_bytes=nb, nrows=1, dst_slot=[0], src_slot=[0])
-            for k in (0, 1)]
+            for k in range(nj)]
 
     def timed(streams):
         best = None
@@ -436,6 +467,7 @@ def _lane_streams(dev, lib, want):
         timed([st])                       # first use binds the hardware queue
     n = len(cand)
     best = []
+    one = None
     for attempt in range(3):              # (a cold device - clocks still ramping - once gave three lanes where there are four)
         one = min(timed([st]) for st in cand[:4])
         ok = [[False] * n for _ in range(n)]
@@ -455,8 +487,26 @@ def _lane_streams(dev, lib, want):
         grow([], 0)
         if len(best) >= want:
             break
-    got = _LANE_STREAMS[dev] = [cand[k] for k in (best or [0])]
-    return got
+    chosen = [cand[k] for k in (best or [0])][:want]
+    # all of them together: pairwise overlap does not prove that `want` lanes run side by side
+    dropped = 0
+    while len(chosen) > 1 and timed(chosen) > 0.88 * timed([chosen[0]] * len(chosen)):      # the same copies one after the other on ONE stream
+        # (side by side four of them are bound by memory bandwidth at ~2 x one copy; streams that share a hardware queue take 4 x)
+        chosen.pop()
+        dropped += 1
+    if len(chosen) < want:
+        warnings.warn(f"mds.predict: {len(chosen)} of {want} lanes overlap on this device right now "
+                      f"({'re-measured on the next stream' if tries < 3 else 'kept'}; MDS_PREDICT_LANES caps the request)", RuntimeWarning)
+    _LANE_LOG.append(f"lanes: wanted {want}, chosen {len(chosen)} of {n} candidate streams (pairwise-overlapping set {len(best)}, dropped by the "
+                     f"joint run {dropped}); one 48 MB copy {one * 1e6:.0f} us, all lanes together {timed(chosen) * 1e6:.0f} us; attempt {tries}")
+    del src, dst, jobs                    # 2 x want x 48 MB of probe buffers go back to the allocator now
+    _LANE_STREAMS[dev] = dict(streams=chosen, cand=cand, tries=tries)
+    return chosen
+
+
+def lane_log():
+    """what the lane selection measured, one line per (re)selection"""
+    return list(_LANE_LOG)
 
 
 def _batched(iterable, size):

@@ -130,6 +130,8 @@ def cpu_baseline(max_seconds=20.0, frames=15, frozen=False):
 def kernel_family(name):
     """'void dw2_bwd_kernel<unsigned short, 4>(...)' -> 'dw_bwd' ; variants of one entry point share a key"""
     fn = name.replace("void ", "").split("<")[0].split("(")[0]
+    if fn in ("c3_kernel", "c3t_kernel"):      # k_c3.hip serves mds_conv_fwd launches and (its one-tap form: last template argument) a few of mds_pw_fwd's
+        return "pw_fwd" if fn == "c3_kernel" and re.search(r",\s*true\s*>\s*\(", name) else "conv_fwd"
     fn = re.sub(r"\d", "", fn)
     for v in ("_tr_kernel", "_p_kernel", "_tiled_kernel", "_wres_kernel", "_q_kernel", "_kernel"):
         if fn.endswith(v):
@@ -367,6 +369,7 @@ def bench_predict(args, dev, rank, world):
     LN = args.lanes or (4 if CH <= 4 else (3 if CH <= 8 else 2))
     L1 = args.lanes or 4          # lanes of the one-frame-per-pass runs
     el = run(False, None, pipelined=LN)
+    lanes_in_use = getattr(last.get("sp"), "lanes_in_use", None)      # what the lane selection gave this process (mds.predict._lane_streams)
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -383,6 +386,9 @@ def bench_predict(args, dev, rank, world):
                                         "fp32_tta_frames_per_s": round(K / run(True, None, chunk=1, pipelined=L1), 1)},
                  "frame_by_frame_api": fbf,
                  "round1_module_call_path_frames_per_s": round(module_path(False), 1)}
+        from mds import predict as _mp
+        extra["lanes"] = {"requested": LN, "in_use": lanes_in_use, "selection": _mp.lane_log(),
+                          "tta_on_is_the_reference_setting": "scripts/ball_action/predict.py:16 TTA = True: fp32_tta_frames_per_s is config 5 as the reference runs it"}
     kroof = None
     if rank == 0 and world == 1 and args.predict_kernel_trace:
         # per-kernel roofline of the reference's frame-by-frame API: algorithmic bytes / flops per launch from the plans'

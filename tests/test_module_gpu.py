@@ -316,3 +316,35 @@ def test_train_step_and_predictor_on_a_non_default_stream():
     assert torch.equal(e0, e1)
     errs = grad_errors(g1, g0)
     assert errs[0][0] < 1e-4, errs[:3]
+
+
+def test_conv_post_statistics_opt_in_matches_the_separate_reduce_passes(monkeypatch):
+    """MDS_FUSE_CONV_POST=1 (opt-in: measured slower): the BatchNorm-backward sums of the first 3x3 layer, the stem and
+    two edge-residual projections ride on the 3x3 data gradients above them (k_c3.hip store waves, mds_poststat_t PLAIN / MASK /
+    SILU).  Same weights, same window (one 15 x 736 x 1280 window: the layers are above the kernel's size bar), same DropPath
+    masks: four bn_bwd_reduce launches fewer, every parameter gradient within bf16 noise of the default schedule's."""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.2)
+    ref = fill_deterministic(orc.MultiDimStacker(**kw), 7, scale=0.05)
+    x = torch.rand(1, 15, 736, 1280, generator=torch.Generator().manual_seed(5)).to(DEV)
+    tgt = torch.tensor([[0.0, 1.0]], device=DEV)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MDS_FUSE_CONV_POST", flag)
+        prod = mds.MultiDimStacker(**kw)
+        prod.load_state_dict(ref.state_dict())
+        prod = prod.to(DEV).train()
+        torch.manual_seed(11)                         # the DropPath masks come from torch's generator
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = prod(x)
+        orc.sigmoid_focal_loss(logits.float(), tgt, alpha=-1.0, gamma=1.2).backward()
+        torch.cuda.synchronize()
+        plan = next(p for pool in prod._cache.plans.values() for p in pool if p.kind == "full" and p.need_grad)
+        nred = sum(1 for seg in ("b2d", "b3d", "bhead") for name, *_ in plan.bound[seg] if name == "bn_bwd_reduce")
+        out[flag] = (logits.detach().float().cpu(), {n: p.grad.detach().float().cpu() for n, p in prod.named_parameters()}, nred)
+    assert out["0"][2] - out["1"][2] == 4, (out["0"][2], out["1"][2])
+    assert torch.equal(out["0"][0], out["1"][0])                              # the forward does not change
+    top = max(g.norm().item() for g in out["0"][1].values())
+    worst = max((((out["1"][1][n] - g).norm() / max(g.norm().item(), 1e-4 * top)).item(), n) for n, g in out["0"][1].items())
+    # (worst: the stem's weight gradient, 4e-2 - its dy is formed from g = u * silu'(z) that the fused form has rounded to bf16 once
+    #  more; the same tensor's error against the fp32 oracle is ~0.2 in either schedule: tests/test_fullsize_gpu.py)
+    assert worst[0] < 6e-2, worst
