@@ -984,15 +984,25 @@ class Plan:
             # acquire stay.  12.67 -> 12.56 ms per step same-box (profiles/r05_ab_event_flags.txt; MDS_EVENT_FLAGS=0 = default events).
             self.flags = int(os.environ.get("MDS_EVENT_FLAGS", "0x20000002"), 0)
 
+        def _create(self):
+            """one hipEvent_t with the cheapest flags this runtime accepts: disable-timing | disable-system-fence (ROCm >= 6.x), then
+            disable-timing alone, then a default event - the first combination that works is remembered (a runtime that
+            rejects the fence flag must not fail the first backward)"""
+            v = self.ct.c_void_p()
+            tried = []
+            for flags in dict.fromkeys((self.flags, 0x2, 0x0)):
+                with torch.cuda.device(self.device):
+                    rc = self.hip.hipEventCreateWithFlags(self.ct.byref(v), flags)
+                if rc == 0 and v.value:
+                    self.flags = flags
+                    return v.value
+                tried.append((hex(flags), rc))
+            raise RuntimeError(f"hipEventCreateWithFlags failed for every flag combination: {tried}")
+
         def get(self, seg, k):
             h = self.ev.get((seg, k))
             if h is None:
-                v = self.ct.c_void_p()
-                with torch.cuda.device(self.device):
-                    rc = self.hip.hipEventCreateWithFlags(self.ct.byref(v), self.flags)
-                if rc != 0 or not v.value:
-                    raise RuntimeError(f"hipEventCreateWithFlags failed: {rc}")
-                h = self.ev[(seg, k)] = v.value
+                h = self.ev[(seg, k)] = self._create()
             return h
 
         def wait(self, stream_handle, event):

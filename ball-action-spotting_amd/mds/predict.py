@@ -63,6 +63,7 @@ class StreamPredictor:
         self.idx = StackIndexes(frame_stack_size, frame_stack_step)
         self.step = frame_stack_step
         self._predict_offset = self.idx.make_stack_indexes(0)[-1]
+        self.predict_offset = self._predict_offset      # src/predictors.py:45 (the reference's attribute name)
         self.span = self.ss * self.step                  # frames between the ends of consecutive stacks of one window
         self.max_chunk = 32
         # raw-frame ring: a window behind every frame of a chunk - and, for predict_stream, room for the steps in flight: the

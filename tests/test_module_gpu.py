@@ -348,3 +348,36 @@ def test_conv_post_statistics_opt_in_matches_the_separate_reduce_passes(monkeypa
     # (worst: the stem's weight gradient, 4e-2 - its dy is formed from g = u * silu'(z) that the fused form has rounded to bf16 once
     #  more; the same tensor's error against the fp32 oracle is ~0.2 in either schedule: tests/test_fullsize_gpu.py)
     assert worst[0] < 6e-2, worst
+
+
+def test_handoff_event_flags_do_not_change_the_weight_gradients(monkeypatch):
+    """the ~71 hand-offs to the weight-gradient stream use events without the system-scope fence
+    (hipEventDisableTiming | hipEventDisableSystemFence); with default events (MDS_EVENT_FLAGS=0) the same step must give the
+    same gradients bit for bit where the kernels are deterministic (the BatchNorm / SE / bias gradients: fp64 slot sums) and within
+    atomic-order noise elsewhere - a hand-off that let a weight gradient read its operands early shows up as a gross mismatch"""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    ref = fill_deterministic(orc.MultiDimStacker(**kw), 9, scale=0.05)
+    x = torch.rand(2, 15, 256, 384, generator=torch.Generator().manual_seed(6)).to(DEV)
+    tgt = torch.tensor([[0.0, 1.0], [1.0, 0.0]], device=DEV)
+    out = {}
+    for flags in ("default", "0"):
+        if flags == "0":
+            monkeypatch.setenv("MDS_EVENT_FLAGS", "0")
+        prod = mds.MultiDimStacker(**kw)
+        prod.load_state_dict(ref.state_dict())
+        prod = prod.to(DEV).train()
+        for _ in range(2):                               # the second step runs with every event already created
+            prod.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                logits = prod(x)
+            orc.sigmoid_focal_loss(logits.float(), tgt, alpha=-1.0, gamma=1.2).backward()
+        torch.cuda.synchronize()
+        plan = next(p for pool in prod._cache.plans.values() for p in pool if p.kind == "full" and p.need_grad)
+        out[flags] = ({n: p.grad.detach().float().cpu() for n, p in prod.named_parameters()}, getattr(plan, "_ext", None) and plan._ext.flags)
+    assert out["default"][1] in (0x20000002, 0x2, 0x0) and out["0"][1] == 0
+    top = max(g.norm().item() for g in out["default"][0].values())
+    for n, g in out["default"][0].items():
+        d = (out["0"][0][n] - g).norm().item() / max(g.norm().item(), 1e-4 * top)
+        assert d < 1e-3, (n, d)
+        if n.endswith(".bias") or "bn" in n:
+            assert torch.equal(out["0"][0][n], g), n
