@@ -44,6 +44,7 @@ struct C3Args {
   int dbg;             // MDS_KNOB_C3_DBG bits
   // post statistics (mds_poststat_t; PLAIN, or MASK with one value per image): sum g, sum g * xhat of the BatchNorm below
   const bf16_t* py; const float* pbn; const float* pmask; double* pstats;
+  const float* pro_scale; const float* pro_shift;      // NTW > 0: the input is read through BatchNorm + SiLU (mds_pro_t BN_SILU)
   int pmode;           // MDS_POST_*: SILU also replaces the stored u by g = u * silu'(y * scale + shift)
   void* trace;         // C3_TRACE builds: 160 x 8 x 4 cycle stamps of one block (passed in mds_conv_fwd_args.epi.scale, mode NONE)
 };
@@ -109,8 +110,13 @@ template <> struct C3Out<3> {
 #define C3_STAMP(b_, ph_) ((void)0)
 #endif
 
-template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool RES, bool STATS, bool MASKED, bool POST = false, bool ONE = false>
-__global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
+template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool RES, bool STATS, bool MASKED, bool POST = false, bool ONE = false, int NTW = 0>
+__global__ __launch_bounds__(256 + 64 * (NPW + NSW + NTW)) void c3_kernel(C3Args g) {
+  // NTW > 0: the input tensor is the RAW output of the layer below and is read through its BatchNorm + SiLU (the first 3x3 layer behind
+  // the stem).  LDS-DMA cannot transform, so NTW TRANSFORM waves rewrite every landed row in place - silu(scale * v + shift), zero
+  // outside the image (the padding is applied after the activation) - one batch ahead of the consumers, which therefore run one
+  // barrier behind (LAG); the sigmoid is this layer's whole cost (150 M evaluations), spread here over NTW waves beside the MFMA waves.
+  constexpr int LAG = NTW > 0 ? 1 : 0;
   // ONE: a 1x1 convolution through the same machinery (mds_pw_fwd's large prologue-free launches: the edge-residual projections'
   // data gradients, 0.3 GB of output each): only the centre tap exists - one MFMA in nine - and the rows of the 'image' are just
   // consecutive runs of W pixels.
@@ -243,6 +249,58 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
       }
     }
     raw_barrier();        // the closing barrier: the last batch's outputs are staged
+    if (LAG) raw_barrier();
+#ifdef C3_TRACE
+    raw_barrier();
+#endif
+    return;
+  }
+  if (wave >= 4 + NPW + NSW) {
+    // ------------------------------------------------------------------ transform waves (NTW > 0)
+    MDS_SETPRIO(3);       // the transform is this form's critical stage
+    const int tw = wave - 4 - NPW - NSW;
+    // lane l of piece pc holds part (l % PP) of pixel 64 pc / PP + l / PP; with PP | 64 and a rotation that repeats every 64 / PP
+    // pixels the CHANNELS a lane transforms are the same in every piece: their scale / shift live in registers
+    static_assert(NTW == 0 || (64 % PP == 0 && (((C3Swz<CIN>::A * (64 / PP)) >> C3Swz<CIN>::SH) % PP) == 0), "lane-constant channels");
+    const int lp = lane / PP, lpart = ((lane % PP) - ((C3Swz<CIN>::A * lp) >> C3Swz<CIN>::SH) % PP + PP) % PP;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sc[c] = g.pro_scale[8 * lpart + c]; sh[c] = g.pro_shift[8 * lpart + c]; }
+    constexpr int NPC = (RPX + 63) / 64;                  // pieces of one row
+    int rslot = 0;
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3_item(g, it, WB);
+      const int K = im.r1 - im.r0 + 2;
+      for (int k0 = 0; k0 < K; k0 += 3) {
+        const int n = K - k0 < 3 ? K - k0 : 3;
+        asm volatile("" ::: "memory");
+        raw_barrier();                                    // the batch has landed (the DMA waves waited for it before arriving)
+        asm volatile("" ::: "memory");
+        for (int u = tw; u < n * NPC; u += NTW) {         // (row, piece) pairs of the batch, dealt round the transform waves
+          const int j = u / NPC, pc = u - j * NPC;
+          const int ri = im.r0 - 1 + k0 + j;
+          int rs_ = rslot + j;
+          if (rs_ >= g.NR) rs_ -= g.NR;
+          const int sl = 64 * pc + lane, gx = im.x0 - 1 + (64 / PP) * pc + lp;
+          if (sl < RPX) {
+            char* const ptr = smem + rs_ * ROWB + sl * 16;
+            const u16x8 v = *(const u16x8*)ptr;
+            // zero padding AFTER the activation, as a factor (a select per element becomes eight masked branches in hipcc's hands;
+            // the zero page's raw 0 gives a finite silu(shift) to multiply)
+            const float okf = (ri >= 0 && ri < g.H && gx >= 0 && gx < g.W) ? 1.f : 0.f;
+            float f[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) f[c] = siluf_(bf2f(v[c]) * sc[c] + sh[c]) * okf;
+            *(u16x8*)ptr = pack8(f);
+          }
+        }
+        rslot += n;
+        if (rslot >= g.NR) rslot -= g.NR;
+        wait_lgkm0();                                     // the rewritten rows are in LDS before the next barrier lets the consumers at them
+      }
+    }
+    raw_barrier();
+    raw_barrier();
 #ifdef C3_TRACE
     raw_barrier();
 #endif
@@ -278,6 +336,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
       pmu[c] = POST ? g.pbn[2 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
       prs[c] = POST ? g.pbn[3 * g.Ctot + c0 + 8 * chunk + c] : 0.f;
     }
+    if (LAG) raw_barrier();                               // (the consumers run one barrier behind the ring)
     auto flush = [&](int par) {
       const float pmk = (POST && g.pmask) ? g.pmask[pim.n] : 1.f;      // MASK: DropPath's per-image factor
       for (int j = 0; j < pn; ++j) {
@@ -389,6 +448,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3_kernel(C3Args g) {
   constexpr int CH = FR <= 6 ? FR : 6;                       // fragments per register set ("chunk"): two sets ping-pong
   constexpr int NCH = (FR + CH - 1) / CH;
   int bpar = 0;                                              // parity of the batch: which half of the staging area it fills
+  if (LAG) raw_barrier();                                    // the transform waves work one batch ahead
 
   for (int it = blockIdx.x; it < g.items; it += G) {
     const C3Item im = c3_item(g, it, WB);
@@ -881,7 +941,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
 }
 
 // host side ------------------------------------------------------------------------------------------------------------
-template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool ONE = false>
+template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool ONE = false, int NTW = 0>
 static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
   typedef C3Cfg<CIN, NF, NSPL, SPW, true> CFR;
   typedef C3Cfg<CIN, NF, NSPL, SPW, false> CFN;
@@ -903,9 +963,9 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
   if (RA < 3) RA = 3;
   while (RA > 3 && pcw * (RA - 1) > 40) --RA;
   if (pcw * (RA - 1) > 40) return 0;
-  const int keep = post ? 6 : 3;      // ring rows beyond the RA in flight: the batch being read (+ with post statistics the one before: its y rows serve the store waves)
+  const int keep = (post ? 6 : 3) + (NTW ? 3 : 0);      // ring rows beyond the RA in flight: the batch being read (+ with post statistics the one before: its y rows serve the store waves)
   int NR = RA + keep;
-  const size_t lds_cap = 155 * 1024 - 6 * (size_t)WB * CFN::COUT * 2;     // the staged output rows share the LDS
+  const size_t lds_cap = 155 * 1024 - 6 * (size_t)WB * CFN::COUT * 2 - 2 * CIN * 4;     // the staged output rows share the LDS
   while ((size_t)NR * rowb > lds_cap && RA > 3) { --RA; NR = RA + keep; }
   if ((size_t)NR * rowb > lds_cap) return 0;
   g.RA = RA; g.NR = NR; g.dbg = mds_knob(MDS_KNOB_C3_DBG); g.trace = (void*)a->epi.scale;
@@ -928,8 +988,17 @@ static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_strea
 #ifdef C3_TRACE
   smem += 160 * 32 * 8;
 #endif
-  dim3 block(256 + 64 * (NPW + NSW));
+  dim3 block(256 + 64 * (NPW + NSW + NTW));
   const bool masked = a->IW % WB != 0;
+  g.pro_scale = a->pro.scale; g.pro_shift = a->pro.shift;
+  if (NTW) {
+    if (res || post || ONE) return 0;
+#define C3_GOT(S, M) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, false, S, M, false, false, NTW>), dim3(grid, passes), block, smem, stream, g)
+    if (stats) { if (masked) C3_GOT(true, true); else C3_GOT(true, false); }
+    else { if (masked) C3_GOT(false, true); else C3_GOT(false, false); }
+#undef C3_GOT
+    return 1;
+  }
 #define C3_GO(R, S) do { if (masked) MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, true, false, ONE>), dim3(grid, passes), block, smem, stream, g); \
                          else MDS_LAUNCH((c3_kernel<CIN, NF, NSPL, SPW, NPW, NSW, R, S, false, false, ONE>), dim3(grid, passes), block, smem, stream, g); } while (0)
   if (ONE) {
@@ -1038,7 +1107,10 @@ int c3_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
   if (mds_knob(MDS_KNOB_C3) == 1) return 0;
   if (a->ngroups == 4) return c3t_try(a, stream);
   if (a->dtype != MDS_BF16 || a->is != 1 || a->os != 1 || a->ntaps != 9 || a->ngroups > 1) return 0;
-  if (a->pro.mode != MDS_PRO_NONE || a->epi.mode != MDS_EPI_NONE || !c3_post_ok(a)) return 0;
+  const bool pro = a->pro.mode == MDS_PRO_BN_SILU;
+  if ((a->pro.mode != MDS_PRO_NONE && !pro) || a->epi.mode != MDS_EPI_NONE || !c3_post_ok(a)) return 0;
+  if (pro && (mds_knob(MDS_KNOB_C3_DBG) & 32)) return 0;      // A/B: the first 3x3 layer through k_conv.hip
+  if (pro && !(a->Cin == 32 && a->Cout == 16 && !a->residual && a->post.mode == MDS_POST_NONE && a->pro.scale && a->pro.shift)) return 0;
   if (a->A != a->OH || a->B != a->OW || a->OH != a->IH || a->OW != a->IW || a->oy0 || a->ox0) return 0;
   if ((long)a->IH * a->IW * (a->Cin > a->Cout ? a->Cin : a->Cout) >= (1L << 30)) return 0;
   int tapw[9];
@@ -1053,6 +1125,7 @@ int c3_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
   // helper waves: the data gradients read wide rows and write narrow ones (three DMA waves, one store wave); the forward layers two and two
   const bool alt = (mds_knob(MDS_KNOB_C3_DBG) & 16) != 0;      // A/B: the other split
   if (a->Cin == 128 && a->Cout == 32) return alt ? c3_launch<128, 1, 2, 1, 2, 2>(a, tapw, stream) : c3_launch<128, 1, 2, 1, 3, 1>(a, tapw, stream);
+  if (pro) return c3_launch<32, 1, 1, 1, 1, 1, false, 8>(a, tapw, stream);      // the first 3x3 layer: BN + SiLU of the stem's output on the way in
   if (a->Cin == 48 && a->Cout == 192) return c3_launch<48, 2, 2, 1, 2, 2>(a, tapw, stream);      // three passes of 64 channels: a 96-channel slice per wave pair does not fit the registers
   if (a->Cin == 16 && a->Cout == 32) return c3_launch<16, 2, 1, 1, 2, 2>(a, tapw, stream);      // (one DMA wave + three store waves for the POST_SILU form: 12.89 vs 12.15 ms per step - the ring starves)
   if (a->Cin == 32 && a->Cout == 128) return alt ? c3_launch<32, 2, 4, 2, 1, 3>(a, tapw, stream) : c3_launch<32, 2, 4, 2, 2, 2>(a, tapw, stream);

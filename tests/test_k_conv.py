@@ -360,6 +360,19 @@ def test_c3_post_statistics(be, stride, N, H, W, blocks, masked, Cin, Cout):
         be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
 
 
+@pytest.mark.parametrize("N,H,W,blocks", [(2, 13, 128, 0), (1, 21, 70, 2), (1, 40, 64, 1), (1, 2, 64, 0)])
+def test_c3_prologue_through_transform_waves(be, N, H, W, blocks):
+    """the first 3x3 layer (32 -> 16, input = the stem's raw output read through BatchNorm + SiLU): k_c3.hip's transform waves rewrite
+    the landed rows in place one batch ahead of the consumers; zero padding is applied AFTER the activation"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        test_conv_fwd(be, "bf16", N, H, W, 32, 16, 1, 2)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+
+
 def _rand_cases(n, seed):
     import random
     r = random.Random(seed)
