@@ -101,7 +101,7 @@ template <> struct C3Out<3> {
 };
 
 #ifndef C3_ABL
-#define C3_ABL 0   /* experiment builds (make c3abl ABL=n): 1 no output stores, 2 no statistics, 4 fragment reads replaced by a register, 8 no MFMAs */
+#define C3_ABL 0   /* experiment builds (make c3abl ABL=n): 1 no output stores, 2 no statistics, 4 fragment reads replaced by a register, 8 no MFMAs, 16 transform waves copy, 32 transform waves idle */
 #endif
 #ifdef C3_TRACE   /* experiment build (make c3trace): cycle stamps of block C3_TRACE, [batch][wave][phase] in LDS behind the ring, dumped through g.trace */
 #define C3_STAMP(b_, ph_) do { if (trc && lane == 0 && (b_) < 160) { const unsigned long long t_ = __builtin_readcyclecounter(); \
@@ -259,14 +259,22 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW + NTW)) void c3_kernel(C3Args
     // ------------------------------------------------------------------ transform waves (NTW > 0)
     MDS_SETPRIO(3);       // the transform is this form's critical stage
     const int tw = wave - 4 - NPW - NSW;
-    // lane l of piece pc holds part (l % PP) of pixel 64 pc / PP + l / PP; with PP | 64 and a rotation that repeats every 64 / PP
-    // pixels the CHANNELS a lane transforms are the same in every piece: their scale / shift live in registers
-    static_assert(NTW == 0 || (64 % PP == 0 && (((C3Swz<CIN>::A * (64 / PP)) >> C3Swz<CIN>::SH) % PP) == 0), "lane-constant channels");
-    const int lp = lane / PP, lpart = ((lane % PP) - ((C3Swz<CIN>::A * lp) >> C3Swz<CIN>::SH) % PP + PP) % PP;
-    float sc[8], sh[8];
+    // The unit of work is HALF a 16-byte slot (four channels): a row's 2 RPX half slots make NPC pieces of 64, dealt round the
+    // transform waves row by row - finer pieces balance the four SIMDs' VALU queues (the stage is bound by v_exp / v_rcp issue:
+    // 24.5 cycles per wave instruction each, profiles/r06_probe_valu_rate.txt).  Lane l of piece pc holds half (l & 1) of part
+    // ((l >> 1) % PP) of pixel (32 pc + (l >> 1)) / PP; with PP | 32 and a rotation that repeats every 32 / PP pixels the
+    // CHANNELS a lane transforms are the same in every piece: their scale / shift live in registers.
+    static_assert(NTW == 0 || (32 % PP == 0 && (((C3Swz<CIN>::A * (32 / PP)) >> C3Swz<CIN>::SH) % PP) == 0), "lane-constant channels");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int hl = lane >> 1, lp = hl / PP, lpart = ((hl % PP) - ((C3Swz<CIN>::A * lp) >> C3Swz<CIN>::SH) % PP + PP) % PP;
+    f32x2 sc[2], sh[2];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { sc[c] = g.pro_scale[8 * lpart + c]; sh[c] = g.pro_shift[8 * lpart + c]; }
-    constexpr int NPC = (RPX + 63) / 64;                  // pieces of one row
+    for (int c = 0; c < 2; ++c) {
+      const int ch = 8 * lpart + 4 * (lane & 1) + 2 * c;
+      sc[c] = (f32x2){g.pro_scale[ch], g.pro_scale[ch + 1]};
+      sh[c] = (f32x2){g.pro_shift[ch], g.pro_shift[ch + 1]};
+    }
+    constexpr int NPC = (2 * RPX + 63) / 64;              // pieces of one row
     int rslot = 0;
     for (int it = blockIdx.x; it < g.items; it += G) {
       const C3Item im = c3_item(g, it, WB);
@@ -276,23 +284,51 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW + NTW)) void c3_kernel(C3Args
         asm volatile("" ::: "memory");
         raw_barrier();                                    // the batch has landed (the DMA waves waited for it before arriving)
         asm volatile("" ::: "memory");
-        for (int u = tw; u < n * NPC; u += NTW) {         // (row, piece) pairs of the batch, dealt round the transform waves
-          const int j = u / NPC, pc = u - j * NPC;
-          const int ri = im.r0 - 1 + k0 + j;
-          int rs_ = rslot + j;
-          if (rs_ >= g.NR) rs_ -= g.NR;
-          const int sl = 64 * pc + lane, gx = im.x0 - 1 + (64 / PP) * pc + lp;
-          if (sl < RPX) {
-            char* const ptr = smem + rs_ * ROWB + sl * 16;
-            const u16x8 v = *(const u16x8*)ptr;
-            // zero padding AFTER the activation, as a factor (a select per element becomes eight masked branches in hipcc's hands;
-            // the zero page's raw 0 gives a finite silu(shift) to multiply)
-            const float okf = (ri >= 0 && ri < g.H && gx >= 0 && gx < g.W) ? 1.f : 0.f;
-            float f[8];
+        // (row, piece) pairs of the batch, dealt round the transform waves; a wave's reads of the batch all go out before its
+        // first piece's arithmetic (one piece in flight per wave leaves the LDS round trip and the v_exp / v_rcp latencies bare)
+        constexpr int MAXP = (3 * NPC + NTW - 1) / (NTW ? NTW : 1);
+        u16x4 v[MAXP];
+        char* ptr[MAXP];
+        int edge[MAXP];                                   // 0 = inside the image, 1 = touches its edge, -1 = no piece
 #pragma unroll
-            for (int c = 0; c < 8; ++c) f[c] = siluf_(bf2f(v[c]) * sc[c] + sh[c]) * okf;
-            *(u16x8*)ptr = pack8(f);
+        for (int q = 0; q < MAXP; ++q) {
+          const int u = tw + q * NTW;
+          edge[q] = -1;
+          if (u < n * NPC) {
+            const int j = u / NPC, pc = u - j * NPC;
+            const int ri = im.r0 - 1 + k0 + j, px0 = im.x0 - 1 + (32 / PP) * pc;
+            int rs_ = rslot + j;
+            if (rs_ >= g.NR) rs_ -= g.NR;
+            const int h = 64 * pc + lane;
+            ptr[q] = smem + rs_ * ROWB + (h < 2 * RPX ? h : 0) * 8;
+            if (!(C3_ABL & 32)) v[q] = *(const u16x4*)ptr[q];
+            const bool in = ri >= 0 && ri < g.H && px0 >= 0 && px0 + 32 / PP <= g.W;
+            edge[q] = in ? 0 : 1;
           }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) {
+          if (edge[q] < 0 || (C3_ABL & 32)) continue;     // wave-uniform
+          if (C3_ABL & 16) { *(u16x4*)ptr[q] = v[q]; continue; }
+          const int u = tw + q * NTW;
+          const int j = u / NPC, pc = u - j * NPC;
+          f32x2 z[2], e[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            z[c] = (f32x2){bf2f(v[q][2 * c]), bf2f(v[q][2 * c + 1])} * sc[c] + sh[c];
+            const f32x2 t = z[c] * -1.4426950408889634f;
+            e[c] = (f32x2){fast_exp2(t[0]), fast_exp2(t[1])} + 1.0f;
+            z[c] *= (f32x2){fast_rcp(e[c][0]), fast_rcp(e[c][1])};
+          }
+          // zero padding AFTER the activation, as a factor and only in the pieces that touch the image's edge (a select per
+          // element becomes eight masked branches in hipcc's hands; the zero page's raw 0 gives a finite silu(shift))
+          if (edge[q]) {
+            const int ri = im.r0 - 1 + k0 + j, gx = im.x0 - 1 + (32 / PP) * pc + lp;
+            const float okf = (ri >= 0 && ri < g.H && gx >= 0 && gx < g.W) ? 1.f : 0.f;
+            z[0] *= okf; z[1] *= okf;
+          }
+          typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+          if (64 * pc + lane < 2 * RPX) *(u32x2_*)ptr[q] = (u32x2_){pack2(z[0][0], z[0][1]), pack2(z[1][0], z[1][1])};
         }
         rslot += n;
         if (rslot >= g.NR) rslot -= g.NR;
