@@ -976,6 +976,418 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW)) void c3t_kernel(C3Args g) {
   raw_barrier();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Stride-2 FORWARD (TF-SAME with even input extents: pads 0 / 1): out(oy, ox) = sum in(2 oy + ky, 2 ox + kx) w[ky][kx], ky, kx in 0..2
+// (blocks.1.0's and blocks.2.0's first convolutions: 16 -> 64 and 32 -> 128 channels, a quarter of the pixels out).  c3_kernel's
+// machinery - filter slice in registers, DMA row ring, store waves, transform waves for an input read through BatchNorm + SiLU -
+// around a different walk:
+//   * an output row needs input rows 2 oy (ky = 0), 2 oy + 1 (ky = 1) and 2 oy + 2 (ky = 2, also ky = 0 of the row below): an EVEN
+//     input row closes one accumulator set and opens the other, an odd row feeds the open one - two sets, batches of four input
+//     rows (two output rows) behind one barrier;
+//   * the three taps of a row are 3 CIN consecutive channels starting at pixel 2 ox, so the flattened k-steps of c3_kernel carry
+//     over with fragment lane i at pixel 2 i (+ dx): pixel stride 2 costs a 2-way LDS bank conflict whatever the part rotation
+//     (tools/probes/c3_swizzle_check.py) - 8 cycles per fragment read where the HBM stream leaves ~100;
+//   * an input row of a band is 2 WB + 1 pixels; rows / columns H, W (the pad) come from the zero page.
+template <int CIN> struct C3SwzS2;     // part' = (part + ((A * pixel) >> SH)) % (CIN / 8) under pixel stride 2
+template <> struct C3SwzS2<16> { static constexpr int A = 1, SH = 3; };
+template <> struct C3SwzS2<32> { static constexpr int A = 1, SH = 1; };
+
+MDS_DEV C3Item c3s_item(const C3Args& g, int it, int WB) {      // output coordinates
+  const int seg = it % g.nseg, t = it / g.nseg;
+  const int band = t % g.nbands, n = t / g.nbands;
+  C3Item r;
+  r.n = n; r.x0 = band * WB; r.r0 = seg * g.rps;
+  r.r1 = r.r0 + g.rps < g.OH ? r.r0 + g.rps : g.OH;
+  return r;
+}
+
+template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool STATS, bool MASKED, int NTW>
+__global__ __launch_bounds__(256 + 64 * (NPW + NSW + NTW)) void c3s_kernel(C3Args g) {
+  constexpr int LAG = NTW > 0 ? 1 : 0;
+  constexpr int PP = CIN / 8, KSR = (3 * PP + 3) / 4, NSG = 4 / NSPL, WB = 16 * NSG * SPW, COUT = 16 * NF * NSPL, CPP = COUT / 8;
+  constexpr int RPX = (2 * WB + 1) * PP, PIECES = (RPX + 63) / 64, ROWB = RPX * 16;
+  constexpr int STGROW = WB * COUT * 2;
+  constexpr int RSH = CPP == 4 ? 1 : 0;
+  typedef C3SwzS2<CIN> SW;
+  static_assert((((SW::A * 32) >> SW::SH) % PP) == 0, "the rotation repeats from strip to strip");
+  MDS_DYN_SMEM(smem);
+  char* const stg = smem + g.NR * ROWB;               // [2 batch parities][2 output rows][WB pixels][COUT] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int G = gridDim.x;
+  const int c0 = blockIdx.y * COUT;
+  int E = 0;                                          // input rows this block stages and consumes: 2 rows + 1 per item
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3s_item(g, it, WB);
+    E += 2 * (im.r1 - im.r0) + 1;
+  }
+  if (wave >= 4 && wave < 4 + NPW) {
+    // ------------------------------------------------------------------ DMA waves
+    MDS_SETPRIO(3);
+    const int pw = wave - 4;
+    constexpr int PCWMAX = (PIECES + NPW - 1) / NPW;
+    const int pcw = (PIECES - pw + NPW - 1) / NPW;
+    int dcol[PCWMAX], eoff[PCWMAX];
+#pragma unroll
+    for (int j = 0; j < PCWMAX; ++j) {
+      const int sg_ = 64 * (pw + NPW * j) + lane;
+      if (sg_ < RPX) {
+        const int p = sg_ / PP, psw = sg_ - p * PP;
+        const int rot = ((SW::A * p) >> SW::SH) % PP;
+        dcol[j] = p; eoff[j] = 8 * ((psw - rot + PP) % PP);
+      } else {
+        dcol[j] = -(1 << 30); eoff[j] = 0;
+      }
+    }
+    const lds_t ring = lds_addr_of(smem);
+    int hit = blockIdx.x, hk = 0;
+    C3Item him = c3s_item(g, hit < g.items ? hit : 0, WB);
+    int C = 0, hslot = 0;
+    const char* cur[PCWMAX];
+    unsigned step[PCWMAX];
+    auto open_item = [&]() {
+      const char* xrow0 = (const char*)g.x + ((long)him.n * g.H + 2 * him.r0) * g.W * CIN * 2;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const int gx = 2 * him.x0 + dcol[j];
+        const bool ok = gx >= 0 && gx < g.W;
+        cur[j] = ok ? xrow0 + (gx * CIN + eoff[j]) * 2 : (const char*)c3_zero_page;
+        step[j] = ok ? (unsigned)(g.W * CIN * 2) : 0u;
+      }
+    };
+    open_item();
+    auto issue = [&]() {
+      const bool xok = 2 * him.r0 + hk < g.H;             // (row H: the bottom pad)
+      const lds_t dst = ring + (lds_t)(hslot * ROWB);
+      hslot = hslot + 1 == g.NR ? 0 : hslot + 1;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const int pi = pw + NPW * j;
+        if (pi < PIECES) {
+          const char* src = xok ? cur[j] : (const char*)c3_zero_page;
+          if (dcol[j] > -(1 << 29)) glds16(src, dst + (lds_t)(pi * 1024));
+          cur[j] += step[j];
+        }
+      }
+      ++C;
+      if (++hk == 2 * (him.r1 - him.r0) + 1) {
+        hk = 0; hit += G;
+        if (hit < g.items) { him = c3s_item(g, hit, WB); open_item(); }
+      }
+    };
+    while (C < g.RA && C < E) issue();
+    int e0 = 0;
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3s_item(g, it, WB);
+      const int K = 2 * (im.r1 - im.r0) + 1;
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        const int n = K - k0 < 4 ? K - k0 : 4;
+        wait_vm_dyn(pcw * (C - e0 - n));
+        raw_barrier();
+        e0 += n;
+        while (C < e0 + g.RA && C < E) issue();
+      }
+    }
+    raw_barrier();
+    if (LAG) raw_barrier();
+    return;
+  }
+  if (wave >= 4 + NPW + NSW) {
+    // ------------------------------------------------------------------ transform waves (NTW > 0): as in c3_kernel
+    MDS_SETPRIO(3);
+    const int tw = wave - 4 - NPW - NSW;
+    static_assert(NTW == 0 || (32 % PP == 0 && (((SW::A * (32 / PP)) >> SW::SH) % PP) == 0), "lane-constant channels");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int hl = lane >> 1, lp = hl / PP, lpart = ((hl % PP) - ((SW::A * lp) >> SW::SH) % PP + PP) % PP;
+    f32x2 sc[2], sh[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ch = 8 * lpart + 4 * (lane & 1) + 2 * c;
+      sc[c] = (f32x2){g.pro_scale[ch], g.pro_scale[ch + 1]};
+      sh[c] = (f32x2){g.pro_shift[ch], g.pro_shift[ch + 1]};
+    }
+    constexpr int NPC = (2 * RPX + 63) / 64;              // half-slot pieces of one row
+    int rslot = 0;
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3s_item(g, it, WB);
+      const int K = 2 * (im.r1 - im.r0) + 1;
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        const int n = K - k0 < 4 ? K - k0 : 4;
+        asm volatile("" ::: "memory");
+        raw_barrier();
+        asm volatile("" ::: "memory");
+        constexpr int MAXP = (4 * NPC + NTW - 1) / (NTW ? NTW : 1);
+        u16x4 v[MAXP];
+        char* ptr[MAXP];
+        int edge[MAXP];
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) {
+          const int u = tw + q * NTW;
+          edge[q] = -1;
+          if (u < n * NPC) {
+            const int j = u / NPC, pc = u - j * NPC;
+            const int ri = 2 * im.r0 + k0 + j, px0 = 2 * im.x0 + (32 / PP) * pc;
+            int rs_ = rslot + j;
+            if (rs_ >= g.NR) rs_ -= g.NR;
+            const int h = 64 * pc + lane;
+            ptr[q] = smem + rs_ * ROWB + (h < 2 * RPX ? h : 0) * 8;
+            if (!(C3_ABL & 32)) v[q] = *(const u16x4*)ptr[q];
+            edge[q] = (ri < g.H && px0 + 32 / PP <= g.W) ? 0 : 1;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) {
+          if (edge[q] < 0 || (C3_ABL & 32)) continue;
+          if (C3_ABL & 16) { *(u16x4*)ptr[q] = v[q]; continue; }
+          const int u = tw + q * NTW;
+          const int j = u / NPC, pc = u - j * NPC;
+          f32x2 z[2], e[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            z[c] = (f32x2){bf2f(v[q][2 * c]), bf2f(v[q][2 * c + 1])} * sc[c] + sh[c];
+            const f32x2 t = z[c] * -1.4426950408889634f;
+            e[c] = (f32x2){fast_exp2(t[0]), fast_exp2(t[1])} + 1.0f;
+            z[c] *= (f32x2){fast_rcp(e[c][0]), fast_rcp(e[c][1])};
+          }
+          if (edge[q]) {      // the pad (row H, column W and beyond) is zero AFTER the activation
+            const int ri = 2 * im.r0 + k0 + j, gx = 2 * im.x0 + (32 / PP) * pc + lp;
+            const float okf = (ri < g.H && gx < g.W) ? 1.f : 0.f;
+            z[0] *= okf; z[1] *= okf;
+          }
+          typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+          if (64 * pc + lane < 2 * RPX) *(u32x2_*)ptr[q] = (u32x2_){pack2(z[0][0], z[0][1]), pack2(z[1][0], z[1][1])};
+        }
+        rslot += n;
+        if (rslot >= g.NR) rslot -= g.NR;
+        wait_lgkm0();
+      }
+    }
+    raw_barrier();
+    raw_barrier();
+    return;
+  }
+  if (wave >= 4 + NPW) {
+    // ------------------------------------------------------------------ store waves
+    MDS_SETPRIO(3);
+    const int sw = wave - 4 - NPW;
+    constexpr int PPP = 64 / CPP, NP = (WB + PPP - 1) / PPP;
+    static_assert(CPP <= 64, "an output pixel is at most one piece wide");
+    const int lpx = lane / CPP, chunk = lane - lpx * CPP;
+    const bool lact = lpx < PPP;
+    int bidx = 0;
+    C3Item pim = c3s_item(g, blockIdx.x, WB);
+    int pk0 = 0;
+    if (LAG) raw_barrier();
+    auto flush = [&](int par) {
+      for (int j = 0; j < 2; ++j) {
+        const int ro = pim.r0 + pk0 / 2 - 1 + j;          // batch k0 / 4 stages output rows r0 + k0 / 2 - 1 and r0 + k0 / 2
+        if (ro < pim.r0 || ro >= pim.r1) continue;
+        const char* srow = stg + (par * 2 + j) * STGROW;
+        bf16_t* const orow = g.y + c0 + (((long)pim.n * g.OH + ro) * g.OW + pim.x0) * g.Ctot;
+        for (int pc = sw; pc < NP; pc += NSW) {
+          const int cl = pc * PPP + lpx;
+          if (lact && cl < WB && (!MASKED || pim.x0 + cl < g.OW)) {
+            const u16x8 v = *(const u16x8*)(srow + (cl * CPP + (chunk + (cl >> RSH)) % CPP) * 16);
+            *(u16x8*)(orow + cl * g.Ctot + 8 * chunk) = v;
+          }
+        }
+      }
+    };
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3s_item(g, it, WB);
+      const int K = 2 * (im.r1 - im.r0) + 1;
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        asm volatile("" ::: "memory");
+        raw_barrier();
+        asm volatile("" ::: "memory");
+        if (bidx > 0) flush((bidx - 1) & 1);
+        pim = im; pk0 = k0;
+        ++bidx;
+      }
+    }
+    asm volatile("" ::: "memory");
+    raw_barrier();
+    asm volatile("" ::: "memory");
+    flush((bidx - 1) & 1);
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  MDS_SETPRIO(2);
+  const int i = lane & 15, q = lane >> 4;
+  const int nsl = wave % NSPL, sg = wave / NSPL;
+  const int cb = nsl * 16 * NF;
+  u16x8 wr[3][KSR][NF];      // [ky][k-step of (kx, channel)][output fragment]: c3_kernel's row order
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int s = 0; s < KSR; ++s)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int gr = 4 * s + q;
+        u16x8 v = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (gr < 3 * PP) {
+          const int dxi = gr / PP, part = gr - dxi * PP;
+          const int slot = dxi == 0 ? g.tapw[3 * d] : (dxi == 1 ? g.tapw[3 * d + 1] : g.tapw[3 * d + 2]);
+          const int ch = c0 + cb + 4 * NF * (i >> 2) + 4 * nf + (i & 3);
+          v = *(const u16x8*)(g.w + ((long)ch * g.wtaps + slot) * CIN + 8 * part);
+        }
+        wr[d][s][nf] = v;
+      }
+  int xoff[KSR];
+#pragma unroll
+  for (int s = 0; s < KSR; ++s) {
+    const int gr = (4 * s + q) < 3 * PP ? 4 * s + q : 3 * PP - 1;
+    const int dxi = gr / PP, part = gr - dxi * PP, p = 2 * i + dxi;
+    xoff[s] = (p * PP + (part + ((SW::A * p) >> SW::SH)) % PP) * 16 + sg * SPW * 512 * PP;
+  }
+  f32x4 acc[2][SPW][NF];
+  float ps[4 * NF], pss[4 * NF];
+#pragma unroll
+  for (int c = 0; c < 4 * NF; ++c) { ps[c] = 0.f; pss[c] = 0.f; }
+  int slot = 0;
+  constexpr int FR = SPW * KSR;
+  constexpr int CH = FR <= 6 ? FR : 6;
+  constexpr int NCH = (FR + CH - 1) / CH;
+  int bpar = 0;
+  if (LAG) raw_barrier();
+
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3s_item(g, it, WB);
+    const int K = 2 * (im.r1 - im.r0) + 1;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int st = 0; st < SPW; ++st)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[sl][st][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // One batch = input rows (e0, o0, e1, o1) of the item, e0 = 2 r0 + k0 even: e_jj closes set jj (output row r0 + k0 / 2 - 1 + jj:
+    // its ky = 2 taps) and opens set 1 - jj (the row below: ky = 0, zero C operand on the first k-step); o_jj feeds set 1 - jj (ky = 1).
+    // The first batch of an item (HEAD) leaves out e0's closing taps: set 0 stays zero, "output row r0 - 1" is staged as zeros
+    // and skipped by the store waves.
+    auto batch = [&](auto fullc, auto headc, int k0, int n) {
+      constexpr bool FULL = decltype(fullc)::value, HEAD = decltype(headc)::value;
+      wait_lgkm0();
+      raw_barrier();
+      asm volatile("" ::: "memory");
+      char* const sbat = stg + bpar * 2 * STGROW;
+      bpar ^= 1;
+      const char* rows[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rows[j] = smem + slot * ROWB;
+        if (FULL || j < n) slot = slot + 1 == g.NR ? 0 : slot + 1;
+      }
+      u16x8 xs[2][CH];
+      auto load_chunk = [&](int c) {
+        const int j = c / NCH, cc = c - j * NCH;
+        if (FULL || j < n) {
+#pragma unroll
+          for (int f = 0; f < CH; ++f) {
+            const int fr = cc * CH + f;
+            if (fr < FR) xs[c & 1][f] = *(const u16x8*)(rows[j] + (fr / KSR) * 512 * PP + xoff[fr % KSR]);
+          }
+        }
+      };
+      constexpr int NT = (STATS && SPW > 1) ? 3 : 1;
+      auto task = [&](int jj, int ss, int tt) {
+        if (!(FULL || 2 * jj < n)) return;
+        const int cl = 16 * (sg * SPW + ss) + i;
+        const bool ok = !MASKED || im.x0 + cl < g.OW;
+        float v[4 * NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * nf + r] = acc[jj][ss][nf][r];
+        if (tt == 0) {
+          char* const sp = sbat + (jj * WB + cl) * (COUT * 2);
+          const int rot = (cl >> RSH) % CPP;
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            const int o = (cb + 4 * NF * q + 4 * nf) * 2;
+            float v4[4] = {v[4 * nf], v[4 * nf + 1], v[4 * nf + 2], v[4 * nf + 3]};
+            store4((bf16_t*)(sp + ((o / 16 + rot) % CPP) * 16 + (o & 8)), v4);
+          }
+        }
+        if (STATS && tt == (NT == 1 ? 0 : 1)) {
+#pragma unroll
+          for (int c2 = 0; c2 < 4 * NF; ++c2) ps[c2] += (MASKED && !ok) ? 0.f : v[c2];
+        }
+        if (STATS && tt == (NT == 1 ? 0 : 2)) {
+#pragma unroll
+          for (int c2 = 0; c2 < 4 * NF; ++c2) pss[c2] += (MASKED && !ok) ? 0.f : v[c2] * v[c2];
+        }
+      };
+      load_chunk(0);
+#pragma unroll
+      for (int L = 0; L < 4 * FR; ++L) {
+        const int j = L / FR, fr = L - j * FR, st = fr / KSR, s = fr - st * KSR;
+        const int c = j * NCH + fr / CH, f = fr % CH;
+        if (f == 0 && c + 1 < 4 * NCH) load_chunk(c + 1);
+        // output row jj of the batch is closed by even row 2 jj: its strip ss is ready after that row's k-steps of the strip
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int ss = 0; ss < SPW; ++ss)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+              if (2 * jj * FR + ss * KSR + KSR + tt == L) task(jj, ss, tt);
+        if (FULL || j < n) {
+          const int jj = j / 2;
+          if ((j & 1) == 0) {
+            if (!(HEAD && j == 0)) {
+#pragma unroll
+              for (int nf = 0; nf < NF; ++nf) mma16(wr[2][s][nf], xs[c & 1][f], acc[jj][st][nf]);
+            }
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+              if (s == 0) {
+                f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                mma16(wr[0][s][nf], xs[c & 1][f], z);
+                acc[1 - jj][st][nf] = z;
+              } else {
+                mma16(wr[0][s][nf], xs[c & 1][f], acc[1 - jj][st][nf]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) mma16(wr[1][s][nf], xs[c & 1][f], acc[1 - jj][st][nf]);
+          }
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ss = 0; ss < SPW; ++ss)
+#pragma unroll
+          for (int tt = 0; tt < NT; ++tt)
+            if (2 * jj * FR + ss * KSR + KSR + tt >= 4 * FR) task(jj, ss, tt);
+    };
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      if (k0 + 4 <= K) {
+        if (k0 == 0) batch(std::true_type(), std::true_type(), k0, 4);
+        else batch(std::true_type(), std::false_type(), k0, 4);
+      } else {
+        if (k0 == 0) batch(std::false_type(), std::true_type(), k0, K - k0);
+        else batch(std::false_type(), std::false_type(), k0, K - k0);
+      }
+    }
+  }
+  wait_lgkm0();
+  raw_barrier();
+  if (STATS) {
+    double* st = g.stats + (long)(blockIdx.x % MDS_STAT_SLOTS) * 2 * g.Ctot + c0;
+#pragma unroll
+    for (int c = 0; c < 4 * NF; ++c) {
+      const float a = sum_over_i16(ps[c]), b = sum_over_i16(pss[c]);
+      if (i == 0) {
+        atomicAdd(st + cb + 4 * NF * q + c, (double)a);
+        atomicAdd(st + g.Ctot + cb + 4 * NF * q + c, (double)b);
+      }
+    }
+  }
+}
+
 // host side ------------------------------------------------------------------------------------------------------------
 template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, bool ONE = false, int NTW = 0>
 static int c3_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
@@ -1138,10 +1550,78 @@ static int c3t_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
   return 0;
 }
 
+template <int CIN, int NF, int NSPL, int SPW, int NPW, int NSW, int NTW>
+static int c3s_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stream_t stream) {
+  constexpr int PP = CIN / 8, NSG = 4 / NSPL, WB = 16 * NSG * SPW, COUT = 16 * NF * NSPL;
+  constexpr int RPX = (2 * WB + 1) * PP, PIECES = (RPX + 63) / 64, ROWB = RPX * 16, STGROW = WB * COUT * 2;
+  if (a->Cout % COUT) return 0;
+  C3Args g;
+  g.x = (const bf16_t*)a->x; g.w = (const bf16_t*)a->w; g.y = (bf16_t*)a->y; g.res = nullptr; g.stats = a->stats;
+  g.N = a->N; g.H = a->IH; g.W = a->IW; g.OH = a->OH; g.OW = a->OW; g.wtaps = a->wtaps; g.Ctot = a->Cout;
+  const int passes = a->Cout / COUT;
+  for (int t = 0; t < 9; ++t) g.tapw[t] = tapw[t];
+  const int pcw = (PIECES + NPW - 1) / NPW;
+  int RA = (64 * 1024 + ROWB - 1) / ROWB;
+  if (RA < 4) RA = 4;
+  while (RA > 4 && pcw * (RA - 1) > 40) --RA;
+  if (pcw * (RA - 1) > 40) return 0;
+  const int keep = 4 + (NTW ? 4 : 0);       // ring rows beyond the RA in flight: the batch being read (+ the one being transformed)
+  int NR = RA + keep;
+  const size_t lds_cap = 155 * 1024 - 4 * (size_t)STGROW;
+  while ((size_t)NR * ROWB > lds_cap && RA > 4) { --RA; NR = RA + keep; }
+  if ((size_t)NR * ROWB > lds_cap) return 0;
+  g.RA = RA; g.NR = NR; g.dbg = 0; g.trace = nullptr;
+  g.py = nullptr; g.pbn = nullptr; g.pmask = nullptr; g.pstats = nullptr; g.pmode = 0;
+  g.pro_scale = a->pro.scale; g.pro_shift = a->pro.shift;
+  int CUS = 256 / passes;
+  if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);
+  g.nbands = cdiv(a->OW, WB);
+  long best = -1;
+  for (int ns = 1; ns <= 64 && ns <= a->OH; ++ns) {
+    const int rps = cdiv(a->OH, ns), nsr = cdiv(a->OH, rps);
+    const long items = (long)a->N * g.nbands * nsr;
+    const long per = (items + CUS - 1) / CUS;
+    const long cost = per * (2 * rps + 1 + 4);
+    if (best < 0 || cost < best) { best = cost; g.nseg = nsr; g.rps = rps; g.items = (int)items; }
+  }
+  const int grid = g.items < CUS ? g.items : CUS;
+  const size_t smem = (size_t)NR * ROWB + 4 * (size_t)STGROW;
+  dim3 block(256 + 64 * (NPW + NSW + NTW));
+  const bool masked = a->OW % WB != 0, stats = a->stats != nullptr;
+#define C3S_GO(S, M) MDS_LAUNCH((c3s_kernel<CIN, NF, NSPL, SPW, NPW, NSW, S, M, NTW>), dim3(grid, passes), block, smem, stream, g)
+  if (stats) { if (masked) C3S_GO(true, true); else C3S_GO(true, false); }
+  else { if (masked) C3S_GO(false, true); else C3S_GO(false, false); }
+#undef C3S_GO
+  return 1;
+}
+
+// the stride-2 forward layers (TF-SAME pads 0 / 1, even extents): taps (ky, kx) in 0..2 from the input pixel (2 oy, 2 ox)
+static int c3s_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
+  const bool pro = a->pro.mode == MDS_PRO_BN_SILU;
+  if (a->dtype != MDS_BF16 || a->os != 1 || a->ntaps != 9 || a->ngroups > 1 || a->residual || a->post.mode != MDS_POST_NONE) return 0;
+  if ((a->pro.mode != MDS_PRO_NONE && !pro) || a->epi.mode != MDS_EPI_NONE || (pro && !(a->pro.scale && a->pro.shift))) return 0;
+  if ((mds_knob(MDS_KNOB_C3_DBG) & 64)) return 0;      // A/B: the stride-2 forward layers through k_conv.hip
+  if (a->IH % 2 || a->IW % 2 || a->OH != a->IH / 2 || a->OW != a->IW / 2 || a->A != a->OH || a->B != a->OW || a->oy0 || a->ox0) return 0;
+  if ((long)a->IH * a->IW * a->Cin >= (1L << 30) || (long)a->OH * a->OW * a->Cout >= (1L << 30)) return 0;
+  int tapw[9];
+  for (int t = 0; t < 9; ++t) tapw[t] = -1;
+  for (int t = 0; t < 9; ++t) {
+    if (a->dy[t] < 0 || a->dy[t] > 2 || a->dx[t] < 0 || a->dx[t] > 2) return 0;
+    tapw[3 * a->dy[t] + a->dx[t]] = a->wi[t];
+  }
+  for (int t = 0; t < 9; ++t) if (tapw[t] < 0 || tapw[t] >= a->wtaps) return 0;
+  if ((long)a->N * a->OH * a->OW < 16384 && mds_knob(MDS_KNOB_C3) != 2) return 0;
+  if (a->Cin == 32 && a->Cout == 128 && !pro) return c3s_launch<32, 2, 4, 2, 2, 2, 0>(a, tapw, stream);      // blocks.2.0
+  if (a->Cin == 16 && a->Cout == 64 && !pro) return c3s_launch<16, 2, 2, 2, 2, 2, 0>(a, tapw, stream);
+  if (a->Cin == 16 && a->Cout == 64 && pro) return c3s_launch<16, 1, 4, 4, 1, 1, 6>(a, tapw, stream);        // blocks.1.0: reads blocks.0.0's raw output
+  return 0;
+}
+
 // 1 = launched, 0 = not a shape of this kernel (the caller goes on to k_conv.hip's kernels)
 int c3_try(const mds_conv_fwd_args* a, mds_stream_t stream) {
   if (mds_knob(MDS_KNOB_C3) == 1) return 0;
   if (a->ngroups == 4) return c3t_try(a, stream);
+  if (a->is == 2) return c3s_try(a, stream);
   if (a->dtype != MDS_BF16 || a->is != 1 || a->os != 1 || a->ntaps != 9 || a->ngroups > 1) return 0;
   const bool pro = a->pro.mode == MDS_PRO_BN_SILU;
   if ((a->pro.mode != MDS_PRO_NONE && !pro) || a->epi.mode != MDS_EPI_NONE || !c3_post_ok(a)) return 0;

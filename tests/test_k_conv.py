@@ -373,6 +373,31 @@ def test_c3_prologue_through_transform_waves(be, N, H, W, blocks):
         be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
 
 
+C3S_CASES = [  # N, H, W (even: TF-SAME pads 0 / 1), Cin, Cout, prologue mode, block cap
+    (2, 12, 128, 32, 128, 0, 0),      # blocks.2.0's first convolution: two exact 32-column output bands, two images
+    (1, 22, 40, 32, 128, 0, 2),       # ragged band (20 output columns), an odd number of output rows, two blocks walk several items
+    (1, 8, 256, 16, 64, 0, 0),        # blocks.1.0's shape without the prologue: 64-column output bands, half-empty second k-step
+    (1, 30, 70, 16, 64, 0, 3),
+    (1, 2, 32, 32, 128, 0, 1),        # a single output row: one even input row + the pad row
+    (2, 10, 128, 16, 64, 2, 0),       # blocks.1.0: the input is blocks.0.0's raw output read through BatchNorm + SiLU (transform waves)
+    (1, 26, 100, 16, 64, 2, 2),       # ... ragged band: the pad column and the columns past it are zero AFTER the activation
+    (1, 4, 36, 16, 64, 2, 1),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,mode,blocks", C3S_CASES)
+def test_c3s_stride2_forward(be, N, H, W, Cin, Cout, mode, blocks):
+    """k_c3.hip's stride-2 forward kernel (bf16, even extents): two rolling accumulator sets over batches of four input rows,
+    pixel-stride-2 fragment reads, zero-page pad row / column, forward statistics - against torch's conv2d through test_conv_fwd"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        test_conv_fwd(be, "bf16", N, H, W, Cin, Cout, 2, mode)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+
+
 def _rand_cases(n, seed):
     import random
     r = random.Random(seed)
