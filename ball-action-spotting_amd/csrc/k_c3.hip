@@ -86,6 +86,15 @@ MDS_DEV C3Item c3_item(const C3Args& g, int it, int WB) {
   return r;
 }
 
+MDS_DEV C3Item c3_item_h(int nseg, int nbands, int rps, int H, int it, int WB) {
+  const int seg = it % nseg, t = it / nseg;
+  const int band = t % nbands, n = t / nbands;
+  C3Item r;
+  r.n = n; r.x0 = band * WB; r.r0 = seg * rps;
+  r.r1 = r.r0 + rps < H ? r.r0 + rps : H;
+  return r;
+}
+
 template <int NF> struct C3Out;
 template <> struct C3Out<1> {
   static MDS_DEV void st(bf16_t* p, const float (&v)[4]) { store4(p, v); }
@@ -1386,6 +1395,296 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW + NTW)) void c3s_kernel(C3Arg
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the stride-1 3x3 layers (blocks.1.1: 32 -> 128, blocks.2.1: 48 -> 192), row streaming:
+//   dw[co][ci][ky][kx] += sum over pixels of dy[n][r][x][co] * in[n][r + ky - 1][x + kx - 1][ci].
+// The MFMA reduction index is the PIXEL: both operands are read from pixel-major LDS rows with the transposing read
+// (ds_read_b64_tr_b16: 4 pixels x 16 channels per 16-lane group), 32 pixels of one band row per k-step.  A ring entry is image row j
+// of the band: its input pixels (+ one halo pixel either side) and its dy pixels (zeros outside the item's rows, so that every
+// (input row, dy row) pair is counted by exactly one item), landed by LDS-DMA waves as in c3_kernel.  Input row j meets dy rows
+// j + 1, j, j - 1 (ky = 0, 1, 2): its three shifted fragments per 16 input channels are read ONCE for all three.  The four
+// consumer waves split the OUTPUT channels (COW 16-channel fragments each, COP = 64 COW per channel pass = grid.y); a wave keeps
+// its 9 x CIN x 16 COW accumulators in registers for the whole launch and adds them to dw once, through LDS, with coalesced atomics.
+// k_conv.hip's kernel stages 8 x 16 patches through registers behind two block barriers per patch: 2.6 / 1.1 TB/s on these layers.
+struct C3WArgs {
+  const bf16_t* x;     // [N][H][W][CIN]
+  const bf16_t* dy;    // [N][H][W][Ctot]
+  float* dw;           // [Ctot][CIN][wtaps]
+  int N, H, W, Ctot, wtaps;
+  int tapw[9];         // weight slot of tap (ky, kx)
+  int nbands, nseg, rps, items;
+  int RA, NR;
+};
+
+template <int NC> MDS_DEV int c3w_rot(int c, int p) {      // where 32-byte chunk c of pixel p sits inside the pixel: 8 consecutive pixels' chunk c tile all 64 banks
+  return NC == 2 ? (c ^ ((p >> 2) & 1)) : (NC == 4 ? ((c + (p >> 1)) & 3) : (NC == 8 ? ((c + p) & 7) : (NC == 6 ? (c + ((p >> 2) & 1)) % 6 : c)));
+}
+template <int NC> MDS_DEV int c3w_unrot(int c, int p) {
+  return NC == 2 ? (c ^ ((p >> 2) & 1)) : (NC == 4 ? ((c - (p >> 1)) & 3) : (NC == 8 ? ((c - p) & 7) : (NC == 6 ? (c - ((p >> 2) & 1) + 6) % 6 : c)));
+}
+
+template <int CIN, int COW, int NCW, int NPW>
+__global__ __launch_bounds__(64 * (NCW + NPW)) void c3w_kernel(C3WArgs g) {
+  constexpr int CI = CIN / 16, COP = 16 * COW * NCW, PPX = CIN / 8, PPY = COP / 8, WB = 32;
+  constexpr int XS = (WB + 2) * PPX, XSP = (XS + 63) / 64 * 64, YS = WB * PPY, RS = XSP + YS, PIECES = RS / 64, ROWB = RS * 16;
+  static_assert(YS % 64 == 0 && (CI == 2 || CI == 3) && (PPY == 8 || PPY == 12 || PPY == 16), "shapes of this kernel");
+  MDS_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int G = gridDim.x;
+  const int c0 = blockIdx.y * COP;
+  int E = 0;
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
+    E += im.r1 - im.r0 + 2;
+  }
+  if (wave >= NCW) {
+    // ------------------------------------------------------------------ DMA waves
+    MDS_SETPRIO(3);
+    const int pw = wave - NCW;
+    constexpr int PCWMAX = (PIECES + NPW - 1) / NPW;
+    const int pcw = (PIECES - pw + NPW - 1) / NPW;
+    int dcol[PCWMAX], eoff[PCWMAX];
+#pragma unroll
+    for (int j = 0; j < PCWMAX; ++j) {
+      const int sg_ = 64 * (pw + NPW * j) + lane;
+      if (sg_ < XS) {
+        const int p = sg_ / PPX, t = sg_ - p * PPX;
+        dcol[j] = p - 1; eoff[j] = 16 * c3w_unrot<CI>(t >> 1, p) + 8 * (t & 1);
+      } else if (sg_ >= XSP && sg_ < RS) {
+        const int u = sg_ - XSP, p = u / PPY, t = u - p * PPY;
+        dcol[j] = p; eoff[j] = 16 * c3w_unrot<PPY / 2>(t >> 1, p) + 8 * (t & 1);
+      } else {
+        dcol[j] = -(1 << 30); eoff[j] = 0;
+      }
+    }
+    const lds_t ring = lds_addr_of(smem);
+    int hit = blockIdx.x, hk = 0;
+    C3Item him = c3_item_h(g.nseg, g.nbands, g.rps, g.H, hit < g.items ? hit : 0, WB);
+    int C = 0, hslot = 0;
+    const char* cur[PCWMAX];
+    unsigned step[PCWMAX];
+    auto open_item = [&]() {
+      const char* xrow0 = (const char*)g.x + ((long)him.n * g.H + him.r0 - 1) * g.W * CIN * 2;
+      const char* yrow0 = (const char*)(g.dy + c0) + ((long)him.n * g.H + him.r0 - 1) * g.W * g.Ctot * 2;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const bool isy = 64 * (pw + NPW * j) >= XSP;
+        const int gx = him.x0 + dcol[j];
+        const bool ok = gx >= 0 && gx < g.W;
+        cur[j] = ok ? (isy ? yrow0 : xrow0) + (gx * (isy ? g.Ctot : CIN) + eoff[j]) * 2 : (const char*)c3_zero_page;
+        step[j] = ok ? (unsigned)(g.W * (isy ? g.Ctot : CIN) * 2) : 0u;
+      }
+    };
+    open_item();
+    auto issue = [&]() {
+      const int ri = him.r0 - 1 + hk;
+      const bool xok = ri >= 0 && ri < g.H, yok = ri >= him.r0 && ri < him.r1;      // dy: the item's own rows only
+      const lds_t dst = ring + (lds_t)(hslot * ROWB);
+      hslot = hslot + 1 == g.NR ? 0 : hslot + 1;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const int pi = pw + NPW * j;
+        if (pi < PIECES) {
+          const bool isy = 64 * pi >= XSP;                     // wave-uniform
+          const char* src = (isy ? yok : xok) ? cur[j] : (const char*)c3_zero_page;
+          if (dcol[j] > -(1 << 29)) glds16(src, dst + (lds_t)(pi * 1024));
+          cur[j] += step[j];
+        }
+      }
+      ++C;
+      if (++hk == him.r1 - him.r0 + 2) {
+        hk = 0; hit += G;
+        if (hit < g.items) { him = c3_item_h(g.nseg, g.nbands, g.rps, g.H, hit, WB); open_item(); }
+      }
+    };
+    while (C < g.RA && C < E) issue();
+    int e0 = 0;
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
+      const int K = im.r1 - im.r0 + 2;
+      for (int k0 = 0; k0 < K; k0 += 3) {
+        const int n = K - k0 < 3 ? K - k0 : 3;
+        wait_vm_dyn(pcw * (C - e0 - n));
+        raw_barrier();
+        e0 += n;
+        while (C < e0 + g.RA && C < E) issue();       // into slots of entries < e0 - n - 2: the consumers read back to there
+      }
+    }
+    raw_barrier();          // the consumers are done with the ring (they reuse it to flush)
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  MDS_SETPRIO(2);
+  const int i = lane & 15, q = lane >> 4;
+  // byte offsets (inside a ring entry) of this lane's 8-byte share of the transposing reads: 4 pixels x 16 channels per 16-lane group
+  int xo[3][2][CI], yo[2][COW];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < CI; ++c) {
+        const int p = kx + 4 * q + 16 * h + (i >> 2);           // band pixel 0 = column x0 - 1; k index 8 q + 4 h + e <-> pixel 4 q + 16 h + e (any
+                                                                // pixel <-> k map serves, as long as both operands use it): a 32-lane LDS cycle touches 8 CONSECUTIVE pixels
+        xo[kx][h][c] = p * PPX * 16 + c3w_rot<CI>(c, p) * 32 + 8 * (i & 3);
+      }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int f = 0; f < COW; ++f) {
+      const int p = 4 * q + 16 * h + (i >> 2);
+      yo[h][f] = XSP * 16 + p * PPY * 16 + c3w_rot<PPY / 2>(wave * COW + f, p) * 32 + 8 * (i & 3);
+    }
+  f32x4 acc[9][CI][COW];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CI; ++c)
+#pragma unroll
+      for (int f = 0; f < COW; ++f) acc[t][c][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int sp = 0, sc = 0, sn = g.NR > 1 ? 1 : 0;           // ring slots of entries k - 1, k, k + 1
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
+    const int K = im.r1 - im.r0 + 2;
+    for (int k0 = 0; k0 < K; k0 += 3) {
+      const int n = K - k0 < 3 ? K - k0 : 3;
+      asm volatile("" ::: "memory");
+      raw_barrier();                                  // entries k0 .. k0 + n - 1 have landed
+      asm volatile("" ::: "memory");
+      // input row k needs dy entries k - 1 .. k + 1: rows up to k0 + n - 2 now, the item's last row with its last batch
+      const int klo = k0 == 0 ? 0 : k0 - 1, khi = k0 + n == K ? K - 1 : k0 + n - 2;
+      for (int k = klo; k <= khi; ++k) {
+        // all of the row's fragments go out before its first MFMA: one LDS round trip per row, which the SIMD's other consumer wave
+        // fills with its MFMAs (NCW = 8: two per SIMD)
+        const char* const er = smem + sc * ROWB;
+        u16x8 af[3][CI], bf[3][COW];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int c = 0; c < CI; ++c) {
+            u16x4 lo, hi;
+            if (C3_ABL & 1024) { lo = (u16x4){(uint16_t)xo[kx][0][c], 1, 2, 3}; hi = lo; }
+            else { lo = lds_tr4((const bf16_t*)(er + xo[kx][0][c])); hi = lds_tr4((const bf16_t*)(er + xo[kx][1][c])); }
+            af[kx][c] = (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          if ((ky == 0 && k == K - 1) || (ky == 2 && k == 0)) continue;      // (wave-uniform) no entry below / above inside the item
+          const char* const yr = smem + (ky == 0 ? sn : (ky == 1 ? sc : sp)) * ROWB;
+#pragma unroll
+          for (int f = 0; f < COW; ++f) {
+            u16x4 lo, hi;
+            if (C3_ABL & 1024) { lo = (u16x4){(uint16_t)yo[0][f], 1, 2, 3}; hi = lo; }
+            else { lo = lds_tr4((const bf16_t*)(yr + yo[0][f])); hi = lds_tr4((const bf16_t*)(yr + yo[1][f])); }
+            bf[ky][f] = (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          if ((ky == 0 && k == K - 1) || (ky == 2 && k == 0)) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < CI; ++c)
+#pragma unroll
+              for (int f = 0; f < COW; ++f) {
+                if (C3_ABL & 512) acc[3 * ky + kx][c][f][0] += bf2f(bf[ky][f][0]) + bf2f(af[kx][c][1]);
+                else mma16(bf[ky][f], af[kx][c], acc[3 * ky + kx][c][f]);      // acc[r] = dw[co = 4 q + r][ci = i]
+              }
+        }
+        sp = sc; sc = sn; sn = sn + 1 == g.NR ? 0 : sn + 1;
+      }
+    }
+  }
+  asm volatile("" ::: "memory");
+  raw_barrier();                                      // every wave is past its last ring read: the ring becomes the flush staging area
+  asm volatile("" ::: "memory");
+  // flush: a wave's 16-channel slab in the parameter's OIHW order through its own LDS region, then coalesced atomics
+  constexpr int SLAB = CIN * 9;                        // floats per output channel (wtaps == 9)
+  float* const fl = (float*)smem + (wave & 3) * 16 * SLAB;
+  for (int rd = 0; rd < (NCW + 3) / 4; ++rd) {          // four waves' staging regions fit the LDS: the waves flush in rounds of four
+    if ((wave >> 2) == rd) {
+#pragma unroll
+      for (int f = 0; f < COW; ++f) {
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int c = 0; c < CI; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fl[(4 * q + r) * SLAB + (16 * c + i) * 9 + g.tapw[t]] = acc[t][c][f][r];
+        wave_lds_sync();
+        float* const dst = g.dw + (long)(c0 + 16 * (wave * COW + f)) * SLAB;
+        // (every block adds to the same 9 CIN COP addresses: each starts somewhere else)
+        const int e0 = (int)((blockIdx.x * 37u) % (16 * SLAB / 64)) * 64;
+        if (!(C3_ABL & 256)) for (int e = lane; e < 16 * SLAB; e += 64) { const int ee = e + e0 < 16 * SLAB ? e + e0 : e + e0 - 16 * SLAB; atomicAdd(dst + ee, fl[ee]); }
+        else if (fl[lane] == 12345.678f) dst[lane] = 1.f;
+      }
+    }
+    if (rd + 1 < (NCW + 3) / 4) { wait_lgkm0(); raw_barrier(); }
+  }
+}
+
+template <int CIN, int COW, int NCW, int NPW>
+static int c3w_launch(const mds_conv_wgrad_args* a, const int (&tapw)[9], mds_stream_t stream) {
+  constexpr int COP = 16 * COW * NCW, PPX = CIN / 8, PPY = COP / 8, WB = 32;
+  constexpr int XS = (WB + 2) * PPX, XSP = (XS + 63) / 64 * 64, RS = XSP + WB * PPY, PIECES = RS / 64, ROWB = RS * 16;
+  if (a->Cout % COP) return 0;
+  C3WArgs g;
+  g.x = (const bf16_t*)a->x; g.dy = (const bf16_t*)a->dyt; g.dw = a->dw;
+  g.N = a->N; g.H = a->IH; g.W = a->IW; g.Ctot = a->Cout; g.wtaps = a->wtaps;
+  for (int t = 0; t < 9; ++t) g.tapw[t] = tapw[t];
+  const int passes = a->Cout / COP;
+  const int pcw = (PIECES + NPW - 1) / NPW;
+  int RA = (80 * 1024 + ROWB - 1) / ROWB;
+  if (RA < 3) RA = 3;
+  while (RA > 3 && pcw * (RA - 1) > 40) --RA;
+  if (pcw * (RA - 1) > 40) return 0;
+  int NR = RA + 6;                                     // the consumers read back to entry k0 - 2 of the batch (+ one of slack)
+  const size_t lds_cap = 158 * 1024;
+  while ((size_t)NR * ROWB > lds_cap && RA > 3) { --RA; NR = RA + 6; }
+  if ((size_t)NR * ROWB > lds_cap) return 0;
+  g.RA = RA; g.NR = NR;
+  int CUS = 256 / passes;
+  if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);
+  g.nbands = cdiv(a->IW, WB);
+  long best = -1;
+  for (int ns = 1; ns <= 64 && ns <= a->IH; ++ns) {
+    const int rps = cdiv(a->IH, ns), nsr = cdiv(a->IH, rps);
+    const long items = (long)a->N * g.nbands * nsr;
+    const long per = (items + CUS - 1) / CUS;
+    const long cost = per * (rps + 2 + 2);
+    if (best < 0 || cost < best) { best = cost; g.nseg = nsr; g.rps = rps; g.items = (int)items; }
+  }
+  const int grid = g.items < CUS ? g.items : CUS;
+  size_t smem = (size_t)NR * ROWB;
+  const size_t flush = (size_t)4 * 16 * CIN * 9 * 4;
+  if (smem < flush) smem = flush;
+  dim3 block(64 * (NCW + NPW));
+  MDS_LAUNCH((c3w_kernel<CIN, COW, NCW, NPW>), dim3(grid, passes), block, smem, stream, g);
+  return 1;
+}
+
+// mds_conv_wgrad's large prologue-free stride-1 bf16 launches; 1 = launched, 0 = not one of these (k_conv.hip's kernel)
+int c3w_try(const mds_conv_wgrad_args* a, mds_stream_t stream) {
+  if (mds_knob(MDS_KNOB_C3) == 1 || (mds_knob(MDS_KNOB_C3_DBG) & 128)) return 0;
+  if (a->dtype != MDS_BF16 || a->is != 1 || a->ntaps != 9 || a->wtaps != 9 || a->pro.mode != MDS_PRO_NONE) return 0;
+  if (a->OH != a->IH || a->OW != a->IW) return 0;
+  if ((long)a->IH * a->IW * a->Cout >= (1L << 30)) return 0;
+  int tapw[9];
+  for (int t = 0; t < 9; ++t) tapw[t] = -1;
+  for (int t = 0; t < 9; ++t) {
+    if (a->dy[t] < -1 || a->dy[t] > 1 || a->dx[t] < -1 || a->dx[t] > 1) return 0;
+    tapw[3 * (a->dy[t] + 1) + a->dx[t] + 1] = a->wi[t];
+  }
+  for (int t = 0; t < 9; ++t) if (tapw[t] < 0 || tapw[t] >= 9) return 0;
+  if ((long)a->N * a->IH * a->IW < 16384 && mds_knob(MDS_KNOB_C3) != 2) return 0;
+  if (a->Cin == 32 && a->Cout == 128) return c3w_launch<32, 1, 8, 3>(a, tapw, stream);      // blocks.1.1: eight consumer waves of one 16-channel fragment each
+  if (a->Cin == 48 && a->Cout == 192) return c3w_launch<48, 1, 6, 2>(a, tapw, stream);      // blocks.2.1: two passes of 96 channels, six consumer waves
+  return 0;
 }
 
 // host side ------------------------------------------------------------------------------------------------------------

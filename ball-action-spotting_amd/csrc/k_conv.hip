@@ -841,6 +841,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(mds_conv_wgrad_args a, 
   }
 }
 
+int c3w_try(const mds_conv_wgrad_args* a, mds_stream_t stream);      // k_c3.hip: the large stride-1 bf16 launches, row streaming; 1 = launched
 extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream) {
   MDS_REQUIRE(a && a->N > 0 && a->OH > 0 && a->OW > 0, "conv_wgrad: bad dims");
   MDS_REQUIRE(a->Cin % 16 == 0 && a->Cin <= 48 && a->Cout % 16 == 0, "conv_wgrad: needs Cin in {16,32,48}, Cout %% 16 (Cin=%d Cout=%d)", a->Cin, a->Cout);
@@ -848,6 +849,7 @@ extern "C" int mds_conv_wgrad(const mds_conv_wgrad_args* a, mds_stream_t stream)
   MDS_REQUIRE(a->x && a->dyt && a->dw, "conv_wgrad: null pointer");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || a->pro.mode == MDS_PRO_AFFINE || a->pro.mode == MDS_PRO_BN_SILU, "conv_wgrad: prologue mode");
   MDS_REQUIRE(a->pro.mode == MDS_PRO_NONE || (a->pro.scale && a->pro.shift), "conv_wgrad: prologue needs scale/shift");
+  if (c3w_try(a, stream)) return mds_check_launch("conv_wgrad");
   int dymin, dxmin;
   const int eh = tap_extent(a->dy, a->ntaps, &dymin), ew = tap_extent(a->dx, a->ntaps, &dxmin);
   const int TH = (CV_TA - 1) * a->is + eh + 1, TW = (CV_TB - 1) * a->is + ew + 1;

@@ -398,6 +398,29 @@ def test_c3s_stride2_forward(be, N, H, W, Cin, Cout, mode, blocks):
         be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
 
 
+C3W_CASES = [  # N, H, W, Cin, Cout, block cap
+    (2, 13, 37, 32, 128, 0),       # blocks.1.1's weight gradient: ragged 32-column band, two images
+    (1, 23, 64, 32, 128, 3),       # three blocks walk several items each: the ring runs across item boundaries
+    (2, 12, 37, 48, 192, 0),       # blocks.2.1's: three channel passes of 64
+    (1, 20, 50, 48, 192, 2),
+    (1, 3, 32, 32, 128, 1),        # fewer rows than the ring is deep
+    (1, 1, 16, 48, 192, 0),        # a single image row: one input row between two zero entries
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,blocks", C3W_CASES)
+def test_c3w_weight_gradient_row_streaming(be, N, H, W, Cin, Cout, blocks):
+    """k_c3.hip's weight-gradient kernel (bf16, stride 1, no prologue): pixel-major rows of input and dy through the DMA ring, both
+    MFMA operands by transposing LDS reads, dy zero outside an item's rows, OIHW flush through LDS - against autograd"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        test_conv_wgrad(be, "bf16", N, H, W, Cin, Cout, 1, 0)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+
+
 def _rand_cases(n, seed):
     import random
     r = random.Random(seed)

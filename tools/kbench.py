@@ -26,6 +26,8 @@ def frag_pack(lib, w):
     torch.cuda.synchronize()
     return dst
 
+if os.environ.get("C3_LIB"):      # an experiment build (make c3abl ABL=n)
+    cabi.HIP_LIB = os.path.join(ROOT, "ball-action-spotting_amd", "csrc", os.environ["C3_LIB"])
 lib = cabi.load()
 BF = torch.bfloat16
 SLOTS = cabi.MDS_STAT_SLOTS
