@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(mds_se_fc_bwd_args a) {
 }
 // launch B — parameter gradients: dw2[c][r], dw1[r][c] (thread per (r, c), c fastest); r == 0
 // threads also do db2[c]; block 0 db1
-__global__ __launch_bounds__(256) void se_bwd_b_kernel(mds_se_fc_bwd_args a) {
+MDS_DEV void se_bwd_b_body(const mds_se_fc_bwd_args& a) {
   const int G = a.groups, C = a.C, R = a.R;
   if (blockIdx.x == 0) {
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
@@ -483,6 +483,15 @@ __global__ __launch_bounds__(256) void se_bwd_b_kernel(mds_se_fc_bwd_args a) {
   a.dw1[(long)r * C + c] += s1;
   if (r == 0) a.db2[c] += db2;
 }
+__global__ __launch_bounds__(256) void se_bwd_b_kernel(mds_se_fc_bwd_args a) { se_bwd_b_body(a); }
+// the same for a device-resident table of layers (grid.y = layer): the parameter gradients of the squeeze-excite layers are leaves
+// of the backward - nothing downstream reads them before the optimizer - so the planner defers them and launches one table per
+// gradient bucket instead of one 36 us latency-bound kernel per layer (20 per step)
+__global__ __launch_bounds__(256) void se_bwd_b_table_kernel(const mds_se_fc_bwd_args* jobs) {
+  const mds_se_fc_bwd_args a = jobs[blockIdx.y];
+  if ((long)blockIdx.x * 256 >= (long)a.R * a.C) return;
+  se_bwd_b_body(a);
+}
 static int se_fc_bwd_check(const mds_se_fc_bwd_args* a) {
   MDS_REQUIRE(a && a->groups > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= 2048 && a->R > 0 && a->R <= SE_RMAX && a->rows_per_group > 0, "se_fc_bwd: bad dims (R <= %d, C % 4 == 0, C <= 2048)", SE_RMAX);
   MDS_REQUIRE(a->scratch && a->dgate && a->gate && a->hidden && a->pooled && a->dpooled, "se_fc_bwd: null pointer");
@@ -501,6 +510,11 @@ extern "C" int mds_se_fc_bwd_params(const mds_se_fc_bwd_args* a, mds_stream_t st
   MDS_REQUIRE(a->dw1 && a->db1 && a->dw2 && a->db2, "se_fc_bwd_params: null gradient pointer");
   MDS_LAUNCH(se_bwd_b_kernel, dim3(cdiv((long)a->R * a->C, 256)), dim3(256), 0, stream, *a);
   return mds_check_launch("se_fc_bwd_params");
+}
+extern "C" int mds_se_fc_bwd_params_table(const mds_se_fc_bwd_table_args* a, mds_stream_t stream) {
+  MDS_REQUIRE(a && a->jobs && a->njobs > 0 && a->max_rc > 0, "se_fc_bwd_params_table: empty table");
+  MDS_LAUNCH(se_bwd_b_table_kernel, dim3(cdiv(a->max_rc, 256), a->njobs), dim3(256), 0, stream, (const mds_se_fc_bwd_args*)a->jobs);
+  return mds_check_launch("se_fc_bwd_params_table");
 }
 extern "C" int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream) {
   if (int rc = mds_se_fc_bwd_data(a, stream)) return rc;

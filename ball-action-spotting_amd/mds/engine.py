@@ -229,6 +229,8 @@ class Plan:
         self.segs: Dict[str, list] = {"pack": [], "f2d": [], "f3d": [], "fhead": [], "bhead": [], "b3d": [], "b2d": []}
         self._recs: Dict[str, list] = {"2d": [], "3d": [], "head": []}
         self.pack_jobs = []
+        self._se_pending = []       # squeeze-excite parameter-gradient launches deferred to the end of their gradient bucket
+        self.se_table = os.environ.get("MDS_SE_PARAMS_TABLE", "1") == "1"
         self._bn_buffers = []    # running_mean / running_var / num_batches_tracked of every BatchNorm this plan updates
         self.taps = []           # block outputs in forward order: dict(tag, buf, bn (raw tensor read through BN+SiLU) or None, rows, C)
         self.masks = []          # (Lazy view, keep_prob)
@@ -364,13 +366,20 @@ class Plan:
             # lets the all-reduce of that slice of the flat arena start while the rest of the backward still runs.
             self.cuts = {}           # (segment, number of ops issued) -> (lo, hi) slice of the gradient arena
             hi, lo, executed = self.grad_arena.numel, self.grad_arena.numel, []
+            def flush_se(bseg):     # the deferred squeeze-excite parameter gradients of the closures issued so far: one launch
+                if self._se_pending:
+                    self.op(bseg, "se_fc_bwd_params_table", _struct="mds_se_fc_bwd_table_args", _jobs=self._se_pending)
+                    self._se_pending = []
             for i, (rec, bseg) in enumerate(chain):
                 nxt = chain[i + 1][0] if i + 1 < len(chain) else None
                 # `head` of the next closure: the BatchNorm whose backward consumes this closure's output directly
                 gout = rec(bseg, gout, getattr(nxt, "head", None) if self.fuse_bn_bwd else None)
                 last = gout is None or nxt is None
                 lo = min(lo, getattr(rec, "lo", lo))
-                if len(self.segs[bseg]) and (hi - lo >= self.BUCKET_ELEMS or last) and hi > lo:
+                cut = len(self.segs[bseg]) and (hi - lo >= self.BUCKET_ELEMS or last) and hi > lo
+                if cut or last or chain[i + 1][1] != bseg:
+                    flush_se(bseg)          # (a bucket is final only with every launch that adds into it issued)
+                if cut:
                     self.cuts[(bseg, len(self.segs[bseg]))] = (lo, hi)
                     hi = lo
                 if gout is None:
@@ -572,7 +581,10 @@ class Plan:
                         scratch=self.f32(groups * R), dw1=sg[0], db1=sg[1], dw2=sg[2], db2=sg[3],
                         bnsums=bnsums, bn_nblk=nblk, bn_stats=bn2.bstats, w2t=w2t)
             self.op(seg, "se_fc_bwd_data", _struct="mds_se_fc_bwd_args", **sekw)
-            self.op(seg, "se_fc_bwd_params", _struct="mds_se_fc_bwd_args", **sekw)     # parameter gradients: second stream
+            if self.se_table:           # parameter gradients: leaves - deferred to the end of the gradient bucket, one table launch (second stream)
+                self._se_pending.append(sekw)
+            else:
+                self.op(seg, "se_fc_bwd_params", _struct="mds_se_fc_bwd_args", **sekw)
             dy2 = self.act(Mout, mid)
             bn2.backward(self, seg, gsrc(G_SE, u2, gate=gate, dpooled=dpool, rpg=rpg), y2, dy2, reduce=False, frozen=frozen)
             g1 = self.act(Min, mid)
@@ -869,6 +881,14 @@ class Plan:
         for k, v in kw.items():
             if k in ("_struct", "_side"):
                 continue
+            if k == "_jobs":          # a device-resident array of bound mds_se_fc_bwd_args (mds_se_fc_bwd_table_args)
+                arr = (cabi.STRUCTS["mds_se_fc_bwd_args"] * len(v))()
+                for j, kwj in enumerate(v):
+                    arr[j] = self._bind("mds_se_fc_bwd_args", kwj)
+                tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+                self._keep.append(tab)
+                vals.update(jobs=tab, njobs=len(v), max_rc=max(kwj["R"] * kwj["C"] for kwj in v))
+                continue
             if isinstance(v, dict):
                 v = self._bind(v.get("_struct", "mds_pro_t"), v)
             elif isinstance(v, Lazy) and v.kind == "input":
@@ -892,7 +912,7 @@ class Plan:
 
     # (the stem's weight gradient stays on the dependent chain: it is its last launch, and the second stream still has the first
     #  3x3 layer's weight gradient to finish - 14.30 vs 14.35 ms per step)
-    SIDE_OPS = ("pw_wgrad", "conv_wgrad", "se_fc_bwd_params")
+    SIDE_OPS = ("pw_wgrad", "conv_wgrad", "se_fc_bwd_params", "se_fc_bwd_params_table")
     BUCKET_ELEMS = 1_500_000
 
     def _lo(self, *mods_or_params):

@@ -474,6 +474,14 @@ int mds_se_fc_bwd(const mds_se_fc_bwd_args* a, mds_stream_t stream);
  * `scratch` (a leaf of the dependency graph: the planner issues it on its second stream).            */
 int mds_se_fc_bwd_data(const mds_se_fc_bwd_args* a, mds_stream_t stream);
 int mds_se_fc_bwd_params(const mds_se_fc_bwd_args* a, mds_stream_t stream);
+/* `_params` of several layers in ONE launch: a device-resident array of mds_se_fc_bwd_args (grid.y = layer).  The planner defers the
+ * squeeze-excite parameter gradients of a gradient bucket and issues one table per bucket (20 launches per step -> <= 6).       */
+typedef struct {
+  const void* jobs;     /* device array of njobs mds_se_fc_bwd_args */
+  int njobs;
+  int max_rc;           /* max over the jobs of R * C */
+} mds_se_fc_bwd_table_args;
+int mds_se_fc_bwd_params_table(const mds_se_fc_bwd_table_args* a, mds_stream_t stream);
 
 /* ---- BatchNorm backward, split in reduce / finalize / apply.  g (grad wrt the BN output z) is
  * derived on the fly from an upstream tensor u:

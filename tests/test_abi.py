@@ -17,7 +17,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert lib.missing == []
     declared = {n for n, _ in cabi.FUNCS}
     assert {"mds_pw_fwd", "mds_conv_fwd", "mds_dw_bwd", "mds_gem_bwd", "mds_pack_weights"} <= declared
-    assert len(declared) == 39      # + mds_last_error (returns const char*); grows with include/mds.h, never silently
+    assert len(declared) == 40      # + mds_last_error (returns const char*); grows with include/mds.h, never silently
     assert lib.dll.mds_version() == cabi.MDS_VERSION
 
 

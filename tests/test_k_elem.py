@@ -134,6 +134,38 @@ def test_se_forward_backward(be, dt, packed, C, RD):
     assert_close(da, da_ref, dt, scale=3, msg="da")
 
 
+def test_se_parameter_gradients_table_equals_the_per_layer_launches(be):
+    """mds_se_fc_bwd_params_table (a device-resident array of layers, grid.y = layer: what the planner issues once per gradient
+    bucket) against one mds_se_fc_bwd_params launch per layer, on layers of different widths: bit-identical, accumulating (+=)"""
+    g = gen(77)
+    G = 5
+    SJ = cabi.STRUCTS["mds_se_fc_bwd_args"]
+    shapes = [(48, 12), (1152, 48), (328, 28)]
+    jobs, outs = [], []
+    for C, R in shapes:
+        dgate = be.t(torch.randn(G, C, generator=g).double()); gate = be.t(torch.rand(G, C, generator=g))
+        hidden = be.t(torch.randn(G, R, generator=g)); pooled = be.t(torch.randn(G, C, generator=g).double())
+        scratch = be.t(torch.randn(G, R, generator=g)); w1 = be.t(torch.randn(R, C, generator=g)); w2 = be.t(torch.randn(C, R, generator=g))
+        init = [torch.randn(R, C, generator=g), torch.randn(R, generator=g), torch.randn(C, R, generator=g), torch.randn(C, generator=g)]
+        two = []
+        for _ in range(2):
+            gr = [be.t(t.clone()) for t in init]
+            two.append((gr, cabi.make("mds_se_fc_bwd_args", groups=G, C=C, R=R, rows_per_group=70, dgate=dgate, gate=gate, hidden=hidden,
+                                      pooled=pooled, w1=w1, w2=w2, dpooled=torch.empty(G, C, device=be.device), scratch=scratch,
+                                      dw1=gr[0], db1=gr[1], dw2=gr[2], db2=gr[3])))
+        be.call("se_fc_bwd_params", two[0][1])
+        jobs.append(two[1][1]); outs.append((two[0][0], two[1][0]))
+    arr = (SJ * len(jobs))(*jobs)
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(be.device)
+    be.call("se_fc_bwd_params_table", cabi.make("mds_se_fc_bwd_table_args", jobs=tab, njobs=len(jobs), max_rc=max(C * R for C, R in shapes)))
+    be.sync()
+    for (C, R), (ref, got) in zip(shapes, outs):
+        for a_, b_, name in zip(ref, got, ("dw1", "db1", "dw2", "db2")):
+            assert torch.equal(a_.cpu(), b_.cpu()), (C, R, name)
+    with pytest.raises(Exception):
+        be.call("se_fc_bwd_params_table", cabi.make("mds_se_fc_bwd_table_args", jobs=tab, njobs=0, max_rc=1))
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("mode,C", [(0, 40), (1, 40), (2, 40), (3, 40), (1, 1152)])
 def test_bn_backward_chain(be, dt, mode, C):
