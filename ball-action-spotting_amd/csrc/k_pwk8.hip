@@ -454,14 +454,16 @@ int pw_fwd_k_try(const mds_pw_fwd_args* a, mds_stream_t stream) {
   if (!a->w_frag || a->epi.mode != MDS_EPI_NONE || a->split > 1) return 1;
   const int N = a->N, mode = a->pro.mode;
   const bool post = a->post.mode != MDS_POST_NONE;
-  const bool dg = post || a->residual != nullptr;
+  const bool dg = a->form ? a->form == 2 : (post || a->residual != nullptr);      // (the planner's own flag when it gave one)
+  if (!dg && (post || a->residual != nullptr)) return 1;                             // a forward launch with a fused residual / post sums: the general kernel
   if (!mds_pw_fwd_wants_frag(a->M, a->K, a->N, a->dtype, dg)) return 1;
   if (dg && (mode != MDS_PRO_NONE || a->stats)) return 1;
   // tile shapes: 192 columns = 4 waves x 3 fragments, 128 columns = 4 x 2, 96 columns = 2 x 3 with two wave rows.  Row count:
   // one block per CU (512 threads, ~200 VGPRs), so the launch runs in ceil(blocks / 256) rounds - the smallest rounds * BM wins
   // (18 400 rows: 80-row tiles, 230 blocks, one round; 73 600 rows: 96-row tiles, 767 blocks, three rounds)
   const int shape = N > 128 ? 0 : (N > 96 ? 1 : 2);
-  const int cus = 256;
+  static int cus = 0;      // one block per CU: the tile-height rule counts rounds of the chip
+  if (cus == 0) cus = mds_cu_count();
   auto cost = [&](int bm) { const long blocks = cdiv(a->M, bm); return (long)cdiv(blocks, cus) * bm; };
   int BM;
   if (shape == 2) BM = 96;

@@ -160,3 +160,10 @@ MDS_DEV void sreg_pin(f32x8& v) { asm volatile("" : "+s"(v)); }
 // p[idx] for a wave-uniform idx of a table no launch of the same stream is writing: through the scalar cache (s_load), i.e.
 // neither a vector register per lane nor an entry on vmcnt
 MDS_DEV float ld_uniform(const float* p, int idx) { return ((const __attribute__((address_space(4))) float*)(uintptr_t)p)[idx]; }
+
+// CUs of the current device (launch-shape rules that count rounds of the chip ask once)
+inline int mds_cu_count() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  return n;
+}

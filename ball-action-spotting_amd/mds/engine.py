@@ -403,7 +403,7 @@ class Plan:
                     stats=None, epi=dict(_struct="mds_epi_t", mode=epi_mode, scale=stats_bn.scale, shift=stats_bn.shift), **self._split(M, K, N_))
             return y
         self.op(seg, "pw_fwd", dtype=self.code, M=M, K=K, N=N_, x=x, w=w, y=y, pro=pro or dict(mode=0),
-                residual=residual, stats=stats_bn.stats if stats_bn is not None else None, w_frag=wfrag)
+                residual=residual, stats=stats_bn.stats if stats_bn is not None else None, w_frag=wfrag, form=1)
         if stats_bn is not None:
             stats_bn.finalize(self, seg)
         return y
@@ -481,7 +481,7 @@ class Plan:
             extra["post"] = head["bn"].post(head)
         if self.lib.fn["pw_fwd_wants_frag"](int(M), int(N_), int(K), int(self.code), 1):
             extra["w_frag"] = self.pack(wparam, cabi.MDS_PACK_FRAG_IO, N_, K, 1)
-        self.op(seg, "pw_fwd", dtype=self.code, M=M, K=N_, N=K, x=dy, w=wt, y=dx, pro=dict(mode=0), residual=residual, stats=None, **extra)
+        self.op(seg, "pw_fwd", dtype=self.code, M=M, K=N_, N=K, x=dy, w=wt, y=dx, pro=dict(mode=0), residual=residual, stats=None, form=2, **extra)
         return Grad(dx, head["bn"] if head is not None else None)
 
     def _ir_block_eval(self, fseg, blk, bn1, bn2, bn3, xin, N, T, IH, IW, OH, OW, pt, pl, stride, groups, has_skip, kt):

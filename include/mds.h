@@ -185,6 +185,8 @@ typedef struct {
   int split;
   float* split_part;    /* fp32 [split][M][N] scratch */
   int* split_ticket;    /* [tiles * MDS_PW_SPLIT_TICKET_STRIDE], tiles = ceil(M / MDS_PW_SPLIT_TILE_ROWS) * ceil(N / 128); zero before the first launch */
+  int form;             /* what the launch is, as the planner told mds_pw_fwd_wants_frag: 1 = forward, 2 = data gradient, 0 = not said
+                           (then: data gradient if it has post statistics or a residual operand) - the K-streaming kernel's rule differs */
 } mds_pw_fwd_args;
 int mds_pw_fwd(const mds_pw_fwd_args* a, mds_stream_t stream);
 int mds_pw_fwd_split(long M, int K, int N, int dtype);   /* recommended split-K factor (1 = none); <= MDS_PW_MAX_SPLIT */

@@ -258,4 +258,5 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v
 
 inline const char* hipGetErrorString(int) { return "hipemu"; }
 inline int hipGetLastError() { return 0; }
+inline int hipemu_cu_count() { return 256; }      // the simulated device: an MI355X's 256 CUs
 inline int hipPeekAtLastError() { return 0; }

@@ -99,3 +99,5 @@ MDS_DEV float ld_uniform(const float* p, int idx) { return p[idx]; }
 MDS_DEV f32x8 sld8(const float* p) { f32x8 v; for (int j = 0; j < 8; ++j) v[j] = p[j]; return v; }
 MDS_DEV void sreg_pin(f32x8&) {}
 MDS_DEV void gld16(u16x8& dst, const void* p) { memcpy(&dst, p, 16); }
+
+inline int mds_cu_count() { return hipemu_cu_count(); }
