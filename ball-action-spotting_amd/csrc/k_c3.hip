@@ -1416,6 +1416,7 @@ struct C3WArgs {
   int tapw[9];         // weight slot of tap (ky, kx)
   int nbands, nseg, rps, items;
   int RA, NR;
+  const float* pro_scale; const float* pro_shift;      // c3wp_kernel: the input is read through BatchNorm + SiLU
 };
 
 template <int NC> MDS_DEV int c3w_rot(int c, int p) {      // where 32-byte chunk c of pixel p sits inside the pixel: 8 consecutive pixels' chunk c tile all 64 banks
@@ -1628,6 +1629,285 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void c3w_kernel(C3WArgs g) {
   }
 }
 
+// The same for blocks.0.0 (32 -> 16 channels at 368 x 640, input = the stem's RAW output read through BatchNorm + SiLU): a single
+// 16-channel output fragment, so the four consumer waves split the 64-column band's two 32-pixel k-steps and the two 16-channel
+// input fragments instead (9 accumulators each, summed through LDS at the end), and NTW transform waves rewrite the input part of
+// every landed entry in place - silu(scale * v + shift), zero outside the image - one batch ahead of the consumers, which run one
+// barrier behind (as c3_kernel's NTW form; every role executes batches + 2 barriers).
+template <int NPW, int NTW>
+__global__ __launch_bounds__(64 * (4 + NPW + NTW)) void c3wp_kernel(C3WArgs g) {
+  constexpr int CIN = 32, PPX = 4, PPY = 2, WB = 64;
+  constexpr int XS = (WB + 2) * PPX, XSP = (XS + 63) / 64 * 64, YS = WB * PPY, RS = XSP + YS, PIECES = RS / 64, ROWB = RS * 16;
+  static_assert(YS % 64 == 0, "dy rows end on a piece boundary");
+  MDS_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int G = gridDim.x;
+  int E = 0;
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
+    E += im.r1 - im.r0 + 2;
+  }
+  if (wave >= 4 && wave < 4 + NPW) {
+    // ------------------------------------------------------------------ DMA waves (as c3w_kernel)
+    MDS_SETPRIO(3);
+    const int pw = wave - 4;
+    constexpr int PCWMAX = (PIECES + NPW - 1) / NPW;
+    const int pcw = (PIECES - pw + NPW - 1) / NPW;
+    int dcol[PCWMAX], eoff[PCWMAX];
+#pragma unroll
+    for (int j = 0; j < PCWMAX; ++j) {
+      const int sg_ = 64 * (pw + NPW * j) + lane;
+      if (sg_ < XS) {
+        const int p = sg_ / PPX, t = sg_ - p * PPX;
+        dcol[j] = p - 1; eoff[j] = 16 * c3w_unrot<2>(t >> 1, p) + 8 * (t & 1);
+      } else if (sg_ >= XSP && sg_ < RS) {
+        const int u = sg_ - XSP, p = u / PPY, t = u - p * PPY;
+        dcol[j] = p; eoff[j] = 8 * t;
+      } else {
+        dcol[j] = -(1 << 30); eoff[j] = 0;
+      }
+    }
+    const lds_t ring = lds_addr_of(smem);
+    int hit = blockIdx.x, hk = 0;
+    C3Item him = c3_item_h(g.nseg, g.nbands, g.rps, g.H, hit < g.items ? hit : 0, WB);
+    int C = 0, hslot = 0;
+    const char* cur[PCWMAX];
+    unsigned step[PCWMAX];
+    auto open_item = [&]() {
+      const char* xrow0 = (const char*)g.x + ((long)him.n * g.H + him.r0 - 1) * g.W * CIN * 2;
+      const char* yrow0 = (const char*)g.dy + ((long)him.n * g.H + him.r0 - 1) * g.W * g.Ctot * 2;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const bool isy = 64 * (pw + NPW * j) >= XSP;
+        const int gx = him.x0 + dcol[j];
+        const bool ok = gx >= 0 && gx < g.W;
+        cur[j] = ok ? (isy ? yrow0 : xrow0) + (gx * (isy ? g.Ctot : CIN) + eoff[j]) * 2 : (const char*)c3_zero_page;
+        step[j] = ok ? (unsigned)(g.W * (isy ? g.Ctot : CIN) * 2) : 0u;
+      }
+    };
+    open_item();
+    auto issue = [&]() {
+      const int ri = him.r0 - 1 + hk;
+      const bool xok = ri >= 0 && ri < g.H, yok = ri >= him.r0 && ri < him.r1;
+      const lds_t dst = ring + (lds_t)(hslot * ROWB);
+      hslot = hslot + 1 == g.NR ? 0 : hslot + 1;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const int pi = pw + NPW * j;
+        if (pi < PIECES) {
+          const bool isy = 64 * pi >= XSP;
+          const char* src = (isy ? yok : xok) ? cur[j] : (const char*)c3_zero_page;
+          if (dcol[j] > -(1 << 29)) glds16(src, dst + (lds_t)(pi * 1024));
+          cur[j] += step[j];
+        }
+      }
+      ++C;
+      if (++hk == him.r1 - him.r0 + 2) {
+        hk = 0; hit += G;
+        if (hit < g.items) { him = c3_item_h(g.nseg, g.nbands, g.rps, g.H, hit, WB); open_item(); }
+      }
+    };
+    while (C < g.RA && C < E) issue();
+    int e0 = 0;
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
+      const int K = im.r1 - im.r0 + 2;
+      for (int k0 = 0; k0 < K; k0 += 3) {
+        const int n = K - k0 < 3 ? K - k0 : 3;
+        wait_vm_dyn(pcw * (C - e0 - n));
+        raw_barrier();
+        e0 += n;
+        while (C < e0 + g.RA && C < E) issue();       // into slots of entries two batches back and older (ring: RA + 8)
+      }
+    }
+    raw_barrier();
+    raw_barrier();
+    return;
+  }
+  if (wave >= 4 + NPW) {
+    // ------------------------------------------------------------------ transform waves: half slots (four channels) of the input part
+    MDS_SETPRIO(3);
+    const int tw = wave - 4 - NPW;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // lane l of a piece: slot 32 pc + l / 2 = part (l / 2) % 4 of pixel 8 pc + l / 8; the 32-byte chunks of pixels 4 .. 7 of a piece
+    // are swapped (c3w_rot<2>): the channels a lane transforms are the same in every piece
+    const int tpart = (lane >> 1) & 3, ch0 = 16 * ((tpart >> 1) ^ ((lane >> 5) & 1)) + 8 * (tpart & 1) + 4 * (lane & 1);
+    f32x2 sc[2], sh[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      sc[c] = (f32x2){g.pro_scale[ch0 + 2 * c], g.pro_scale[ch0 + 2 * c + 1]};
+      sh[c] = (f32x2){g.pro_shift[ch0 + 2 * c], g.pro_shift[ch0 + 2 * c + 1]};
+    }
+    constexpr int NPC = (2 * XS + 63) / 64;
+    int rslot = 0;
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
+      const int K = im.r1 - im.r0 + 2;
+      for (int k0 = 0; k0 < K; k0 += 3) {
+        const int n = K - k0 < 3 ? K - k0 : 3;
+        asm volatile("" ::: "memory");
+        raw_barrier();
+        asm volatile("" ::: "memory");
+        constexpr int MAXP = (3 * NPC + NTW - 1) / NTW;
+        u16x4 v[MAXP];
+        char* ptr[MAXP];
+        int edge[MAXP];
+#pragma unroll
+        for (int qq = 0; qq < MAXP; ++qq) {
+          const int u = tw + qq * NTW;
+          edge[qq] = -1;
+          if (u < n * NPC) {
+            const int j = u / NPC, pc = u - j * NPC;
+            const int ri = im.r0 - 1 + k0 + j, px0 = im.x0 - 1 + 8 * pc;
+            int rs_ = rslot + j;
+            if (rs_ >= g.NR) rs_ -= g.NR;
+            const int h = 64 * pc + lane;
+            ptr[qq] = smem + rs_ * ROWB + (h < 2 * XS ? h : 0) * 8;
+            if (!(C3_ABL & 32)) v[qq] = *(const u16x4*)ptr[qq];
+            edge[qq] = (ri >= 0 && ri < g.H && px0 >= 0 && px0 + 8 <= g.W) ? 0 : 1;
+          }
+        }
+#pragma unroll
+        for (int qq = 0; qq < MAXP; ++qq) {
+          if (edge[qq] < 0 || (C3_ABL & 32)) continue;
+          if (C3_ABL & 16) { *(u16x4*)ptr[qq] = v[qq]; continue; }
+          const int u = tw + qq * NTW;
+          const int j = u / NPC, pc = u - j * NPC;
+          f32x2 z[2], e[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            z[c] = (f32x2){bf2f(v[qq][2 * c]), bf2f(v[qq][2 * c + 1])} * sc[c] + sh[c];
+            const f32x2 t = z[c] * -1.4426950408889634f;
+            e[c] = (f32x2){fast_exp2(t[0]), fast_exp2(t[1])} + 1.0f;
+            z[c] *= (f32x2){fast_rcp(e[c][0]), fast_rcp(e[c][1])};
+          }
+          if (edge[qq]) {
+            const int ri = im.r0 - 1 + k0 + j, gx = im.x0 - 1 + 8 * pc + (lane >> 3);
+            const float okf = (ri >= 0 && ri < g.H && gx >= 0 && gx < g.W) ? 1.f : 0.f;
+            z[0] *= okf; z[1] *= okf;
+          }
+          typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+          if (64 * pc + lane < 2 * XS) *(u32x2_*)ptr[qq] = (u32x2_){pack2(z[0][0], z[0][1]), pack2(z[1][0], z[1][1])};
+        }
+        rslot += n;
+        if (rslot >= g.NR) rslot -= g.NR;
+        wait_lgkm0();
+      }
+    }
+    raw_barrier();
+    raw_barrier();
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers: wave = (32-pixel k-step of the band, 16-channel input fragment)
+  MDS_SETPRIO(2);
+  const int i = lane & 15, q = lane >> 4;
+  const int chunk = wave >> 1, cf = wave & 1;
+  int xo[3][2], yo[2];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = kx + 32 * chunk + 4 * q + 16 * h + (i >> 2);
+      xo[kx][h] = p * PPX * 16 + c3w_rot<2>(cf, p) * 32 + 8 * (i & 3);
+    }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) yo[h] = XSP * 16 + (32 * chunk + 4 * q + 16 * h + (i >> 2)) * PPY * 16 + 8 * (i & 3);
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int sp = 0, sc_ = 0, sn = g.NR > 1 ? 1 : 0;
+  raw_barrier();                                      // one barrier behind the ring: batch j is consumed after barrier j + 1
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
+    const int K = im.r1 - im.r0 + 2;
+    for (int k0 = 0; k0 < K; k0 += 3) {
+      const int n = K - k0 < 3 ? K - k0 : 3;
+      asm volatile("" ::: "memory");
+      raw_barrier();                                  // batch k0's input rows are transformed; the entry after it has landed
+      asm volatile("" ::: "memory");
+      for (int k = k0; k < k0 + n; ++k) {
+        if (C3_ABL & 1024) continue;
+        const char* const er = smem + sc_ * ROWB;
+        u16x8 af[3], bf[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const u16x4 lo = lds_tr4((const bf16_t*)(er + xo[kx][0])), hi = lds_tr4((const bf16_t*)(er + xo[kx][1]));
+          af[kx] = (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          if ((ky == 0 && k == K - 1) || (ky == 2 && k == 0)) continue;
+          const char* const yr = smem + (ky == 0 ? sn : (ky == 1 ? sc_ : sp)) * ROWB;
+          const u16x4 lo = lds_tr4((const bf16_t*)(yr + yo[0])), hi = lds_tr4((const bf16_t*)(yr + yo[1]));
+          bf[ky] = (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          if ((ky == 0 && k == K - 1) || (ky == 2 && k == 0)) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            if (C3_ABL & 512) acc[3 * ky + kx][0] += bf2f(bf[ky][0]) + bf2f(af[kx][1]);
+            else mma16(bf[ky], af[kx], acc[3 * ky + kx]);      // acc[r] = dw[co = 4 q + r][ci = 16 cf + i]
+          }
+        }
+        sp = sc_; sc_ = sn; sn = sn + 1 == g.NR ? 0 : sn + 1;
+      }
+    }
+  }
+  asm volatile("" ::: "memory");
+  raw_barrier();                                      // (the other roles' last barrier) the ring becomes the staging area
+  asm volatile("" ::: "memory");
+  constexpr int SLAB = CIN * 9;
+  float* const fl = (float*)smem;                     // [16 output channels][CIN][9]: the four waves' sums meet here
+  for (int e = tid; e < 16 * SLAB; e += 256) fl[e] = 0.f;
+  wait_lgkm0();
+  raw_barrier();
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&fl[(4 * q + r) * SLAB + (16 * cf + i) * 9 + g.tapw[t]], acc[t][r]);
+  wait_lgkm0();
+  raw_barrier();
+  const int e0 = (int)((blockIdx.x * 37u) % (16 * SLAB / 256)) * 256;
+  for (int e = tid; e < 16 * SLAB; e += 256) { const int ee = e + e0 < 16 * SLAB ? e + e0 : e + e0 - 16 * SLAB; atomicAdd(g.dw + ee, fl[ee]); }
+}
+
+template <int NPW, int NTW>
+static int c3wp_launch(const mds_conv_wgrad_args* a, const int (&tapw)[9], mds_stream_t stream) {
+  constexpr int PPX = 4, PPY = 2, WB = 64;
+  constexpr int XS = (WB + 2) * PPX, XSP = (XS + 63) / 64 * 64, RS = XSP + WB * PPY, PIECES = RS / 64, ROWB = RS * 16;
+  C3WArgs g;
+  g.x = (const bf16_t*)a->x; g.dy = (const bf16_t*)a->dyt; g.dw = a->dw;
+  g.N = a->N; g.H = a->IH; g.W = a->IW; g.Ctot = a->Cout; g.wtaps = a->wtaps;
+  g.pro_scale = a->pro.scale; g.pro_shift = a->pro.shift;
+  for (int t = 0; t < 9; ++t) g.tapw[t] = tapw[t];
+  const int pcw = (PIECES + NPW - 1) / NPW;
+  int RA = (100 * 1024 + ROWB - 1) / ROWB;      // rows in flight: the ring is the whole LDS (a batch dips it by three rows)
+  while (RA > 3 && pcw * (RA - 1) > 40) --RA;
+  int NR = RA + 8;
+  const size_t lds_cap = 158 * 1024;
+  while ((size_t)NR * ROWB > lds_cap && RA > 3) { --RA; NR = RA + 8; }
+  if ((size_t)NR * ROWB > lds_cap || pcw * (RA - 1) > 40) return 0;
+  g.RA = RA; g.NR = NR;
+  int CUS = 256;
+  if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);
+  g.nbands = cdiv(a->IW, WB);
+  long best = -1;
+  for (int ns = 1; ns <= 64 && ns <= a->IH; ++ns) {
+    const int rps = cdiv(a->IH, ns), nsr = cdiv(a->IH, rps);
+    const long items = (long)a->N * g.nbands * nsr;
+    const long per = (items + CUS - 1) / CUS;
+    const long cost = per * (rps + 2 + 2);
+    if (best < 0 || cost < best) { best = cost; g.nseg = nsr; g.rps = rps; g.items = (int)items; }
+  }
+  const int grid = g.items < CUS ? g.items : CUS;
+  size_t smem = (size_t)NR * ROWB;
+  if (smem < (size_t)16 * 32 * 9 * 4) smem = (size_t)16 * 32 * 9 * 4;
+  MDS_LAUNCH((c3wp_kernel<NPW, NTW>), dim3(grid), dim3(64 * (4 + NPW + NTW)), smem, stream, g);
+  return 1;
+}
+
 template <int CIN, int COW, int NCW, int NPW>
 static int c3w_launch(const mds_conv_wgrad_args* a, const int (&tapw)[9], mds_stream_t stream) {
   constexpr int COP = 16 * COW * NCW, PPX = CIN / 8, PPY = COP / 8, WB = 32;
@@ -1635,7 +1915,7 @@ static int c3w_launch(const mds_conv_wgrad_args* a, const int (&tapw)[9], mds_st
   if (a->Cout % COP) return 0;
   C3WArgs g;
   g.x = (const bf16_t*)a->x; g.dy = (const bf16_t*)a->dyt; g.dw = a->dw;
-  g.N = a->N; g.H = a->IH; g.W = a->IW; g.Ctot = a->Cout; g.wtaps = a->wtaps;
+  g.N = a->N; g.H = a->IH; g.W = a->IW; g.Ctot = a->Cout; g.wtaps = a->wtaps; g.pro_scale = nullptr; g.pro_shift = nullptr;
   for (int t = 0; t < 9; ++t) g.tapw[t] = tapw[t];
   const int passes = a->Cout / COP;
   const int pcw = (PIECES + NPW - 1) / NPW;
@@ -1671,7 +1951,9 @@ static int c3w_launch(const mds_conv_wgrad_args* a, const int (&tapw)[9], mds_st
 // mds_conv_wgrad's large prologue-free stride-1 bf16 launches; 1 = launched, 0 = not one of these (k_conv.hip's kernel)
 int c3w_try(const mds_conv_wgrad_args* a, mds_stream_t stream) {
   if (mds_knob(MDS_KNOB_C3) == 1 || (mds_knob(MDS_KNOB_C3_DBG) & 128)) return 0;
-  if (a->dtype != MDS_BF16 || a->is != 1 || a->ntaps != 9 || a->wtaps != 9 || a->pro.mode != MDS_PRO_NONE) return 0;
+  const bool pro = a->pro.mode == MDS_PRO_BN_SILU;
+  if (a->dtype != MDS_BF16 || a->is != 1 || a->ntaps != 9 || a->wtaps != 9 || (a->pro.mode != MDS_PRO_NONE && !pro)) return 0;
+  if (pro && !(a->Cin == 32 && a->Cout == 16 && a->pro.scale && a->pro.shift && !(mds_knob(MDS_KNOB_C3_DBG) & 256))) return 0;
   if (a->OH != a->IH || a->OW != a->IW) return 0;
   if ((long)a->IH * a->IW * a->Cout >= (1L << 30)) return 0;
   int tapw[9];
@@ -1682,6 +1964,7 @@ int c3w_try(const mds_conv_wgrad_args* a, mds_stream_t stream) {
   }
   for (int t = 0; t < 9; ++t) if (tapw[t] < 0 || tapw[t] >= 9) return 0;
   if ((long)a->N * a->IH * a->IW < 16384 && mds_knob(MDS_KNOB_C3) != 2) return 0;
+  if (pro) return c3wp_launch<3, 8>(a, tapw, stream);      // blocks.0.0: behind the stem's BatchNorm + SiLU
   if (a->Cin == 32 && a->Cout == 128) return c3w_launch<32, 1, 8, 3>(a, tapw, stream);      // blocks.1.1: eight consumer waves of one 16-channel fragment each
   if (a->Cin == 48 && a->Cout == 192) return c3w_launch<48, 1, 6, 2>(a, tapw, stream);      // blocks.2.1: two passes of 96 channels, six consumer waves
   return 0;

@@ -130,8 +130,13 @@ def cpu_baseline(max_seconds=20.0, frames=15, frozen=False):
 def kernel_family(name):
     """'void dw2_bwd_kernel<unsigned short, 4>(...)' -> 'dw_bwd' ; variants of one entry point share a key"""
     fn = name.replace("void ", "").split("<")[0].split("(")[0]
-    if fn in ("c3_kernel", "c3t_kernel"):      # k_c3.hip serves mds_conv_fwd launches and (its one-tap form: last template argument) a few of mds_pw_fwd's
-        return "pw_fwd" if fn == "c3_kernel" and re.search(r",\s*true\s*>\s*\(", name) else "conv_fwd"
+    if fn in ("c3_kernel", "c3t_kernel", "c3s_kernel"):      # k_c3.hip serves mds_conv_fwd launches and (its one-tap form: template argument ONE, the 11th) a few of mds_pw_fwd's
+        targs = [t.strip() for t in name.split("<", 1)[1].split(">")[0].split(",")] if "<" in name else []
+        return "pw_fwd" if fn == "c3_kernel" and len(targs) > 10 and targs[10] == "true" else "conv_fwd"
+    if fn == "c3w_kernel":                     # ... and mds_conv_wgrad's stride-1 launches
+        return "conv_wgrad"
+    if fn == "se_bwd_b_table_kernel":          # the table form of se_bwd_b_kernel (one launch per gradient bucket)
+        return "se_bwd_b"
     fn = re.sub(r"\d", "", fn)
     for v in ("_tr_kernel", "_p_kernel", "_tiled_kernel", "_wres_kernel", "_q_kernel", "_kernel"):
         if fn.endswith(v):

@@ -421,6 +421,19 @@ def test_c3w_weight_gradient_row_streaming(be, N, H, W, Cin, Cout, blocks):
         be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
 
 
+@pytest.mark.parametrize("N,H,W,blocks", [(2, 9, 128, 0), (1, 20, 70, 2), (1, 3, 64, 1), (1, 14, 200, 3)])
+def test_c3w_weight_gradient_behind_the_prologue(be, N, H, W, blocks):
+    """blocks.0.0's weight gradient (32 -> 16, input = the stem's raw output through BatchNorm + SiLU): transform waves on the input part
+    of the ring entries, consumers one barrier behind, pixel-split consumer waves summed through LDS; zero padding after the activation"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        test_conv_wgrad(be, "bf16", N, H, W, 32, 16, 1, 2)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+
+
 def _rand_cases(n, seed):
     import random
     r = random.Random(seed)
