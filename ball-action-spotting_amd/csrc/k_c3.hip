@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256 + 64 * (NPW + NSW + NTW)) void c3_kernel(C3Args
   }
   if (wave >= 4 + NPW + NSW) {
     // ------------------------------------------------------------------ transform waves (NTW > 0)
-    MDS_SETPRIO(3);       // the transform is this form's critical stage
+    MDS_SETPRIO(1);       // below the consumers (prio 2): their short read - MFMA bursts must not queue behind two transform waves per SIMD
     const int tw = wave - 4 - NPW - NSW;
     // The unit of work is HALF a 16-byte slot (four channels): a row's 2 RPX half slots make NPC pieces of 64, dealt round the
     // transform waves row by row - finer pieces balance the four SIMDs' VALU queues (the stage is bound by v_exp / v_rcp issue:
@@ -1726,7 +1726,7 @@ __global__ __launch_bounds__(64 * (4 + NPW + NTW)) void c3wp_kernel(C3WArgs g) {
   }
   if (wave >= 4 + NPW) {
     // ------------------------------------------------------------------ transform waves: half slots (four channels) of the input part
-    MDS_SETPRIO(3);
+    MDS_SETPRIO(0);       // below the consumers: their short read - MFMA bursts must not queue behind two waves of v_exp / v_rcp per SIMD
     const int tw = wave - 4 - NPW;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // lane l of a piece: slot 32 pc + l / 2 = part (l / 2) % 4 of pixel 8 pc + l / 8; the 32-byte chunks of pixels 4 .. 7 of a piece
@@ -1800,7 +1800,7 @@ __global__ __launch_bounds__(64 * (4 + NPW + NTW)) void c3wp_kernel(C3WArgs g) {
   }
 
   // -------------------------------------------------------------------- consumers: wave = (32-pixel k-step of the band, 16-channel input fragment)
-  MDS_SETPRIO(2);
+  MDS_SETPRIO(3);
   const int i = lane & 15, q = lane >> 4;
   const int chunk = wave >> 1, cf = wave & 1;
   int xo[3][2], yo[2];
