@@ -2171,8 +2171,12 @@ static int c3s_launch(const mds_conv_fwd_args* a, const int (&tapw)[9], mds_stre
   dim3 block(256 + 64 * (NPW + NSW + NTW));
   const bool masked = a->OW % WB != 0, stats = a->stats != nullptr;
 #define C3S_GO(S, M) MDS_LAUNCH((c3s_kernel<CIN, NF, NSPL, SPW, NPW, NSW, S, M, NTW>), dim3(grid, passes), block, smem, stream, g)
-  if (stats) { if (masked) C3S_GO(true, true); else C3S_GO(true, false); }
-  else { if (masked) C3S_GO(false, true); else C3S_GO(false, false); }
+  if (masked) {
+    // (the transform-wave form runs three waves per SIMD - 168 VGPRs - and its column-masked statistics variant spills 34 of them: the
+    //  network's widths are whole bands, ragged widths behind a prologue stay with k_conv.hip)
+    if constexpr (NTW == 0) { if (stats) C3S_GO(true, true); else C3S_GO(false, true); }
+    else return 0;
+  } else { if (stats) C3S_GO(true, false); else C3S_GO(false, false); }
 #undef C3S_GO
   return 1;
 }

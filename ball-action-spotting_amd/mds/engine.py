@@ -368,7 +368,7 @@ class Plan:
             hi, lo, executed = self.grad_arena.numel, self.grad_arena.numel, []
             def flush_se(bseg):     # the deferred squeeze-excite parameter gradients of the closures issued so far: one launch
                 if self._se_pending:
-                    self.op(bseg, "se_fc_bwd_params_table", _struct="mds_se_fc_bwd_table_args", _jobs=self._se_pending)
+                    self.op(bseg, "se_fc_bwd_params_table", _struct="mds_se_fc_bwd_table_args", _jobs=[kw for _, kw in self._se_pending])
                     self._se_pending = []
             for i, (rec, bseg) in enumerate(chain):
                 nxt = chain[i + 1][0] if i + 1 < len(chain) else None
@@ -582,7 +582,7 @@ class Plan:
                         bnsums=bnsums, bn_nblk=nblk, bn_stats=bn2.bstats, w2t=w2t)
             self.op(seg, "se_fc_bwd_data", _struct="mds_se_fc_bwd_args", **sekw)
             if self.se_table:           # parameter gradients: leaves - deferred to the end of the gradient bucket, one table launch (second stream)
-                self._se_pending.append(sekw)
+                self._se_pending.append((seg, sekw))
             else:
                 self.op(seg, "se_fc_bwd_params", _struct="mds_se_fc_bwd_args", **sekw)
             dy2 = self.act(Mout, mid)
@@ -814,6 +814,11 @@ class Plan:
     # ------------------------------------------------------------------ binding
     def _finalize(self):
         dev = self.device
+        # deferred squeeze-excite parameter gradients that no gradient-bucket cut flushed (a builder that called a block's backward
+        # closure on its own): they close the segment they were recorded in
+        for seg in dict.fromkeys(sg for sg, _ in self._se_pending):
+            self.op(seg, "se_fc_bwd_params_table", _struct="mds_se_fc_bwd_table_args", _jobs=[kw for sg, kw in self._se_pending if sg == seg])
+        self._se_pending = []
         self.zf_arena.numel, self.zb_arena.numel, self.mask_arena.numel, self.zb64_arena.numel = self._zf, self._zb, self._mask_total, self._zb64
         self.zf64_arena.numel = self._zf64
         self.mask_arena.tensor = torch.zeros(max(self.mask_arena.numel, 1), dtype=torch.float32, device=dev)
