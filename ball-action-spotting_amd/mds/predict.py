@@ -71,14 +71,58 @@ class StreamPredictor:
         # back to 28 frames behind their first frame): ring > lanes * chunk + 27, lanes * chunk <= MAX_IN_FLIGHT.  Same for the
         # feature store (one slot per stack END index, modulo): a lane's encoder pass runs at most lanes + 1 steps ahead of
         # another lane's tail pass, which reads 24 frames back.
-        self.nframes = 2 * self._predict_offset + 1 + self.MAX_IN_FLIGHT + 8
-        self.nfeat = (self.S - 1) * self.span + self.MAX_IN_FLIGHT + 2 * self.max_chunk + 8
+        # The rings start at what predict() / predict_batch need (one chunk in flight on one stream) and GROW on the first
+        # predict_stream call that asks for more frames in flight (every predictor paid 128 frames' worth - 0.3 GB).
+        self.in_flight = self.max_chunk
+        self._size_rings()
         self.use_graphs = use_graphs
         self._built = None
         self.encoder_passes = 0          # 2D-encoder passes issued so far (steady state: one per chunk)
         self.lanes_in_use = 1            # lanes of the last predict_stream (what the device gave: see _lane_streams)
         self._pipe = None                # predict_stream: the streams / lane of the step being issued
         self.reset_buffers()
+
+    def _size_rings(self):
+        self.nframes = 2 * self._predict_offset + 1 + self.in_flight + 8
+        self.nfeat = (self.S - 1) * self.span + self.in_flight + 2 * self.max_chunk + 8
+
+    def _grow_rings(self, in_flight: int):
+        """rings for `in_flight` frames of predict_stream steps in flight: larger rings, every tagged frame / stack moved to its
+        slot in them (slot = index modulo the ring length), the cached copy argument blocks dropped (they hold slots and pointers)"""
+        in_flight = min(self.MAX_IN_FLIGHT, int(in_flight))
+        if in_flight <= self.in_flight:
+            return
+        old_ft, old_st = self.frame_tag, self.feat_tag
+        self.in_flight = in_flight
+        self._size_rings()
+
+        def remap(tags, n_new, key):
+            best = {}                                   # new slot -> (index, old slot); the newer index wins a collision
+            for slot, tag in enumerate(tags):
+                if tag is not None:
+                    k = key(tag)
+                    if k % n_new not in best or best[k % n_new][0] < k:
+                        best[k % n_new] = (k, slot)
+            new_tags = [None] * n_new
+            for ns, (_, os_) in best.items():
+                new_tags[ns] = tags[os_]
+            return new_tags, [ns for ns in best], [best[ns][1] for ns in best]
+
+        self.frame_tag, fdst, fsrc = remap(old_ft, self.nframes, lambda i: i)
+        self.feat_tag, sdst, ssrc = remap(old_st, self.nfeat, lambda st: st[-1])
+        if self._built is not None:
+            dev = self.frames.device
+            new = torch.zeros((self.nframes,) + tuple(self.frames.shape[1:]), dtype=torch.uint8, device=dev)
+            if fdst:
+                new[torch.tensor(fdst, device=dev)] = self.frames[torch.tensor(fsrc, device=dev)]
+            self.frames = new
+            if self.store is not None:
+                new = torch.zeros((self.nfeat,) + tuple(self.store.shape[1:]), dtype=self.store.dtype, device=dev)
+                if sdst:
+                    new[torch.tensor(sdst, device=dev)] = self.store[torch.tensor(ssrc, device=dev)]
+                self.store = new
+            for c in self.plans.values():
+                c["cache"] = {}
 
     def close(self):
         """hand the launch plans back to the module's cache (they stay pinned while the predictor lives)"""
@@ -229,9 +273,15 @@ class StreamPredictor:
         n = frames.shape[0]
         with torch.cuda.device(dev) if dev.type == "cuda" else _Null():
             results, ready = [], []
+            # steps still in flight on other lanes read back to 2 * offset frames behind their first frame: a slot written now
+            # must not hold a frame that young (the rings are sized for it - _size_rings; this is the check)
+            oldest_live = first_index - (self.in_flight if self._pipe is not None else 0) - 2 * self._predict_offset
             for j in range(n):
                 index = first_index + j
                 slot = index % self.nframes
+                prev = self.frame_tag[slot]
+                assert prev is None or prev == index or prev < oldest_live or prev > index, \
+                    f"frame ring too short: slot {slot} still holds frame {prev} while frame {index} arrives ({self.nframes} slots)"
                 self.frame_tag[slot] = index
                 results.append((None, index - self._predict_offset))
             # ring update (n <= ring length; the frames of one chunk land in distinct slots)
@@ -359,6 +409,7 @@ class StreamPredictor:
             lanes = min(lanes, len(enc))
             self.lanes_in_use = lanes          # (what bench.py prints beside the rate)
             cur = torch.cuda.current_stream(dev)
+            self._grow_rings(lanes * int(chunk))      # (on the caller's stream, before the lanes are ordered behind it)
             for st in self._streams:              # whatever the caller queued so far (weights, earlier predict calls) comes first
                 st.wait_stream(cur)
             pending, idx, step, last_ring, stack_ev = [], first_index, 0, None, {}

@@ -203,6 +203,41 @@ def test_chunked_prediction_encodes_every_stack_once(be):
     assert passes[4] <= 2, passes
 
 
+def test_rings_start_small_and_grow_without_losing_the_window(be):
+    """the frame ring / feature store are sized for one chunk in flight and grow when predict_stream asks for more
+    (lanes x chunk): growing in the middle of a stream must keep every cached frame and stack - the same predictions as a
+    predictor that never grew, with no extra encoder pass - and the WAR check of the ring update stays quiet"""
+    kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
+    prod = fill_deterministic(mds.MultiDimStacker(**kw), 5, scale=0.02).to(be.device)
+    if be.name == "emu":
+        prod._lib = be.lib
+    g = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 256, (44, 32, 64), generator=g, dtype=torch.uint8)
+    a = StreamPredictor(prod, frame_size=(64, 32), use_graphs=False)
+    b = StreamPredictor(prod, frame_size=(64, 32), use_graphs=False)
+    assert a.in_flight == a.max_chunk and a.nframes < 2 * a.predict_offset + 1 + StreamPredictor.MAX_IN_FLIGHT
+    small = (a.nframes, a.nfeat)
+    outs_a, outs_b = [], []
+    for first in range(0, 44, 4):
+        if first == 36:
+            a._grow_rings(96)                      # what predict_stream(chunk=32, lanes=3) would ask for
+            assert a.nframes > small[0] and a.nfeat > small[1] and a.in_flight == 96
+            before = a.encoder_passes
+        outs_a += a.predict_batch(frames[first:first + 4], first)
+        outs_b += b.predict_batch(frames[first:first + 4], first)
+    assert a.encoder_passes - before == 2 and a.encoder_passes == b.encoder_passes      # one pass per chunk: nothing was re-encoded
+    assert (b.nframes, b.nfeat) == small
+    n_pred = 0
+    for (pa, ia), (pb, ib) in zip(outs_a, outs_b):
+        assert ia == ib and (pa is None) == (pb is None)
+        if pa is not None:
+            n_pred += 1
+            assert torch.equal(pa.cpu(), pb.cpu())
+    assert n_pred >= 12
+    a._grow_rings(8)                               # never shrinks
+    assert a.in_flight == 96
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tta", [False, True])
 def test_stream_predictor_at_the_real_frame_size(tta):
