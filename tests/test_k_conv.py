@@ -435,6 +435,57 @@ def test_c3w_weight_gradient_behind_the_prologue(be, N, H, W, blocks):
         be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
 
 
+TRAIN_LAYERS = [  # the 3x3 layers of the benchmarked step (20 images): H, W, Cin, Cout, stride, prologue
+    (368, 640, 32, 16, 1, 2),       # blocks.0.0 (behind the stem's BatchNorm + SiLU)
+    (368, 640, 16, 64, 2, 2),       # blocks.1.0 first convolution (behind blocks.0.0's)
+    (184, 320, 32, 128, 1, 0),      # blocks.1.1
+    (184, 320, 32, 128, 2, 0),      # blocks.2.0
+    (92, 160, 48, 192, 1, 0),       # blocks.2.1
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,Cin,Cout,stride,mode", TRAIN_LAYERS)
+def test_k_c3_at_the_training_sizes_against_k_conv(be_gpu, H, W, Cin, Cout, stride, mode):
+    """BASELINE config 2's own layer sizes (the sizes the row-streaming kernels are dispatched at without a knob): forward output +
+    forward statistics and the weight gradient from k_c3.hip against k_conv.hip's kernels (MDS_KNOB_C3 = 1) on the same tensors.
+    Both are bf16 MFMA paths with fp32 accumulation: outputs agree to bf16 rounding, sums to their fp32 partial-sum order."""
+    be, N = be_gpu, 20
+    code, tdt = DT["bf16"]
+    g = torch.Generator(device=be.device).manual_seed(H + Cin + stride)
+    x = torch.randn(N, H, W, Cin, device=be.device, generator=g).to(tdt)
+    w = (torch.randn(Cout, Cin, 3, 3, device=be.device, generator=g) / (9 * Cin) ** 0.5).to(tdt)
+    scale = 1 + 0.2 * torch.randn(Cin, device=be.device, generator=g); shift = 0.3 * torch.randn(Cin, device=be.device, generator=g)
+    OH, OW, pt, pl = geo.conv_geometry(H, W, stride)
+    dyt = torch.randn(N, OH, OW, Cout, device=be.device, generator=g).to(tdt)
+    dy, dx, wi = geo.taps_fwd(pt, pl)
+    wp = be.t(pack(w.cpu(), "oi", tdt))
+    out = {}
+    for knob in (0, 1):
+        be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, knob), "dev_set")
+        try:
+            y = torch.full((N, OH, OW, Cout), float("nan"), device=be.device).to(tdt)
+            st = torch.zeros(cabi.MDS_STAT_SLOTS, 2, Cout, device=be.device, dtype=torch.float64)
+            be.call("conv_fwd", cabi.make("mds_conv_fwd_args", dtype=code, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout, A=OH, B=OW,
+                                          oy0=0, ox0=0, os=1, **{"is": stride}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9, x=x, w=wp, y=y,
+                                          pro=cabi.pro(mode, scale, shift), residual=None, stats=st))
+            dw = torch.zeros(Cout, Cin, 3, 3, device=be.device)
+            be.call("conv_wgrad", cabi.make("mds_conv_wgrad_args", dtype=code, N=N, IH=H, IW=W, Cin=Cin, OH=OH, OW=OW, Cout=Cout,
+                                            **{"is": stride}, ntaps=9, dy=dy, dx=dx, wi=wi, wtaps=9, x=x, dyt=dyt, dw=dw,
+                                            pro=cabi.pro(mode, scale, shift)))
+            be.sync()
+            out[knob] = (y, st.sum(0), dw)
+        finally:
+            be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+    (y0, s0, w0), (y1, s1, w1) = out[0], out[1]
+    assert not torch.isnan(y0.float()).any()
+    assert_close(y0, y1, "bf16", msg="y")
+    cnt = N * OH * OW
+    assert_close(s0[0], s1[0], "bf16", scale=cnt ** 0.5, msg="sum")
+    assert_close(s0[1], s1[1], "bf16", scale=cnt ** 0.5, msg="sumsq")
+    assert_close(w0, w1, "bf16", scale=cnt ** 0.5, msg="dw")
+
+
 def _rand_cases(n, seed):
     import random
     r = random.Random(seed)
