@@ -38,7 +38,7 @@ from mds import train as mtrain  # noqa: E402
 
 CHAIN_FAMILIES = ["bn_bwd_apply", "pw_fwd", "conv_fwd", "dw_bwd", "dw_fwd", "bn_bwd_reduce", "se_bwd_reduce", "bn_res", "se_pool",
                   "bn_finalize", "bn_bwd_finalize", "se_fc_fwd", "se_fc_bwd_data", "stem_fwd", "stem_wgrad"]
-SIDE_FAMILIES = ["pw_wgrad", "conv_wgrad", "se_fc_bwd_params"]
+SIDE_FAMILIES = ["pw_wgrad", "conv_wgrad", "se_fc_bwd_params", "se_fc_bwd_params_table"]
 
 
 def family_us(path):
@@ -46,9 +46,9 @@ def family_us(path):
     fam = {}
     if not path or not os.path.exists(path):
         return fam
-    pats = [("pw_wgrad", r"pw_wgrad"), ("conv_wgrad", r"conv_wgrad"), ("se_fc_bwd_params", r"se_bwd_b_kernel"), ("se_fc_bwd_data", r"se_bwd_a_kernel"),
+    pats = [("pw_wgrad", r"pw_wgrad"), ("conv_wgrad", r"conv_wgrad|c3wp?_kernel"), ("se_fc_bwd_params_table", r"se_bwd_b_table_kernel"), ("se_fc_bwd_params", r"se_bwd_b_kernel"), ("se_fc_bwd_data", r"se_bwd_a_kernel"),
             ("bn_bwd_apply", r"bn_bwd_apply"), ("bn_bwd_reduce", r"bn_bwd_reduce"), ("bn_bwd_finalize", r"bn_bwd_finalize"), ("bn_finalize", r"bn_finalize"),
-            ("pw_fwd", r"pw_fwd|pwk"), ("conv_fwd", r"conv_fwd"), ("dw_bwd", r"dw\w*_bwd"), ("dw_fwd", r"dw\w*_fwd"),
+            ("pw_fwd", r"pw_fwd|pwk"), ("conv_fwd", r"conv_fwd|c3[st]?_kernel"), ("dw_bwd", r"dw\w*_bwd"), ("dw_fwd", r"dw\w*_fwd"),
             ("se_bwd_reduce", r"se_bwd_reduce"), ("bn_res", r"bn_res"), ("se_pool", r"se_pool"), ("se_fc_fwd", r"se_fc_fwd|se_fwd"),
             ("stem_fwd", r"stem_fwd"), ("stem_wgrad", r"stem_wgrad")]
     for r in csv.DictReader(open(path)):
