@@ -1634,9 +1634,12 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void c3w_kernel(C3WArgs g) {
 // input fragments instead (9 accumulators each, summed through LDS at the end), and NTW transform waves rewrite the input part of
 // every landed entry in place - silu(scale * v + shift), zero outside the image - one batch ahead of the consumers, which run one
 // barrier behind (as c3_kernel's NTW form; every role executes batches + 2 barriers).
+#ifndef C3WP_BATCH
+#define C3WP_BATCH 3      /* (6 measured the same: 166 vs 168 us - the barrier rate is not what keeps the three stages from overlapping) */
+#endif
 template <int NPW, int NTW>
 __global__ __launch_bounds__(64 * (4 + NPW + NTW)) void c3wp_kernel(C3WArgs g) {
-  constexpr int CIN = 32, PPX = 4, PPY = 2, WB = 64;
+  constexpr int CIN = 32, PPX = 4, PPY = 2, WB = 64, BT = C3WP_BATCH;      // BT ring entries per barrier
   constexpr int XS = (WB + 2) * PPX, XSP = (XS + 63) / 64 * 64, YS = WB * PPY, RS = XSP + YS, PIECES = RS / 64, ROWB = RS * 16;
   static_assert(YS % 64 == 0, "dy rows end on a piece boundary");
   MDS_DYN_SMEM(smem);
@@ -1712,8 +1715,8 @@ __global__ __launch_bounds__(64 * (4 + NPW + NTW)) void c3wp_kernel(C3WArgs g) {
     for (int it = blockIdx.x; it < g.items; it += G) {
       const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
       const int K = im.r1 - im.r0 + 2;
-      for (int k0 = 0; k0 < K; k0 += 3) {
-        const int n = K - k0 < 3 ? K - k0 : 3;
+      for (int k0 = 0; k0 < K; k0 += BT) {
+        const int n = K - k0 < BT ? K - k0 : BT;
         wait_vm_dyn(pcw * (C - e0 - n));
         raw_barrier();
         e0 += n;
@@ -1743,12 +1746,12 @@ __global__ __launch_bounds__(64 * (4 + NPW + NTW)) void c3wp_kernel(C3WArgs g) {
     for (int it = blockIdx.x; it < g.items; it += G) {
       const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
       const int K = im.r1 - im.r0 + 2;
-      for (int k0 = 0; k0 < K; k0 += 3) {
-        const int n = K - k0 < 3 ? K - k0 : 3;
+      for (int k0 = 0; k0 < K; k0 += BT) {
+        const int n = K - k0 < BT ? K - k0 : BT;
         asm volatile("" ::: "memory");
         raw_barrier();
         asm volatile("" ::: "memory");
-        constexpr int MAXP = (3 * NPC + NTW - 1) / NTW;
+        constexpr int MAXP = (BT * NPC + NTW - 1) / NTW;
         u16x4 v[MAXP];
         char* ptr[MAXP];
         int edge[MAXP];
@@ -1821,8 +1824,8 @@ __global__ __launch_bounds__(64 * (4 + NPW + NTW)) void c3wp_kernel(C3WArgs g) {
   for (int it = blockIdx.x; it < g.items; it += G) {
     const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, g.H, it, WB);
     const int K = im.r1 - im.r0 + 2;
-    for (int k0 = 0; k0 < K; k0 += 3) {
-      const int n = K - k0 < 3 ? K - k0 : 3;
+    for (int k0 = 0; k0 < K; k0 += BT) {
+      const int n = K - k0 < BT ? K - k0 : BT;
       asm volatile("" ::: "memory");
       raw_barrier();                                  // batch k0's input rows are transformed; the entry after it has landed
       asm volatile("" ::: "memory");
@@ -1885,9 +1888,9 @@ static int c3wp_launch(const mds_conv_wgrad_args* a, const int (&tapw)[9], mds_s
   const int pcw = (PIECES + NPW - 1) / NPW;
   int RA = (100 * 1024 + ROWB - 1) / ROWB;      // rows in flight: the ring is the whole LDS (a batch dips it by three rows)
   while (RA > 3 && pcw * (RA - 1) > 40) --RA;
-  int NR = RA + 8;
+  int NR = RA + 2 * C3WP_BATCH + 2;      // the batch being consumed + the one being transformed + the entry above / below
   const size_t lds_cap = 158 * 1024;
-  while ((size_t)NR * ROWB > lds_cap && RA > 3) { --RA; NR = RA + 8; }
+  while ((size_t)NR * ROWB > lds_cap && RA > 3) { --RA; NR = RA + 2 * C3WP_BATCH + 2; }
   if ((size_t)NR * ROWB > lds_cap || pcw * (RA - 1) > 40) return 0;
   g.RA = RA; g.NR = NR;
   int CUS = 256;
