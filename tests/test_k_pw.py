@@ -342,7 +342,7 @@ def test_pw_fwd_filter_resident(be, force_filter_resident, dt, M, K, N, res, sta
     (200, 704, 192, True, False, 1),     # 11 chunks, two n-tiles, residual, PLAIN post statistics
     (130, 1096, 144, False, False, 3),   # K % 64 != 0, ragged n-tile, SILU post statistics
 ])
-def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken, frag=False):
+def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken, frag=False, form=0):
     code, tdt = DT[dt]
     g_ = torch.Generator().manual_seed(M + 3 * K + post)
     rpg = 41
@@ -363,9 +363,9 @@ def _run_pw_plain(be, dt, M, K, N, res, stats, post, check_taken, frag=False):
     if frag:
         kw["w_frag"] = _frag_pack(be, w, io=True)
     be.call("pw_fwd", cabi.make("mds_pw_fwd_args", dtype=code, M=M, K=K, N=N, x=be.t(x), w=be.t(w), y=out, pro=cabi.pro(0),
-                                residual=be.t(r) if res else None, stats=st if stats else None, **kw))
+                                residual=be.t(r) if res else None, stats=st if stats else None, form=form, **kw))
     be.sync()
-    if frag and post:
+    if frag and post and form != 1:
         assert int((st.abs().sum((1, 2)) > 0).sum()) <= -(-M // 64), "the K-streaming kernel was not taken"
     v = x.float() @ w.float().t() + (r.float() if res else 0.0)
     if check_taken and (stats or post) and M > 640:   # this kernel adds into 8 + 1 statistic slots (8 blocks per n-tile), the general one into M/64 + 1
@@ -497,6 +497,14 @@ def test_pw_fwd_kstream_tile_rows(be, force_kstream, bm, M, K, N, mode):
 ])
 def test_pw_fwd_kstream_data_gradient(be, force_kstream, M, K, N, res, post):
     _run_pw_plain(be, "bf16", M, K, N, res, False, post, False, frag=True)
+
+
+@pytest.mark.parametrize("form,res,post", [(2, False, 0), (2, True, 2), (1, True, 0), (1, False, 0)])
+def test_pw_fwd_form_field_decides_what_the_kstream_kernel_sees(be, force_kstream, form, res, post):
+    """mds_pw_fwd_args.form: the planner's own forward / data-gradient flag instead of inferring it from the operands - a
+    data gradient without residual and post sums still takes the data-gradient tiles, a FORWARD launch with a fused residual is not
+    mistaken for one (it goes to the general kernel); every combination gives the same numbers"""
+    _run_pw_plain(be, "bf16", 300, 1152, 192, res, False, post, False, frag=True, form=form)
 
 
 # ------------------------------------------------------------------------------------------------ linear form of BatchNorm backward
