@@ -273,9 +273,10 @@ class StreamPredictor:
         n = frames.shape[0]
         with torch.cuda.device(dev) if dev.type == "cuda" else _Null():
             results, ready = [], []
-            # steps still in flight on other lanes read back to 2 * offset frames behind their first frame: a slot written now
-            # must not hold a frame that young (the rings are sized for it - _size_rings; this is the check)
-            oldest_live = first_index - (self.in_flight if self._pipe is not None else 0) - 2 * self._predict_offset
+            # the steps still in flight on the OTHER lanes (at most in_flight - n frames of them) read back to 2 * offset frames behind
+            # their first frame: a slot written now must not hold a frame that young (the rings are sized for it - _size_rings;
+            # this is the check)
+            oldest_live = first_index - (max(0, self.in_flight - n) if self._pipe is not None else 0) - 2 * self._predict_offset
             for j in range(n):
                 index = first_index + j
                 slot = index % self.nframes

@@ -295,11 +295,11 @@ def test_stream_predictor_at_the_real_frame_size(tta):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tta,chunk,lanes", [(False, 1, 4), (True, 1, 4), (False, 5, 4), (False, 1, 3), (False, 5, 3), (False, 3, 2),
-                                             (False, 8, 3), (True, 8, 3)])
+                                             (False, 8, 3), (True, 8, 3), (False, 20, 2), (False, 16, 3)])
 def test_predict_stream_lanes_over_several_ring_periods(tta, chunk, lanes):
     """predict_stream with 2 - 4 lanes in flight (the ring periods are multiples of 4, not of 3: a slot pattern then comes back
-    on ANOTHER lane) over a stream long enough to wrap the raw-frame ring (165 slots) and the feature
-    store (216 slots) more than twice, every frame distinct: a ring update or an encoder pass of a later step overtaking a
+    on ANOTHER lane) over a stream long enough to wrap the raw-frame ring (69 slots while lanes x chunk <= 32; grown on the first
+    call that needs more in flight: the (20, 2) and (16, 3) cases) and the feature store many times, every frame distinct: a ring update or an encoder pass of a later step overtaking a
     reader on another lane, or a tail pass that did not wait for an encoder pass on another lane, shows up as a mismatch
     against the same frames through plain predict_batch calls on one stream (identical kernels: the bar is 1e-5)."""
     kw = dict(orc.BASIC_CONFIG_KWARGS, drop_rate=0.0, drop_path_rate=0.0)
@@ -319,6 +319,7 @@ def test_predict_stream_lanes_over_several_ring_periods(tta, chunk, lanes):
     sp = StreamPredictor(prod, frame_size=size, tta=tta)
     got = list(sp.predict_stream(iter(frames), 0, chunk=chunk, lanes=lanes))
     torch.cuda.synchronize()
+    assert sp.in_flight == max(sp.max_chunk, sp.lanes_in_use * chunk) and sp.nframes == 2 * sp.predict_offset + 1 + sp.in_flight + 8
     # one encoder pass per chunk in steady state; the start of the stream costs extra passes (the first complete windows are run
     # frame by frame - 5 new stacks each - and the stacks of frames before the first window are encoded when first needed)
     assert len(got) == len(want) == n and sp.encoder_passes <= -(-n // chunk) + 8 + 3 * chunk
