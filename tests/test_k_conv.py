@@ -450,7 +450,8 @@ def test_k_c3_at_the_training_sizes_against_k_conv(be_gpu, H, W, Cin, Cout, stri
     """BASELINE config 2's own layer sizes (the sizes the row-streaming kernels are dispatched at without a knob): forward output +
     forward statistics and the weight gradient from k_c3.hip against k_conv.hip's kernels (MDS_KNOB_C3 = 1) on the same tensors.
     Both are bf16 MFMA paths with fp32 accumulation: outputs agree to bf16 rounding, sums to their fp32 partial-sum order."""
-    be, N = be_gpu, 20
+    import os
+    be, N = be_gpu, int(os.environ.get("MDS_TEST_IMAGES", "20"))      # (20 = batch 4; 5 / 10 / 15 - other item and block counts - were run by hand: profiles/r06_other_batch_sizes.txt)
     code, tdt = DT["bf16"]
     g = torch.Generator(device=be.device).manual_seed(H + Cin + stride)
     x = torch.randn(N, H, W, Cin, device=be.device, generator=g).to(tdt)
