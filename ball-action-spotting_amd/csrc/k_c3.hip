@@ -1951,9 +1951,238 @@ static int c3w_launch(const mds_conv_wgrad_args* a, const int (&tapw)[9], mds_st
   return 1;
 }
 
+// The same for a STRIDE-2 layer (TF-SAME, even extents: blocks.2.0, 32 -> 128): dw[co][ci][ky][kx] += sum dy[r][x][co] in[2 r + ky][2 x + kx][ci].
+// A ring entry is dy row r of a 32-column band with ITS two input rows 2 r and 2 r + 1 (65 pixels each): the even row meets dy row r
+// (ky = 0) and dy row r - 1 (ky = 2, from the entry before - no look-ahead), the odd row meets dy row r (ky = 1); an item ends with one
+// more entry that carries only the even row 2 r1.  Fragment lane (pixel) p reads input pixel 2 p + kx: a 2-way bank conflict
+// whatever the chunk rotation (the pixel stride is half the bank period), on a kernel that moves 18 KB per 18 MFMAs per wave.
+template <int NPW>
+__global__ __launch_bounds__(64 * (8 + NPW)) void c3w2_kernel(C3WArgs g) {      // g.H, g.W: input extents; the dy tensor is H / 2 x W / 2
+  constexpr int CIN = 32, CI = 2, COP = 128, NCW = 8, PPX = 4, PPY = 16, WB = 32;
+  constexpr int XS = (2 * WB + 1) * PPX, XSP = (XS + 63) / 64 * 64, YS = WB * PPY, RS = 2 * XSP + YS, PIECES = RS / 64, ROWB = RS * 16;
+  MDS_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = MDS_UNIFORM(tid >> 6);
+  const int G = gridDim.x, OH = g.H / 2, OW = g.W / 2;
+  const int c0 = blockIdx.y * COP;
+  int E = 0;
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, OH, it, WB);
+    E += im.r1 - im.r0 + 1;
+  }
+  if (wave >= NCW) {
+    // ------------------------------------------------------------------ DMA waves
+    MDS_SETPRIO(3);
+    const int pw = wave - NCW;
+    constexpr int PCWMAX = (PIECES + NPW - 1) / NPW;
+    const int pcw = (PIECES - pw + NPW - 1) / NPW;
+    int dcol[PCWMAX], eoff[PCWMAX];
+#pragma unroll
+    for (int j = 0; j < PCWMAX; ++j) {
+      const int sg_ = 64 * (pw + NPW * j) + lane;
+      const int reg = sg_ < XSP ? 0 : (sg_ < 2 * XSP ? 1 : 2), u = sg_ - reg * XSP;       // even input row | odd input row | dy row
+      if (reg < 2 && u < XS) {
+        const int p = u / PPX, t = u - p * PPX;
+        dcol[j] = p; eoff[j] = 16 * c3w_unrot<CI>(t >> 1, p) + 8 * (t & 1);
+      } else if (reg == 2) {
+        const int p = u / PPY, t = u - p * PPY;
+        dcol[j] = p; eoff[j] = 16 * c3w_unrot<PPY / 2>(t >> 1, p) + 8 * (t & 1);
+      } else {
+        dcol[j] = -(1 << 30); eoff[j] = 0;
+      }
+    }
+    const lds_t ring = lds_addr_of(smem);
+    int hit = blockIdx.x, hk = 0;
+    C3Item him = c3_item_h(g.nseg, g.nbands, g.rps, OH, hit < g.items ? hit : 0, WB);
+    int C = 0, hslot = 0;
+    const char* cur[PCWMAX];
+    unsigned step[PCWMAX];
+    auto open_item = [&]() {
+      const char* xrow0 = (const char*)g.x + ((long)him.n * g.H + 2 * him.r0) * g.W * CIN * 2;
+      const char* yrow0 = (const char*)(g.dy + c0) + ((long)him.n * OH + him.r0) * OW * g.Ctot * 2;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const int reg = 64 * (pw + NPW * j) < XSP ? 0 : (64 * (pw + NPW * j) < 2 * XSP ? 1 : 2);      // wave-uniform
+        const int gx = reg == 2 ? him.x0 + dcol[j] : 2 * him.x0 + dcol[j];
+        const bool ok = gx >= 0 && gx < (reg == 2 ? OW : g.W);
+        cur[j] = !ok ? (const char*)c3_zero_page
+                     : (reg == 2 ? yrow0 + (gx * g.Ctot + eoff[j]) * 2 : xrow0 + (long)reg * g.W * CIN * 2 + (gx * CIN + eoff[j]) * 2);
+        step[j] = ok ? (unsigned)(reg == 2 ? OW * g.Ctot * 2 : 2 * g.W * CIN * 2) : 0u;
+      }
+    };
+    open_item();
+    auto issue = [&]() {
+      const int R = him.r1 - him.r0, xe = 2 * (him.r0 + hk);
+      const bool eok = xe < g.H, ook = hk < R && xe + 1 < g.H, yok = hk < R;      // (the closing entry: the even row only; row H: the pad)
+      const lds_t dst = ring + (lds_t)(hslot * ROWB);
+      hslot = hslot + 1 == g.NR ? 0 : hslot + 1;
+#pragma unroll
+      for (int j = 0; j < PCWMAX; ++j) {
+        const int pi = pw + NPW * j;
+        if (pi < PIECES) {
+          const int reg = 64 * pi < XSP ? 0 : (64 * pi < 2 * XSP ? 1 : 2);
+          const char* src = (reg == 0 ? eok : (reg == 1 ? ook : yok)) ? cur[j] : (const char*)c3_zero_page;
+          if (dcol[j] > -(1 << 29)) glds16(src, dst + (lds_t)(pi * 1024));
+          cur[j] += step[j];
+        }
+      }
+      ++C;
+      if (++hk == R + 1) {
+        hk = 0; hit += G;
+        if (hit < g.items) { him = c3_item_h(g.nseg, g.nbands, g.rps, OH, hit, WB); open_item(); }
+      }
+    };
+    while (C < g.RA && C < E) issue();
+    int e0 = 0;
+    for (int it = blockIdx.x; it < g.items; it += G) {
+      const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, OH, it, WB);
+      const int K = im.r1 - im.r0 + 1;
+      for (int k0 = 0; k0 < K; k0 += 2) {
+        const int n = K - k0 < 2 ? K - k0 : 2;
+        wait_vm_dyn(pcw * (C - e0 - n));
+        raw_barrier();
+        e0 += n;
+        while (C < e0 + g.RA && C < E) issue();       // into slots of entries < e0 - n - 1 (ring: RA + 3)
+      }
+    }
+    raw_barrier();
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers: one 16-channel output fragment each
+  MDS_SETPRIO(2);
+  const int i = lane & 15, q = lane >> 4;
+  int xo[2][3][2][CI], yo[2];
+#pragma unroll
+  for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+          const int p = 2 * (4 * q + 16 * h + (i >> 2)) + kx;      // output pixel 4 q + 16 h + e <-> k index 8 q + 4 h + e (as c3w_kernel)
+          xo[ro][kx][h][c] = ro * XSP * 16 + p * PPX * 16 + c3w_rot<CI>(c, p) * 32 + 8 * (i & 3);
+        }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int p = 4 * q + 16 * h + (i >> 2);
+    yo[h] = 2 * XSP * 16 + p * PPY * 16 + c3w_rot<PPY / 2>(wave, p) * 32 + 8 * (i & 3);
+  }
+  f32x4 acc[9][CI];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int sp = 0, sc = 0;
+  for (int it = blockIdx.x; it < g.items; it += G) {
+    const C3Item im = c3_item_h(g.nseg, g.nbands, g.rps, OH, it, WB);
+    const int K = im.r1 - im.r0 + 1;
+    for (int k0 = 0; k0 < K; k0 += 2) {
+      const int n = K - k0 < 2 ? K - k0 : 2;
+      asm volatile("" ::: "memory");
+      raw_barrier();
+      asm volatile("" ::: "memory");
+      for (int k = k0; k < k0 + n; ++k) {
+        const char* const er = smem + sc * ROWB;
+        const char* const pr = smem + sp * ROWB;
+        auto frag = [&](const char* base, int o0, int o1) {
+          const u16x4 lo = lds_tr4((const bf16_t*)(base + o0)), hi = lds_tr4((const bf16_t*)(base + o1));
+          return (u16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        u16x8 ae[3][CI], ao[3][CI], bc, bp;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int c = 0; c < CI; ++c) ae[kx][c] = frag(er, xo[0][kx][0][c], xo[0][kx][1][c]);
+        if (k < K - 1) {                                   // (wave-uniform) a dy row of the item: its odd input row too
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < CI; ++c) ao[kx][c] = frag(er, xo[1][kx][0][c], xo[1][kx][1][c]);
+          bc = frag(er, yo[0], yo[1]);
+        }
+        if (k > 0) bp = frag(pr, yo[0], yo[1]);
+        if (k < K - 1) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < CI; ++c) { mma16(bc, ae[kx][c], acc[kx][c]); mma16(bc, ao[kx][c], acc[3 + kx][c]); }      // acc[r] = dw[co = 4 q + r][ci = i]
+        }
+        if (k > 0) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < CI; ++c) mma16(bp, ae[kx][c], acc[6 + kx][c]);
+        }
+        sp = sc; sc = sc + 1 == g.NR ? 0 : sc + 1;
+      }
+    }
+  }
+  asm volatile("" ::: "memory");
+  raw_barrier();
+  asm volatile("" ::: "memory");
+  constexpr int SLAB = CIN * 9;
+  float* const fl = (float*)smem + (wave & 3) * 16 * SLAB;
+  for (int rd = 0; rd < 2; ++rd) {
+    if ((wave >> 2) == rd) {
+      wave_lds_sync();
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CI; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fl[(4 * q + r) * SLAB + (16 * c + i) * 9 + g.tapw[t]] = acc[t][c][r];
+      wave_lds_sync();
+      float* const dst = g.dw + (long)(c0 + 16 * wave) * SLAB;
+      const int e0 = (int)((blockIdx.x * 37u) % (16 * SLAB / 64)) * 64;
+      for (int e = lane; e < 16 * SLAB; e += 64) { const int ee = e + e0 < 16 * SLAB ? e + e0 : e + e0 - 16 * SLAB; atomicAdd(dst + ee, fl[ee]); }
+    }
+    if (rd == 0) { wait_lgkm0(); raw_barrier(); }
+  }
+}
+
+static int c3w2_try(const mds_conv_wgrad_args* a, mds_stream_t stream) {
+  constexpr int NPW = 3, WB = 32, XSP = ((2 * WB + 1) * 4 + 63) / 64 * 64, RS = 2 * XSP + WB * 16, PIECES = RS / 64, ROWB = RS * 16;
+  if (a->Cin != 32 || a->Cout != 128 || a->pro.mode != MDS_PRO_NONE || (mds_knob(MDS_KNOB_C3_DBG) & 512)) return 0;
+  if (a->IH % 2 || a->IW % 2 || a->OH != a->IH / 2 || a->OW != a->IW / 2) return 0;
+  if ((long)a->IH * a->IW * a->Cin >= (1L << 30) || (long)a->OH * a->OW * a->Cout >= (1L << 30)) return 0;
+  int tapw[9];
+  for (int t = 0; t < 9; ++t) tapw[t] = -1;
+  for (int t = 0; t < 9; ++t) {
+    if (a->dy[t] < 0 || a->dy[t] > 2 || a->dx[t] < 0 || a->dx[t] > 2) return 0;
+    tapw[3 * a->dy[t] + a->dx[t]] = a->wi[t];
+  }
+  for (int t = 0; t < 9; ++t) if (tapw[t] < 0 || tapw[t] >= 9) return 0;
+  if ((long)a->N * a->OH * a->OW < 16384 && mds_knob(MDS_KNOB_C3) != 2) return 0;
+  C3WArgs g;
+  g.x = (const bf16_t*)a->x; g.dy = (const bf16_t*)a->dyt; g.dw = a->dw;
+  g.N = a->N; g.H = a->IH; g.W = a->IW; g.Ctot = a->Cout; g.wtaps = a->wtaps; g.pro_scale = nullptr; g.pro_shift = nullptr;
+  for (int t = 0; t < 9; ++t) g.tapw[t] = tapw[t];
+  const int pcw = (PIECES + NPW - 1) / NPW;
+  int RA = 5;
+  while (RA > 2 && ((size_t)(RA + 3) * ROWB > 158 * 1024 || pcw * (RA - 1) > 40)) --RA;
+  if ((size_t)(RA + 3) * ROWB > 158 * 1024) return 0;
+  g.RA = RA; g.NR = RA + 3;
+  int CUS = 256;
+  if (mds_knob(MDS_KNOB_CONV_BLOCKS) > 0) CUS = mds_knob(MDS_KNOB_CONV_BLOCKS);
+  g.nbands = cdiv(a->OW, WB);
+  long best = -1;
+  for (int ns = 1; ns <= 64 && ns <= a->OH; ++ns) {
+    const int rps = cdiv(a->OH, ns), nsr = cdiv(a->OH, rps);
+    const long items = (long)a->N * g.nbands * nsr;
+    const long per = (items + CUS - 1) / CUS;
+    const long cost = per * (rps + 1 + 2);
+    if (best < 0 || cost < best) { best = cost; g.nseg = nsr; g.rps = rps; g.items = (int)items; }
+  }
+  const int grid = g.items < CUS ? g.items : CUS;
+  MDS_LAUNCH((c3w2_kernel<NPW>), dim3(grid, 1), dim3(64 * (8 + NPW)), (size_t)g.NR * ROWB, stream, g);
+  return 1;
+}
+
 // mds_conv_wgrad's large prologue-free stride-1 bf16 launches; 1 = launched, 0 = not one of these (k_conv.hip's kernel)
 int c3w_try(const mds_conv_wgrad_args* a, mds_stream_t stream) {
   if (mds_knob(MDS_KNOB_C3) == 1 || (mds_knob(MDS_KNOB_C3_DBG) & 128)) return 0;
+  if (a->dtype == MDS_BF16 && a->is == 2 && a->ntaps == 9 && a->wtaps == 9) return c3w2_try(a, stream);
   const bool pro = a->pro.mode == MDS_PRO_BN_SILU;
   if (a->dtype != MDS_BF16 || a->is != 1 || a->ntaps != 9 || a->wtaps != 9 || (a->pro.mode != MDS_PRO_NONE && !pro)) return 0;
   if (pro && !(a->Cin == 32 && a->Cout == 16 && a->pro.scale && a->pro.shift && !(mds_knob(MDS_KNOB_C3_DBG) & 256))) return 0;

@@ -133,7 +133,7 @@ def kernel_family(name):
     if fn in ("c3_kernel", "c3t_kernel", "c3s_kernel"):      # k_c3.hip serves mds_conv_fwd launches and (its one-tap form: template argument ONE, the 11th) a few of mds_pw_fwd's
         targs = [t.strip() for t in name.split("<", 1)[1].split(">")[0].split(",")] if "<" in name else []
         return "pw_fwd" if fn == "c3_kernel" and len(targs) > 10 and targs[10] == "true" else "conv_fwd"
-    if fn in ("c3w_kernel", "c3wp_kernel"):    # ... and mds_conv_wgrad's stride-1 launches
+    if fn in ("c3w_kernel", "c3wp_kernel", "c3w2_kernel"):    # ... and mds_conv_wgrad's launches
         return "conv_wgrad"
     if fn == "se_bwd_b_table_kernel":          # the table form of se_bwd_b_kernel (one launch per gradient bucket)
         return "se_bwd_b"

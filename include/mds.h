@@ -68,7 +68,7 @@ const char* mds_last_error(void);
 #define MDS_KNOB_STEM_FWD 20       /* 1: the bf16 training stem forward takes the gather kernel instead of the LDS-tiled one (A/B) */
 #define MDS_KNOB_DW3G 21           /* 1: the 3x3x3 depthwise forward at T != 5 takes the LDS-tiled kernel instead of the time-chunked sliding window (A/B) */
 #define MDS_KNOB_C3 22             /* filter-in-registers 3x3 kernel (k_c3.hip): 0 = rule, 1 = never, 2 = every legal shape, any size (tests) */
-#define MDS_KNOB_C3_DBG 23         /* ablation bits of k_c3.hip (measurement only): 1 no output stores, 2 no MFMAs, 4 no LDS-DMA, 8 no fragment reads, 16 the other helper-wave split, 32 no prologue form, 64 no stride-2 forward, 128 no row-streaming weight gradient, 256 not for the layer behind the prologue */
+#define MDS_KNOB_C3_DBG 23         /* ablation bits of k_c3.hip (measurement only): 1 no output stores, 2 no MFMAs, 4 no LDS-DMA, 8 no fragment reads, 16 the other helper-wave split, 32 no prologue form, 64 no stride-2 forward, 128 no row-streaming weight gradient, 256 not for the layer behind the prologue, 512 no stride-2 weight gradient */
 #define MDS_KNOB_C3_BWD_BLOCKS 24   /* blocks of k_c3.hip's data-gradient launches (0 = rule): fewer than the CU count leaves CUs to the weight-gradient stream */
 #define MDS_KNOB_COUNT 25
 int mds_dev_set(int knob, int value);

@@ -435,6 +435,19 @@ def test_c3w_weight_gradient_behind_the_prologue(be, N, H, W, blocks):
         be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
 
 
+@pytest.mark.parametrize("N,H,W,blocks", [(2, 12, 128, 0), (1, 22, 40, 2), (1, 2, 64, 1), (1, 30, 200, 3)])
+def test_c3w2_stride2_weight_gradient(be, N, H, W, blocks):
+    """blocks.2.0's weight gradient (32 -> 128, stride 2, TF-SAME pads 0 / 1): a ring entry = a dy row with its two input rows, the even
+    row also meets the dy row above (ky = 2), pixel-stride-2 transposing reads, one closing entry per item - against autograd"""
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 2), "dev_set")
+    be.lib.check(be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, blocks), "dev_set")
+    try:
+        test_conv_wgrad(be, "bf16", N, H, W, 32, 128, 2, 0)
+    finally:
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_C3, 0)
+        be.lib.fn["dev_set"](cabi.MDS_KNOB_CONV_BLOCKS, 0)
+
+
 TRAIN_LAYERS = [  # the 3x3 layers of the benchmarked step (20 images): H, W, Cin, Cout, stride, prologue
     (368, 640, 32, 16, 1, 2),       # blocks.0.0 (behind the stem's BatchNorm + SiLU)
     (368, 640, 16, 64, 2, 2),       # blocks.1.0 first convolution (behind blocks.0.0's)

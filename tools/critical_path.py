@@ -46,7 +46,7 @@ def family_us(path):
     fam = {}
     if not path or not os.path.exists(path):
         return fam
-    pats = [("pw_wgrad", r"pw_wgrad"), ("conv_wgrad", r"conv_wgrad|c3wp?_kernel"), ("se_fc_bwd_params_table", r"se_bwd_b_table_kernel"), ("se_fc_bwd_params", r"se_bwd_b_kernel"), ("se_fc_bwd_data", r"se_bwd_a_kernel"),
+    pats = [("pw_wgrad", r"pw_wgrad"), ("conv_wgrad", r"conv_wgrad|c3w[p2]?_kernel"), ("se_fc_bwd_params_table", r"se_bwd_b_table_kernel"), ("se_fc_bwd_params", r"se_bwd_b_kernel"), ("se_fc_bwd_data", r"se_bwd_a_kernel"),
             ("bn_bwd_apply", r"bn_bwd_apply"), ("bn_bwd_reduce", r"bn_bwd_reduce"), ("bn_bwd_finalize", r"bn_bwd_finalize"), ("bn_finalize", r"bn_finalize"),
             ("pw_fwd", r"pw_fwd|pwk"), ("conv_fwd", r"conv_fwd|c3[st]?_kernel"), ("dw_bwd", r"dw\w*_bwd"), ("dw_fwd", r"dw\w*_fwd"),
             ("se_bwd_reduce", r"se_bwd_reduce"), ("bn_res", r"bn_res"), ("se_pool", r"se_pool"), ("se_fc_fwd", r"se_fc_fwd|se_fwd"),
